@@ -1,0 +1,201 @@
+/*
+ * oracle/linalg.c -- TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * Dense P x P helpers standing in for the Armadillo calls on the hot path
+ * (third-party, absent from /root/reference; RcppArmadillo is unversioned in DESCRIPTION:11):
+ *   arma::inv     UpdatePhi.h:79, UpdateXi.h:80
+ *   arma::pinv    UpdateNu.h:67,  UpdateEta.h:85
+ *   arma::mvnrnd  UpdateNu.h:69, UpdatePhi.h:82, UpdateEta.h:87, UpdateXi.h:83
+ * All matrices are column-major.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define A_(i, j) A[(i) + (size_t)P * (j)]
+#define L_(i, j) L[(i) + (size_t)P * (j)]
+
+int orc_chol_lower(int P, const double* A, double* L) {
+  memset(L, 0, sizeof(double) * (size_t)P * P);
+  for (int j = 0; j < P; ++j) {
+    double s = A_(j, j);
+    for (int k = 0; k < j; ++k) s -= L_(j, k) * L_(j, k);
+    if (!(s > 0.0)) return 1;
+    double ljj = sqrt(s);
+    L_(j, j) = ljj;
+    for (int i = j + 1; i < P; ++i) {
+      double t = A_(i, j);
+      for (int k = 0; k < j; ++k) t -= L_(i, k) * L_(j, k);
+      L_(i, j) = t / ljj;
+    }
+  }
+  return 0;
+}
+
+static int is_symmetric(int P, const double* A) {
+  for (int j = 0; j < P; ++j)
+    for (int i = j + 1; i < P; ++i) {
+      double a = A_(i, j), b = A_(j, i);
+      double tol = 100.0 * 2.220446049250313e-16 * fmax(fabs(a), fabs(b));
+      if (fabs(a - b) > tol) return 0;
+    }
+  return 1;
+}
+
+static int inv_lu(int P, double* A) {
+  /* Gauss-Jordan with partial pivoting */
+  double* W = (double*)malloc(sizeof(double) * (size_t)P * 2 * P);
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) {
+      W[i * 2 * P + j] = A_(i, j);
+      W[i * 2 * P + P + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < P; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < P; ++r)
+      if (fabs(W[r * 2 * P + c]) > fabs(W[piv * 2 * P + c])) piv = r;
+    if (W[piv * 2 * P + c] == 0.0) { free(W); return 1; }
+    if (piv != c)
+      for (int j = 0; j < 2 * P; ++j) {
+        double t = W[c * 2 * P + j]; W[c * 2 * P + j] = W[piv * 2 * P + j]; W[piv * 2 * P + j] = t;
+      }
+    double d = 1.0 / W[c * 2 * P + c];
+    for (int j = 0; j < 2 * P; ++j) W[c * 2 * P + j] *= d;
+    for (int r = 0; r < P; ++r) {
+      if (r == c) continue;
+      double f = W[r * 2 * P + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < 2 * P; ++j) W[r * 2 * P + j] -= f * W[c * 2 * P + j];
+    }
+  }
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) A_(i, j) = W[i * 2 * P + P + j];
+  free(W);
+  return 0;
+}
+
+/* arma::inv(M, M): Armadillo tries a Cholesky-based inverse when the matrix looks symmetric
+ * positive definite and falls back to LU otherwise; same here. */
+int orc_inv(int P, double* A) {
+  if (is_symmetric(P, A)) {
+    double* L = (double*)malloc(sizeof(double) * (size_t)P * P);
+    if (orc_chol_lower(P, A, L) == 0) {
+      /* invert L (lower) in place into Li, then A^-1 = Li' Li */
+      double* Li = (double*)calloc((size_t)P * P, sizeof(double));
+      for (int j = 0; j < P; ++j) {
+        Li[j + (size_t)P * j] = 1.0 / L_(j, j);
+        for (int i = j + 1; i < P; ++i) {
+          double s = 0.0;
+          for (int k = j; k < i; ++k) s += L_(i, k) * Li[k + (size_t)P * j];
+          Li[i + (size_t)P * j] = -s / L_(i, i);
+        }
+      }
+      for (int i = 0; i < P; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double s = 0.0;
+          for (int k = i; k < P; ++k) s += Li[k + (size_t)P * i] * Li[k + (size_t)P * j];
+          A_(i, j) = s;
+          A_(j, i) = s;
+        }
+      free(Li);
+      free(L);
+      return 0;
+    }
+    free(L);
+  }
+  return inv_lu(P, A);
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric matrix: A = V diag(w) V' */
+static void jacobi_eig(int P, double* A, double* V, double* w) {
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) V[i + (size_t)P * j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int j = 0; j < P; ++j) {
+      diag += A_(j, j) * A_(j, j);
+      for (int i = 0; i < j; ++i) off += A_(i, j) * A_(i, j);
+    }
+    if (off <= 1e-60 || off <= 1e-32 * diag) break;
+    for (int p = 0; p < P - 1; ++p)
+      for (int q = p + 1; q < P; ++q) {
+        double apq = A_(p, q);
+        if (apq == 0.0) continue;
+        double app = A_(p, p), aqq = A_(q, q);
+        double theta = (aqq - app) / (2.0 * apq);
+        double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < P; ++k) {
+          double akp = A_(k, p), akq = A_(k, q);
+          A_(k, p) = cs * akp - sn * akq;
+          A_(k, q) = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < P; ++k) {
+          double apk = A_(p, k), aqk = A_(q, k);
+          A_(p, k) = cs * apk - sn * aqk;
+          A_(q, k) = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < P; ++k) {
+          double vkp = V[k + (size_t)P * p], vkq = V[k + (size_t)P * q];
+          V[k + (size_t)P * p] = cs * vkp - sn * vkq;
+          V[k + (size_t)P * q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < P; ++i) w[i] = A_(i, i);
+}
+
+/* arma::pinv(B_1) for the symmetric matrices of UpdateNu.h:67 / UpdateEta.h:85:
+ * Moore-Penrose inverse through the spectral decomposition, Armadillo's default
+ * tolerance max(m,n) * max singular value * eps. */
+void orc_pinv_sym(int P, double* A) {
+  double* S = (double*)malloc(sizeof(double) * (size_t)P * P);
+  double* V = (double*)malloc(sizeof(double) * (size_t)P * P);
+  double* w = (double*)malloc(sizeof(double) * (size_t)P);
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) S[i + (size_t)P * j] = 0.5 * (A_(i, j) + A_(j, i));
+  jacobi_eig(P, S, V, w);
+  double wmax = 0.0;
+  for (int i = 0; i < P; ++i) wmax = fmax(wmax, fabs(w[i]));
+  const double tol = (double)P * wmax * 2.220446049250313e-16;
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < P; ++k)
+        if (fabs(w[k]) > tol) s += V[i + (size_t)P * k] * V[j + (size_t)P * k] / w[k];
+      A_(i, j) = s;
+    }
+  free(S); free(V); free(w);
+}
+
+/* arma::mvnrnd(mean, C): chol(C) (upper R, R'R = C), out = R' z + mean, z ~ N(0, I) drawn in
+ * index order; if the Cholesky factorisation fails Armadillo falls back to the symmetric
+ * eigen-decomposition, out = V sqrt(max(w,0)) z + mean. */
+void orc_mvnrnd(const orc_rng* r, uint32_t upd, uint32_t idx0, int P,
+                const double* mean, const double* C, double* out) {
+  double* L = (double*)malloc(sizeof(double) * (size_t)P * P);
+  double* z = (double*)malloc(sizeof(double) * (size_t)P);
+  for (int p = 0; p < P; ++p) z[p] = orc_rnorm(r, upd, idx0 + (uint32_t)p);
+  if (orc_chol_lower(P, C, L) == 0) {
+    for (int i = 0; i < P; ++i) {
+      double s = mean[i];
+      for (int k = 0; k <= i; ++k) s += L_(i, k) * z[k];
+      out[i] = s;
+    }
+  } else {
+    double* S = (double*)malloc(sizeof(double) * (size_t)P * P);
+    double* V = (double*)malloc(sizeof(double) * (size_t)P * P);
+    double* w = (double*)malloc(sizeof(double) * (size_t)P);
+    for (int i = 0; i < P; ++i)
+      for (int j = 0; j < P; ++j) S[i + (size_t)P * j] = 0.5 * (C[i + (size_t)P * j] + C[j + (size_t)P * i]);
+    jacobi_eig(P, S, V, w);
+    for (int i = 0; i < P; ++i) {
+      double s = mean[i];
+      for (int k = 0; k < P; ++k) s += V[i + (size_t)P * k] * sqrt(fmax(w[k], 0.0)) * z[k];
+      out[i] = s;
+    }
+    free(S); free(V); free(w);
+  }
+  free(L); free(z);
+}
