@@ -1,0 +1,609 @@
+// C ABI of the sampler (include/bfmmm.h): handle management, state marshalling between the
+// reference's column-major layouts and the device layout, iteration driver with HIP-graph replay.
+#include "../../include/bfmmm.h"
+#include "model.hpp"
+#include "rng.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace bfmmm {
+int launch_stats_functional(int degree, int n, int P, int LREC, const int64_t* off, const double* t, const double* y,
+                            const double* knots, int n_knots, double* rec, int* ni, double* B_dense, int* err,
+                            hipStream_t st);
+void launch_stats_multivariate(int n, int P, int LREC, const double* Y, double* rec, int* ni, hipStream_t st);
+void launch_stats_totals(int n, int LREC, int yy_off, const double* rec, const int* ni, double* out_yy,
+                         long long* out_counts, hipStream_t st);
+int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st);
+int curve_blocks(int n, int P);
+void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st);
+void launch_factor(const Ctx& c, hipStream_t st);
+void launch_sweep(const Ctx& c, hipStream_t st);
+void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
+void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
+}  // namespace bfmmm
+
+using namespace bfmmm;
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) { g_err = msg; return 1; }
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) {                                                                         \
+      char buf_[512];                                                                               \
+      snprintf(buf_, sizeof buf_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); \
+      return fail(buf_);                                                                            \
+    }                                                                                               \
+  } while (0)
+
+enum { FAM_TOTAL = 0, FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK, FAM_COUNT };
+static const char* kFamNames[FAM_COUNT] = {"total", "curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik"};
+
+struct bfmmm_handle {
+  bfmmm_config cfg;
+  int device = 0;
+  hipStream_t st = nullptr;
+  Ctx c;                       // template context (full MD)
+  int T = 0;
+  int64_t n_obs = 0;
+  // raw inputs kept on the device for bfmmm_get_basis
+  double* d_t = nullptr; double* d_y = nullptr; int64_t* d_off = nullptr; double* d_knots = nullptr; int n_knots = 0;
+  std::vector<void*> allocs;
+  size_t pg_part_doubles = 0;
+  // graph cache for the last (mask, md, seed, chain)
+  hipGraphExec_t gexec = nullptr;
+  uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
+  int last_md = -1;
+  int profile = 0;
+  double fam_ms[FAM_COUNT] = {0};
+  int64_t fam_launches[FAM_COUNT] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <typename T>
+static int dalloc(bfmmm_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHK(hipMalloc(&q, bytes));
+  HIPCHK(hipMemset(q, 0, bytes));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+extern "C" void bfmmm_config_defaults(bfmmm_config* cfg) {
+  // defaults of BFMMM_Nu_Z_multiple_try / BFMMM_Theta_est / BFMMM_warm_start
+  // (UserFunctions.cpp:178-193, 697-715, 1353-1378)
+  memset(cfg, 0, sizeof *cfg);
+  for (int k = 0; k < 8; ++k) cfg->c[k] = 10.0;
+  cfg->b = 10; cfg->nu_1 = 3;
+  cfg->alpha1l = 1; cfg->alpha2l = 2; cfg->beta1l = 1; cfg->beta2l = 1;
+  cfg->a_Z_PM = 10000; cfg->a_pi_PM = 1000; cfg->var_alpha3 = 0.05; cfg->var_epsilon1 = 1; cfg->var_epsilon2 = 1;
+  cfg->alpha_nu = 10; cfg->beta_nu = 1; cfg->alpha_eta = 10; cfg->beta_eta = 1; cfg->alpha_0 = 1; cfg->beta_0 = 1;
+}
+
+extern "C" const char* bfmmm_last_error(void) { return g_err.c_str(); }
+
+// dims that depend on how many mt-directions are active
+static void set_md(Dims& d, int MD) {
+  d.MD = MD;
+  d.A = d.K * MD;
+  d.NZZ = d.K * (d.K + 1) / 2;
+  d.NCC = MD * (MD + 1) / 2;
+  d.R = d.NZZ * d.NCC;
+  d.RT = (d.R + 15) / 16;
+  d.AT = (d.A + 15) / 16;
+  d.CTG = (d.LG + 15) / 16;
+  d.CTS = (d.P + 15) / 16;
+  d.NT = d.RT * d.CTG + d.AT * d.CTS;
+}
+
+static void pg_geometry(const Dims& d, int& NTG, int& NKS, int& KS) {
+  NKS = std::max(1, std::min(32, d.n / 16));
+  KS = (d.n + NKS - 1) / NKS;
+  KS = (KS + 3) / 4 * 4;
+  NKS = (d.n + KS - 1) / KS;
+  NTG = std::max(1, std::min(d.NT, 256 / NKS));
+}
+
+extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                            const double* internal_knots, const double* boundary_knots, bfmmm_handle** out) {
+  if (!cfg || !out || !y) return fail("bfmmm_create: null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail("bfmmm_create: no HIP device available (the sampler has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail("bfmmm_create: invalid device index");
+  const bool mv = cfg->model == BFMMM_MODEL_MULTIVARIATE;
+  const int n = cfg->n_funct, K = cfg->K, M = cfg->n_eigen;
+  if (n < 1) return fail("'n_funct' must be an integer greater than or equal to 1");
+  if (K < 2) return fail("'K' must be an integer greater than or equal to 2");
+  if (K > KMAX) return fail("K larger than 6 is not supported by this build");
+  if (M < 1) return fail("'n_eigen' must be an integer greater than or equal to 1");
+  if (cfg->tot_mcmc_iters < 1) return fail("'tot_mcmc_iters' must be positive");
+  int P, BW;
+  if (mv) {
+    P = cfg->P; BW = 0;
+    if (P < 1) return fail("multivariate model: P must be positive");
+  } else {
+    if (!t || !offsets || !boundary_knots || (cfg->n_internal_knots > 0 && !internal_knots))
+      return fail("bfmmm_create: null argument");
+    if (cfg->basis_degree < 1) return fail("'basis_degree' must be an integer greater than or equal to 1");
+    if (cfg->basis_degree > BWMAX) return fail("basis_degree larger than 5 is not supported by this build");
+    for (int i = 0; i < cfg->n_internal_knots; ++i) {
+      if (boundary_knots[0] >= internal_knots[i])
+        return fail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+      if (boundary_knots[1] <= internal_knots[i])
+        return fail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+    }
+    P = cfg->n_internal_knots + cfg->basis_degree + 1;
+    BW = std::min(cfg->basis_degree, P - 1);
+  }
+  if (P > PMAX) return fail("P larger than 64 is not supported by this build");
+
+  HIPCHK(hipSetDevice(device));
+  bfmmm_handle* h = new bfmmm_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  h->T = cfg->tot_mcmc_iters;
+  HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  Ctx& c = h->c;
+  memset(&c, 0, sizeof c);
+  Dims& d = c.d;
+  d.n = n; d.K = K; d.P = P; d.M = M; d.D = 0; d.BW = BW; d.LG = (BW + 1) * P;
+  d.LREC = (d.LG + P + 1 + 1) / 2 * 2;
+  d.mv = mv ? 1 : 0;
+  set_md(d, M + 1);
+  for (int k = 0; k < KMAX; ++k) c.h.c[k] = (k < 8) ? cfg->c[k] : 10.0;
+  c.h.b = cfg->b; c.h.nu_1 = cfg->nu_1;
+  c.h.alpha1l = cfg->alpha1l; c.h.alpha2l = cfg->alpha2l; c.h.beta1l = cfg->beta1l; c.h.beta2l = cfg->beta2l;
+  c.h.a_Z_PM = cfg->a_Z_PM; c.h.a_pi_PM = cfg->a_pi_PM; c.h.var_alpha3 = cfg->var_alpha3;
+  c.h.var_epsilon1 = cfg->var_epsilon1; c.h.var_epsilon2 = cfg->var_epsilon2;
+  c.h.alpha_nu = cfg->alpha_nu; c.h.beta_nu = cfg->beta_nu; c.h.alpha_eta = cfg->alpha_eta; c.h.beta_eta = cfg->beta_eta;
+  c.h.alpha_0 = cfg->alpha_0; c.h.beta_0 = cfg->beta_0;
+  c.T = h->T;
+  c.nblk_curve = curve_blocks(n, P);
+
+  const int64_t n_obs = mv ? (int64_t)n * P : offsets[n];
+  h->n_obs = n_obs;
+  // ---- device buffers ----
+  double* rec; int* ni;
+  if (dalloc(h, &rec, (size_t)n * d.LREC) || dalloc(h, &ni, n)) return 1;
+  c.rec = rec; c.ni = ni;
+  if (dalloc(h, &c.dyn, 1)) return 1;
+  if (dalloc(h, &c.Z, (size_t)n * K) || dalloc(h, &c.chi, (size_t)n * M) || dalloc(h, &c.theta, (size_t)K * (M + 1) * P) ||
+      dalloc(h, &c.delta, (size_t)K * M) || dalloc(h, &c.Aa, (size_t)K * 2) || dalloc(h, &c.gamma, (size_t)K * P * M))
+    return 1;
+  int NTG, NKS, KS;
+  pg_geometry(d, NTG, NKS, KS);
+  h->pg_part_doubles = (size_t)NKS * d.NT * 256;
+  if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
+      dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.Lmat, (size_t)d.A * P * P))
+    return 1;
+  double* pm;
+  if (dalloc(h, &pm, (size_t)P * P)) return 1;
+  c.Pmat = pm;
+  {
+    // RW1 penalty, BFMMM.h:1027-1037
+    std::vector<double> Pm((size_t)P * P, 0.0);
+    for (int j = 0; j < P; ++j) {
+      Pm[0] = 1;
+      if (j > 0) { Pm[j + (size_t)P * j] = 2; Pm[(j - 1) + (size_t)P * j] = -1; Pm[j + (size_t)P * (j - 1)] = -1; }
+      Pm[(P - 1) + (size_t)P * (P - 1)] = 1;
+    }
+    HIPCHK(hipMemcpy(pm, Pm.data(), sizeof(double) * Pm.size(), hipMemcpyHostToDevice));
+  }
+  const size_t T = (size_t)h->T;
+  if (dalloc(h, &c.c_nu, T * K * P) || dalloc(h, &c.c_chi, T * n * M) || dalloc(h, &c.c_Z, T * n * K) ||
+      dalloc(h, &c.c_pi, T * K) || dalloc(h, &c.c_alpha3, T) || dalloc(h, &c.c_delta, T * K * M) ||
+      dalloc(h, &c.c_A, T * K * 2) || dalloc(h, &c.c_sigma, T) || dalloc(h, &c.c_tau, T * K) ||
+      dalloc(h, &c.c_gamma, T * K * P * M) || dalloc(h, &c.c_Phi, T * K * P * M) || dalloc(h, &c.c_loglik, T))
+    return 1;
+
+  // ---- upload data, compute statistics on the device ----
+  if (dalloc(h, &h->d_y, (size_t)n_obs)) return 1;
+  HIPCHK(hipMemcpy(h->d_y, y, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
+  int* d_err;
+  if (dalloc(h, &d_err, 1)) return 1;
+  if (mv) {
+    launch_stats_multivariate(n, P, d.LREC, h->d_y, rec, ni, h->st);
+  } else {
+    const int deg = cfg->basis_degree, nint = cfg->n_internal_knots;
+    h->n_knots = nint + 2 * (deg + 1);
+    std::vector<double> knots(h->n_knots);
+    for (int i = 0; i <= deg; ++i) knots[i] = boundary_knots[0];
+    for (int i = 0; i < nint; ++i) knots[deg + 1 + i] = internal_knots[i];
+    for (int i = 0; i <= deg; ++i) knots[deg + 1 + nint + i] = boundary_knots[1];
+    if (dalloc(h, &h->d_t, (size_t)n_obs) || dalloc(h, &h->d_off, (size_t)n + 1) || dalloc(h, &h->d_knots, h->n_knots))
+      return 1;
+    HIPCHK(hipMemcpy(h->d_t, t, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_off, offsets, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_knots, knots.data(), sizeof(double) * knots.size(), hipMemcpyHostToDevice));
+    if (launch_stats_functional(deg, n, P, d.LREC, h->d_off, h->d_t, h->d_y, h->d_knots, h->n_knots, rec, ni, nullptr,
+                                d_err, h->st))
+      return fail("unsupported basis_degree");
+  }
+  double* d_yy; long long* d_cnt;
+  if (dalloc(h, &d_yy, 1) || dalloc(h, &d_cnt, 2)) return 1;
+  launch_stats_totals(n, d.LREC, d.LG + P, rec, ni, d_yy, d_cnt, h->st);
+  HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipGetLastError());
+  int herr = 0; long long cnt[2];
+  HIPCHK(hipMemcpy(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&c.YY, d_yy, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+  if (herr) { bfmmm_destroy(h); return fail("at least one time point lies outside 'boundary_knots'"); }
+  d.n_obs_total = cnt[0];
+  d.half_sum = cnt[1];
+  // neutral starting state (everything 1 / 0) so that a run before set_state is well defined
+  Dyn dyn0;
+  memset(&dyn0, 0, sizeof dyn0);
+  dyn0.beta = 1; dyn0.sigma2 = 1; dyn0.alpha3 = 1;
+  for (int k = 0; k < KMAX; ++k) { dyn0.pi[k] = 1.0 / K; dyn0.tau[k] = 1; }
+  HIPCHK(hipMemcpy(c.dyn, &dyn0, sizeof dyn0, hipMemcpyHostToDevice));
+  *out = h;
+  return 0;
+}
+
+extern "C" void bfmmm_destroy(bfmmm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->st) (void)hipStreamDestroy(h->st);
+  delete h;
+}
+
+extern "C" int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity) {
+  if (!h || !out) return fail("bfmmm_get_basis: null argument");
+  const Dims& d = h->c.d;
+  if (d.mv) return fail("bfmmm_get_basis: the multivariate model has no basis");
+  const int64_t need = h->n_obs * d.P;
+  if (capacity < need) return fail("bfmmm_get_basis: buffer too small");
+  HIPCHK(hipSetDevice(h->device));
+  double* dB = nullptr; double* rec_tmp = nullptr; int* ni_tmp = nullptr; int* err = nullptr;
+  HIPCHK(hipMalloc((void**)&dB, sizeof(double) * (size_t)need));
+  HIPCHK(hipMalloc((void**)&rec_tmp, sizeof(double) * (size_t)d.n * d.LREC));
+  HIPCHK(hipMalloc((void**)&ni_tmp, sizeof(int) * (size_t)d.n));
+  HIPCHK(hipMalloc((void**)&err, sizeof(int)));
+  HIPCHK(hipMemset(err, 0, sizeof(int)));
+  launch_stats_functional(h->cfg.basis_degree, d.n, d.P, d.LREC, h->d_off, h->d_t, h->d_y, h->d_knots, h->n_knots,
+                          rec_tmp, ni_tmp, dB, err, h->st);
+  HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipMemcpy(out, dB, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
+  (void)hipFree(dB); (void)hipFree(rec_tmp); (void)hipFree(ni_tmp); (void)hipFree(err);
+  return 0;
+}
+
+// ---- state marshalling ----------------------------------------------------------------------
+static int dyn_get(bfmmm_handle* h, Dyn& dyn) {
+  HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipMemcpy(&dyn, h->c.dyn, sizeof dyn, hipMemcpyDeviceToHost));
+  return 0;
+}
+static int dyn_put(bfmmm_handle* h, const Dyn& dyn) {
+  HIPCHK(hipMemcpy(h->c.dyn, &dyn, sizeof dyn, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* v, int64_t count) {
+  if (!h || !name || !v) return fail("bfmmm_set_state: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const Dims& d = h->c.d;
+  const int n = d.n, K = d.K, P = d.P, M = d.M;
+  const std::string s(name);
+  auto need = [&](int64_t want) { return count == want ? 0 : fail("bfmmm_set_state(" + s + "): wrong element count"); };
+  HIPCHK(hipStreamSynchronize(h->st));
+  if (s == "nu" || s == "Phi") {
+    std::vector<double> th((size_t)K * (M + 1) * P);
+    HIPCHK(hipMemcpy(th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    if (s == "nu") {
+      if (need((int64_t)K * P)) return 1;
+      for (int j = 0; j < K; ++j)
+        for (int p = 0; p < P; ++p) th[((size_t)j * (M + 1)) * P + p] = v[j + (size_t)K * p];
+    } else {
+      if (need((int64_t)K * P * M)) return 1;
+      for (int j = 0; j < K; ++j)
+        for (int m = 0; m < M; ++m)
+          for (int p = 0; p < P; ++p) th[((size_t)j * (M + 1) + m + 1) * P + p] = v[j + (size_t)K * (p + (size_t)P * m)];
+    }
+    HIPCHK(hipMemcpy(h->c.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
+    return 0;
+  }
+  struct Arr { const char* nm; double* p; int64_t len; };
+  const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
+                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M}};
+  for (const Arr& a : arrs)
+    if (s == a.nm) {
+      if (need(a.len)) return 1;
+      HIPCHK(hipMemcpy(a.p, v, sizeof(double) * (size_t)a.len, hipMemcpyHostToDevice));
+      return 0;
+    }
+  Dyn dyn;
+  if (dyn_get(h, dyn)) return 1;
+  if (s == "pi") { if (need(K)) return 1; for (int k = 0; k < K; ++k) dyn.pi[k] = v[k]; }
+  else if (s == "tau") { if (need(K)) return 1; for (int k = 0; k < K; ++k) dyn.tau[k] = v[k]; }
+  else if (s == "alpha_3") { if (need(1)) return 1; dyn.alpha3 = v[0]; }
+  else if (s == "sigma_sq") { if (need(1)) return 1; dyn.sigma2 = v[0]; }
+  else return fail("bfmmm_set_state: unknown name '" + s + "'");
+  return dyn_put(h, dyn);
+}
+
+extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, int64_t capacity) {
+  if (!h || !name || !out) return fail("bfmmm_get_state: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const Dims& d = h->c.d;
+  const int n = d.n, K = d.K, P = d.P, M = d.M;
+  const std::string s(name);
+  auto need = [&](int64_t want) { return capacity >= want ? 0 : fail("bfmmm_get_state(" + s + "): buffer too small"); };
+  HIPCHK(hipStreamSynchronize(h->st));
+  if (s == "nu" || s == "Phi") {
+    std::vector<double> th((size_t)K * (M + 1) * P);
+    HIPCHK(hipMemcpy(th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    if (s == "nu") {
+      if (need((int64_t)K * P)) return 1;
+      for (int j = 0; j < K; ++j)
+        for (int p = 0; p < P; ++p) out[j + (size_t)K * p] = th[((size_t)j * (M + 1)) * P + p];
+    } else {
+      if (need((int64_t)K * P * M)) return 1;
+      for (int j = 0; j < K; ++j)
+        for (int m = 0; m < M; ++m)
+          for (int p = 0; p < P; ++p) out[j + (size_t)K * (p + (size_t)P * m)] = th[((size_t)j * (M + 1) + m + 1) * P + p];
+    }
+    return 0;
+  }
+  struct Arr { const char* nm; double* p; int64_t len; };
+  const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
+                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M}};
+  for (const Arr& a : arrs)
+    if (s == a.nm) {
+      if (need(a.len)) return 1;
+      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
+      return 0;
+    }
+  Dyn dyn;
+  if (dyn_get(h, dyn)) return 1;
+  if (s == "pi") { if (need(K)) return 1; for (int k = 0; k < K; ++k) out[k] = dyn.pi[k]; }
+  else if (s == "tau") { if (need(K)) return 1; for (int k = 0; k < K; ++k) out[k] = dyn.tau[k]; }
+  else if (s == "alpha_3") { if (need(1)) return 1; out[0] = dyn.alpha3; }
+  else if (s == "sigma_sq") { if (need(1)) return 1; out[0] = dyn.sigma2; }
+  else if (s == "loglik") { if (need(1)) return 1; out[0] = dyn.loglik; }
+  else if (s == "status") { if (need(1)) return 1; out[0] = (double)dyn.status; }
+  else return fail("bfmmm_get_state: unknown name '" + s + "'");
+  return 0;
+}
+
+// Initial states of BFMMM_Nu_Z (BFMMM.h:1039-1071) and BFMMM_Theta (:1210-1235)
+extern "C" int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain) {
+  if (!h) return fail("bfmmm_init_state: null handle");
+  const Dims& d = h->c.d;
+  const int n = d.n, K = d.K, P = d.P, M = d.M;
+  const RngKey key = make_key(seed, chain, 0, 0);
+  std::vector<double> nu((size_t)K * P), chi((size_t)n * M, 0.0), Phi((size_t)K * P * M, 0.0), Z((size_t)n * K), pi(K);
+  for (int q = 0; q < K * P; ++q) nu[q] = rnorm(key, UPD_INIT_NU, (uint32_t)q);
+  {
+    double sum = 0;
+    for (int k = 0; k < K; ++k) {
+      const double a = h->c.h.c[k] <= 0 ? 10.0 : h->c.h.c[k];
+      pi[k] = rgamma(key, UPD_INIT_PI, (uint32_t)k, a, 1.0);
+      sum += pi[k];
+    }
+    for (int k = 0; k < K; ++k) pi[k] /= sum;
+  }
+  for (int i = 0; i < n; ++i) {
+    double g[KMAX], sum = 0;
+    for (int k = 0; k < K; ++k) {
+      double a = pi[k] * 100;
+      if (a <= 0) a = 10;
+      g[k] = rgamma(key, UPD_INIT_Z, (uint32_t)(i * K + k), a, 1.0);
+      sum += g[k];
+    }
+    for (int k = 0; k < K; ++k) Z[i + (size_t)n * k] = g[k] / sum;
+  }
+  if (stage == 1) {
+    for (size_t q = 0; q < chi.size(); ++q) chi[q] = rnorm(key, UPD_INIT_CHI, (uint32_t)q);
+    for (size_t q = 0; q < Phi.size(); ++q) Phi[q] = rnorm(key, UPD_INIT_PHI, (uint32_t)q);
+  }
+  std::vector<double> ones((size_t)K * P * M, 1.0);
+  const double one = 1.0;
+  if (bfmmm_set_state(h, "nu", nu.data(), (int64_t)nu.size()) || bfmmm_set_state(h, "chi", chi.data(), (int64_t)chi.size()) ||
+      bfmmm_set_state(h, "Phi", Phi.data(), (int64_t)Phi.size()) || bfmmm_set_state(h, "Z", Z.data(), (int64_t)Z.size()) ||
+      bfmmm_set_state(h, "pi", pi.data(), K) || bfmmm_set_state(h, "alpha_3", &one, 1) ||
+      bfmmm_set_state(h, "sigma_sq", &one, 1) || bfmmm_set_state(h, "tau", ones.data(), K) ||
+      bfmmm_set_state(h, "delta", ones.data(), (int64_t)K * M) || bfmmm_set_state(h, "A", ones.data(), (int64_t)K * 2) ||
+      bfmmm_set_state(h, "gamma", ones.data(), (int64_t)K * P * M))
+    return 1;
+  return 0;
+}
+
+// ---- iteration driver -------------------------------------------------------------------------
+struct Plan {
+  bool z, pg, factor, chi;
+  int z_update, chi_update, use_rss_part;
+};
+
+static Plan make_plan(uint32_t mask, int MD) {
+  Plan p;
+  p.z = (mask & (U_Z | U_PI | U_ALPHA3)) != 0;
+  p.z_update = (mask & U_Z) ? 1 : 0;
+  p.pg = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
+  p.factor = (mask & (U_PHI | U_NU)) != 0;
+  p.chi_update = ((mask & U_CHI) && MD > 1) ? 1 : 0;
+  p.chi = p.chi_update || ((mask & U_LOGLIK) && !(mask & U_SIGMA));
+  p.use_rss_part = p.chi ? 1 : 0;
+  return p;
+}
+
+static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NTG, int NKS, int KS, hipStream_t st,
+                             std::vector<hipEvent_t>* evs) {
+  auto mark = [&]() {
+    if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
+  };
+  mark();
+  if (p.z) launch_curve(c, 0, p.z_update, st);
+  mark();
+  if (p.pg) launch_pair_gram(c, NTG, NKS, KS, st);
+  mark();
+  if (p.factor) launch_factor(c, st);
+  mark();
+  launch_sweep(c, st);
+  mark();
+  if (p.chi) launch_curve(c, 1, p.chi_update, st);
+  mark();
+  launch_loglik(c, p.use_rss_part, 0, st);
+  mark();
+}
+
+extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+                         int phi_chi_zero, double beta) {
+  if (!h) return fail("bfmmm_run: null handle");
+  if (n_iters < 0 || first_iter < 0 || first_iter + n_iters > h->T) return fail("bfmmm_run: iterations exceed the allocated chain");
+  HIPCHK(hipSetDevice(h->device));
+  Ctx c = h->c;
+  const int MD = phi_chi_zero ? 1 : (c.d.M + 1);
+  set_md(c.d, MD);
+  c.seed = seed; c.chain = chain; c.mask = mask;
+  int NTG, NKS, KS;
+  pg_geometry(c.d, NTG, NKS, KS);
+  if ((size_t)NKS * c.d.NT * 256 > h->pg_part_doubles) return fail("bfmmm_run: internal workspace too small");
+  const Plan plan = make_plan(mask, MD);
+  h->last_md = MD;
+  Dyn dyn;
+  if (dyn_get(h, dyn)) return 1;
+  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = 0; dyn.beta = beta; dyn.status = 0;
+  if (dyn_put(h, dyn)) return 1;
+  for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
+  HIPCHK(hipEventRecord(h->ev0, h->st));
+  if (h->profile) {
+    for (int it = 0; it < n_iters; ++it) {
+      std::vector<hipEvent_t> evs;
+      launch_iteration(h, c, plan, NTG, NKS, KS, h->st, &evs);
+      HIPCHK(hipStreamSynchronize(h->st));
+      const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
+      const bool ran[6] = {plan.z, plan.pg, plan.factor, true, plan.chi, true};
+      for (int q = 0; q < 6; ++q) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, evs[q], evs[q + 1]);
+        if (ran[q]) { h->fam_ms[fams[q]] += ms; h->fam_launches[fams[q]] += 1; }
+      }
+      for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    }
+  } else if (n_iters > 0) {
+    const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
+    if (!reuse) {
+      if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+      launch_iteration(h, c, plan, NTG, NKS, KS, h->st, nullptr);
+      HIPCHK(hipStreamEndCapture(h->st, &graph));
+      HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
+    }
+    for (int it = 0; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+  }
+  // chain slots of blocks this sweep does not touch hold the (constant) current value
+  if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);
+  if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter, first_iter + n_iters, h->st);
+  HIPCHK(hipEventRecord(h->ev1, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->fam_ms[FAM_TOTAL] = ms;
+  h->fam_launches[FAM_TOTAL] = n_iters;
+  if (dyn_get(h, dyn)) return 1;
+  if (dyn.status & 1u)
+    return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
+                "eigen-decomposition fallback here; not supported on the device)");
+  return 0;
+}
+
+extern "C" int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, double* out, int64_t capacity) {
+  if (!h || !name || !out) return fail("bfmmm_get_chain: null argument");
+  if (n_slots < 0 || n_slots > h->T) return fail("bfmmm_get_chain: n_slots out of range");
+  HIPCHK(hipSetDevice(h->device));
+  const Ctx& c = h->c;
+  const Dims& d = c.d;
+  const int64_t n = d.n, K = d.K, P = d.P, M = d.M;
+  const std::string s(name);
+  struct Arr { const char* nm; const double* p; int64_t len; };
+  const Arr arrs[] = {{"nu", c.c_nu, K * P}, {"chi", c.c_chi, n * M}, {"Z", c.c_Z, n * K}, {"pi", c.c_pi, K},
+                      {"alpha_3", c.c_alpha3, 1}, {"delta", c.c_delta, K * M}, {"A", c.c_A, K * 2},
+                      {"sigma_sq", c.c_sigma, 1}, {"gamma", c.c_gamma, K * P * M}, {"Phi", c.c_Phi, K * P * M},
+                      {"loglik", c.c_loglik, 1}};
+  HIPCHK(hipStreamSynchronize(h->st));
+  for (const Arr& a : arrs)
+    if (s == a.nm) {
+      const int64_t want = a.len * n_slots;
+      if (capacity < want) return fail("bfmmm_get_chain(" + s + "): buffer too small");
+      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost));
+      return 0;
+    }
+  if (s == "tau") {   // stored T_alloc x K column-major on the device; returned n_slots x K column-major
+    const int64_t want = (int64_t)n_slots * K;
+    if (capacity < want) return fail("bfmmm_get_chain(tau): buffer too small");
+    for (int k = 0; k < K; ++k)
+      HIPCHK(hipMemcpy(out + (size_t)n_slots * k, c.c_tau + (size_t)h->T * k, sizeof(double) * (size_t)n_slots,
+                       hipMemcpyDeviceToHost));
+    return 0;
+  }
+  return fail("bfmmm_get_chain: unknown name '" + s + "'");
+}
+
+extern "C" int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, int64_t capacity, int64_t* count) {
+  if (!h || !name || !out || !count) return fail("bfmmm_debug_get: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const Ctx& c = h->c;
+  Dims d = c.d;
+  if (h->last_md > 0) set_md(d, h->last_md);
+  const std::string s(name);
+  HIPCHK(hipStreamSynchronize(h->st));
+  if (s == "dims") {
+    const double v[] = {(double)d.n, (double)d.K, (double)d.P, (double)d.M, (double)d.BW, (double)d.LG, (double)d.LREC,
+                        (double)d.MD, (double)d.A, (double)d.R, (double)d.NT, (double)d.n_obs_total, (double)d.half_sum, c.YY};
+    const int64_t cnt = sizeof v / sizeof v[0];
+    if (capacity < cnt) return fail("bfmmm_debug_get: buffer too small");
+    memcpy(out, v, sizeof v);
+    *count = cnt;
+    return 0;
+  }
+  struct Arr { const char* nm; const double* p; int64_t len; };
+  const Arr arrs[] = {{"rec", c.rec, (int64_t)d.n * d.LREC}, {"H", c.H, (int64_t)d.R * d.LG}, {"tvec", c.tvec, (int64_t)d.A * d.P},
+                      {"Cmat", c.Cmat, (int64_t)d.A * d.P * d.P}, {"Lmat", c.Lmat, (int64_t)d.A * d.P * d.P},
+                      {"theta", c.theta, (int64_t)d.K * (d.M + 1) * d.P}};
+  for (const Arr& a : arrs)
+    if (s == a.nm) {
+      if (capacity < a.len) return fail("bfmmm_debug_get(" + s + "): buffer too small");
+      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
+      *count = a.len;
+      return 0;
+    }
+  return fail("bfmmm_debug_get: unknown name '" + s + "'");
+}
+
+extern "C" int bfmmm_set_profile(bfmmm_handle* h, int enable) {
+  if (!h) return fail("bfmmm_set_profile: null handle");
+  h->profile = enable ? 1 : 0;
+  return 0;
+}
+
+extern "C" int bfmmm_get_timing(bfmmm_handle* h, const char* name, double* ms, int64_t* launches) {
+  if (!h || !name || !ms || !launches) return fail("bfmmm_get_timing: null argument");
+  for (int f = 0; f < FAM_COUNT; ++f)
+    if (!strcmp(name, kFamNames[f])) { *ms = h->fam_ms[f]; *launches = h->fam_launches[f]; return 0; }
+  return fail("bfmmm_get_timing: unknown name");
+}

@@ -1,0 +1,109 @@
+// Device-side data model of the MI355X Gibbs sampler (internal header, not part of the C ABI).
+//
+// Algebra: every data term of every full conditional of
+// inst/include/BayesFMMM/Update*.h depends on curve i only through
+//     G_i = B_i'B_i (P x P, banded with half-bandwidth = spline degree),  s_i = B_i'y_i,  yy_i = y_i'y_i.
+// They are computed once (kernels_stats.hip) and kept resident in HBM as one record per curve:
+//     rec_i = [ G_i band-packed (BW+1) x P, diagonal-major : rec[d*P + p] = G_i[p][p+d] | s_i (P) | yy_i | pad ]
+// The sampled P-vectors are "directions" a = (j, mt): mt = 0 is nu_j, mt = m+1 is phi_{j,m};
+// curve i sees direction a with weight  w_{a,i} = Z_ij * chit_{i,mt},  chit_{i,0} = 1, chit_{i,m+1} = chi_im,
+// so that the fitted coefficient is  c_i = sum_a w_{a,i} theta_a.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bfmmm {
+
+constexpr int KMAX = 6;     // clusters supported by the unrolled per-curve code
+constexpr int PMAX = 64;    // basis functions: one lane per basis function inside a curve group
+constexpr int BWMAX = 5;    // spline degree (band half-width) instantiated
+
+// update mask bits, in the (fixed) order in which every reference driver applies them
+// (BFMMM.h:1073-1107, 1253-1292, 1502-1553, 3741-3780, 3944-4010, 4809-4894)
+enum : uint32_t {
+  U_Z = 1u << 0, U_PI = 1u << 1, U_ALPHA3 = 1u << 2, U_PHI = 1u << 3, U_DELTA = 1u << 4, U_A = 1u << 5,
+  U_GAMMA = 1u << 6, U_NU = 1u << 7, U_TAU = 1u << 8, U_SIGMA = 1u << 9, U_CHI = 1u << 10,
+  U_ETA = 1u << 11, U_TAU_ETA = 1u << 12, U_XI = 1u << 13, U_DELTA_XI = 1u << 14, U_A_XI = 1u << 15,
+  U_GAMMA_XI = 1u << 16, U_LOGLIK = 1u << 17
+};
+
+struct Hyper {
+  double c[KMAX];
+  double b, nu_1;
+  double alpha1l, alpha2l, beta1l, beta2l;
+  double a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2;
+  double alpha_nu, beta_nu, alpha_eta, beta_eta, alpha_0, beta_0;
+};
+
+// Scalars that change every iteration live in device memory so that a captured HIP graph
+// can be replayed without re-recording kernel arguments.
+struct Dyn {
+  uint32_t iter;        // chain iteration index (RNG counter word) of the sweep being executed
+  uint32_t slot;        // chain slot that sweep writes (iter % r_stored_iters)
+  uint32_t tt_step;     // tempered-transition sub-step (0 outside)
+  uint32_t status;      // sticky error bits (1: precision matrix not positive definite)
+  double beta;          // temperature (1 = untempered)
+  double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
+  double alpha3;
+  double rss;           // residual sum of squares after the last sigma / chi pass
+  double loglik;
+  double pi[KMAX];
+  double tau[KMAX];
+};
+
+struct Dims {
+  int n, K, P, M, D;
+  int BW;               // band half-width of G_i (= spline degree; 0 for the multivariate model)
+  int LG;               // (BW+1)*P
+  int LREC;             // record length in doubles (LG + P + 1, padded to even)
+  int MD;               // active mt values: M+1, or 1 when Phi = chi = 0 (Nu_Z stage)
+  int A;                // directions = K * MD
+  int NZZ, NCC, R;      // pair rows: K(K+1)/2 * MD(MD+1)/2
+  int RT, AT;           // 16-row tiles of pair rows / of single-weight rows
+  int CTG, CTS;         // 16-col tiles over the G part / the s part of a record
+  int NT;               // total output tiles of the pair-Gram kernel = RT*CTG + AT*CTS
+  int NWG;              // workgroups (= K-slices) of the pair-Gram kernel
+  int mv;               // multivariate model flags (prior (1/tau) I, tau stored inverted, ...)
+  int64_t n_obs_total;  // sum_i n_i
+  int64_t half_sum;     // sum_i floor(n_i / 2)   (UpdateSigma.h:49 integer division)
+};
+
+// Everything a kernel needs, passed by value (kernarg).
+struct Ctx {
+  Dims d;
+  Hyper h;
+  uint64_t seed;
+  uint32_t chain;
+  uint32_t mask;
+  int T;                        // chain slots allocated
+  Dyn* dyn;
+  // per-curve statistics
+  const double* rec;            // n x LREC
+  const int* ni;                // n
+  // current state
+  double* Z;                    // n x K col-major
+  double* chi;                  // n x M col-major
+  double* theta;                // A_full x P  (a = j*(M+1) + mt), direction-major
+  double* delta;                // K x M
+  double* Aa;                   // K x 2
+  double* gamma;                // K x P x M
+  // work buffers
+  double* logz_part;            // nblk_curve x K   partial sums of log Z
+  double* rss_part;             // nblk_curve       partial residual sums of squares
+  double* pg_part;              // NWG x NT x 256   pair-Gram partial tiles
+  double* H;                    // R x LG           pair-weighted Gram blocks (band-packed)
+  double* tvec;                 // A x P            sum_i w_ai s_i
+  double* Cmat;                 // A x P x P        covariance of each direction's conditional
+  double* Lmat;                 // A x P x P        its lower Cholesky factor
+  const double* Pmat;           // P x P penalty
+  double YY;                    // sum_i yy_i
+  // chain storage (slot-major, each slot laid out exactly as the reference returns it)
+  double *c_nu, *c_chi, *c_Z, *c_pi, *c_alpha3, *c_delta, *c_A, *c_sigma, *c_tau, *c_gamma, *c_Phi, *c_loglik;
+  int nblk_curve;
+};
+
+__host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
+  return a * n - (a * (a - 1)) / 2 + (b - a);
+}
+
+}  // namespace bfmmm

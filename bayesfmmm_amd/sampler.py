@@ -1,0 +1,134 @@
+"""Thin object wrapper over the C ABI (include/bfmmm.h): one `Sampler` = one `bfmmm_handle`.
+
+All arrays cross the boundary in the reference's layouts (column-major, R/Armadillo order);
+numpy arrays returned here are Fortran-ordered with the reference's shapes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+U_Z, U_PI, U_ALPHA3, U_PHI, U_DELTA, U_A, U_GAMMA, U_NU, U_TAU, U_SIGMA, U_CHI = (1 << i for i in range(11))
+U_LOGLIK = 1 << 17
+SWEEP_NU_Z = U_Z | U_PI | U_ALPHA3 | U_NU | U_TAU | U_SIGMA | U_LOGLIK
+SWEEP_THETA = U_PHI | U_DELTA | U_A | U_GAMMA | U_TAU | U_SIGMA | U_CHI | U_LOGLIK
+SWEEP_WARM = SWEEP_NU_Z | SWEEP_THETA
+
+MODEL_FUNCTIONAL, MODEL_MULTIVARIATE = 0, 1
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def default_config(**kw):
+    cfg = _lib.BfmmmConfig()
+    _lib.load().bfmmm_config_defaults(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "c":
+            for i, x in enumerate(v):
+                cfg.c[i] = float(x)
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class Sampler:
+    def __init__(self, cfg, Y, time=None, internal_knots=None, boundary_knots=None, device=0):
+        """Functional model: Y, time are lists of 1-D arrays (one per curve).
+        Multivariate model: Y is an (n, P) matrix."""
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        if cfg.model == MODEL_FUNCTIONAL:
+            self.offsets = np.zeros(len(Y) + 1, dtype=np.int64)
+            self.offsets[1:] = np.cumsum([len(y) for y in Y])
+            y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))
+            t = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in time]))
+            ik = np.ascontiguousarray(internal_knots, dtype=np.float64)
+            bk = np.ascontiguousarray(boundary_knots, dtype=np.float64)
+            cfg.n_funct = len(Y)
+            cfg.n_internal_knots = len(ik)
+            self.P = len(ik) + cfg.basis_degree + 1
+            _lib.check(self.lib.bfmmm_create(C.byref(cfg), device, _dp(y), _dp(t),
+                                             self.offsets.ctypes.data_as(_lib.c_int64_p), _dp(ik), _dp(bk),
+                                             C.byref(self.h)))
+        else:
+            Ym = np.asfortranarray(Y, dtype=np.float64)
+            cfg.n_funct, cfg.P = Ym.shape
+            self.P = cfg.P
+            self.offsets = None
+            _lib.check(self.lib.bfmmm_create(C.byref(cfg), device, _dp(Ym), None, None, None, None, C.byref(self.h)))
+        self.n, self.K, self.M, self.T = cfg.n_funct, cfg.K, cfg.n_eigen, cfg.tot_mcmc_iters
+
+    def close(self):
+        if self.h:
+            self.lib.bfmmm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- shapes of the reference's objects ----
+    def _state_shape(self, name):
+        n, K, P, M = self.n, self.K, self.P, self.M
+        return {"nu": (K, P), "Phi": (K, P, M), "chi": (n, M), "Z": (n, K), "pi": (K,), "alpha_3": (1,),
+                "delta": (K, M), "A": (K, 2), "gamma": (K, P, M), "tau": (K,), "sigma_sq": (1,),
+                "loglik": (1,), "status": (1,)}[name]
+
+    def set_state(self, **kw):
+        for name, v in kw.items():
+            a = np.asfortranarray(np.asarray(v, dtype=np.float64).reshape(self._state_shape(name), order="F"))
+            _lib.check(self.lib.bfmmm_set_state(self.h, name.encode(), _dp(a), a.size))
+
+    def get_state(self, name):
+        out = np.zeros(self._state_shape(name), order="F")
+        _lib.check(self.lib.bfmmm_get_state(self.h, name.encode(), _dp(out), out.size))
+        return out
+
+    def init_state(self, stage, seed, chain=0):
+        _lib.check(self.lib.bfmmm_init_state(self.h, stage, seed, chain))
+
+    def run(self, mask, n_iters, first_iter=0, seed=1, chain=0, phi_chi_zero=False, beta=1.0):
+        _lib.check(self.lib.bfmmm_run(self.h, mask, first_iter, n_iters, seed, chain, int(phi_chi_zero), beta))
+
+    def get_chain(self, name, n_slots=None):
+        T = self.T if n_slots is None else n_slots
+        shp = {"nu": (self.K, self.P, T), "chi": (self.n, self.M, T), "Z": (self.n, self.K, T), "pi": (self.K, T),
+               "alpha_3": (T,), "delta": (self.K, self.M, T), "A": (self.K, 2, T), "sigma_sq": (T,),
+               "tau": (T, self.K), "gamma": (self.K, self.P, self.M, T), "Phi": (self.K, self.P, self.M, T),
+               "loglik": (T,)}[name]
+        out = np.zeros(shp, order="F")
+        _lib.check(self.lib.bfmmm_get_chain(self.h, name.encode(), T, _dp(out), out.size))
+        return out
+
+    def get_basis(self):
+        n_obs = int(self.offsets[-1])
+        out = np.zeros((n_obs, self.P))
+        _lib.check(self.lib.bfmmm_get_basis(self.h, _dp(out), out.size))
+        return [out[self.offsets[i]:self.offsets[i + 1]] for i in range(self.n)]
+
+    def debug(self, name, capacity=1 << 24):
+        out = np.zeros(capacity)
+        cnt = C.c_int64()
+        _lib.check(self.lib.bfmmm_debug_get(self.h, name.encode(), _dp(out), capacity, C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def dims(self):
+        v = self.debug("dims", 64)
+        names = ["n", "K", "P", "M", "BW", "LG", "LREC", "MD", "A", "R", "NT", "n_obs_total", "half_sum"]
+        d = {k: int(x) for k, x in zip(names, v)}
+        d["YY"] = float(v[13])
+        return d
+
+    def set_profile(self, enable):
+        _lib.check(self.lib.bfmmm_set_profile(self.h, int(enable)))
+
+    def timing(self, name="total"):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(self.lib.bfmmm_get_timing(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

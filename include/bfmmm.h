@@ -1,0 +1,128 @@
+/*
+ * bfmmm.h -- C ABI of the MI355X-native Gibbs sampler for the functional / multivariate
+ * mixed-membership models of ndmarco/BayesFMMM.
+ *
+ * This is the drop-in boundary for the sampler's hot path.  The reference exposes that path to R
+ * through Rcpp-generated `.Call` entry points
+ *     _BayesFMMM_BFMMM_Nu_Z_multiple_try   src/RcppExports.cpp:358   (R/RcppExports.R:1604)
+ *     _BayesFMMM_BFMMM_Theta_est           src/RcppExports.cpp:396   (R/RcppExports.R:1791)
+ *     _BayesFMMM_BFMMM_warm_start          src/RcppExports.cpp:438   (R/RcppExports.R:2018)
+ *     _BayesFMMM_BMVMMM_Nu_Z_multiple_try  src/RcppExports.cpp:680
+ *     _BayesFMMM_BMVMMM_Theta_est          src/RcppExports.cpp:713
+ *     _BayesFMMM_BMVMMM_warm_start         src/RcppExports.cpp:750
+ * whose C++ bodies (src/UserFunctions.cpp:166, 684, 1341, 4579, 4995, 5540) build B-splines, run the
+ * chain drivers of inst/include/BayesFMMM/BFMMM.h and return named lists of Armadillo arrays.
+ * A `.Call` shim (shim/bfmmm_rcall.cpp) marshals SEXPs onto the plain-C entry
+ * points below: ragged R lists become CSR arrays (values + offsets), matrices stay column-major,
+ * results are copied into caller-allocated buffers laid out exactly like the reference's return
+ * values.  No C++ types, no torch types, no exceptions cross this boundary.
+ *
+ * All functions return 0 on success and a non-zero code on failure; bfmmm_last_error() then gives
+ * the message (the argument-validation messages are the reference's own, UserFunctions.cpp:198-286).
+ * The library needs a HIP device: there is no CPU fallback.
+ */
+#ifndef BFMMM_H
+#define BFMMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bfmmm_handle bfmmm_handle;
+
+enum { BFMMM_MODEL_FUNCTIONAL = 0, BFMMM_MODEL_MULTIVARIATE = 1 };
+
+/* Update mask bits: every reference driver applies its updates in this relative order
+ * (BFMMM.h:1073-1107 Nu_Z, :1253-1292 Theta, :1502-1553 warm start). */
+enum {
+  BFMMM_U_Z = 1 << 0, BFMMM_U_PI = 1 << 1, BFMMM_U_ALPHA3 = 1 << 2, BFMMM_U_PHI = 1 << 3,
+  BFMMM_U_DELTA = 1 << 4, BFMMM_U_A = 1 << 5, BFMMM_U_GAMMA = 1 << 6, BFMMM_U_NU = 1 << 7,
+  BFMMM_U_TAU = 1 << 8, BFMMM_U_SIGMA = 1 << 9, BFMMM_U_CHI = 1 << 10, BFMMM_U_LOGLIK = 1 << 17
+};
+/* sweeps of the three stages */
+#define BFMMM_SWEEP_NU_Z  (BFMMM_U_Z | BFMMM_U_PI | BFMMM_U_ALPHA3 | BFMMM_U_NU | BFMMM_U_TAU | BFMMM_U_SIGMA | BFMMM_U_LOGLIK)
+#define BFMMM_SWEEP_THETA (BFMMM_U_PHI | BFMMM_U_DELTA | BFMMM_U_A | BFMMM_U_GAMMA | BFMMM_U_TAU | BFMMM_U_SIGMA | BFMMM_U_CHI | BFMMM_U_LOGLIK)
+#define BFMMM_SWEEP_WARM  (BFMMM_SWEEP_NU_Z | BFMMM_SWEEP_THETA)
+
+/* Hyper-parameters and sizes; field names follow the reference's argument names
+ * (UserFunctions.cpp:166-193, 684-715, 1341-1378).  bfmmm_config_defaults() fills in the
+ * reference defaults of the functional entry points. */
+typedef struct {
+  int32_t model;             /* BFMMM_MODEL_* */
+  int32_t n_funct;           /* number of curves (rows of Y for the multivariate model) */
+  int32_t K;                 /* clusters */
+  int32_t n_eigen;           /* M */
+  int32_t basis_degree;      /* functional model only */
+  int32_t n_internal_knots;  /* functional model only; P = n_internal_knots + basis_degree + 1 */
+  int32_t P;                 /* multivariate model: dimension of the observations */
+  int32_t tot_mcmc_iters;    /* chain slots to allocate (r_stored_iters == tot_mcmc_iters) */
+  double c[8];               /* Dirichlet hyper-parameter of pi (length K) */
+  double b, nu_1;
+  double alpha1l, alpha2l, beta1l, beta2l;
+  double a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2;
+  double alpha_nu, beta_nu, alpha_eta, beta_eta, alpha_0, beta_0;
+} bfmmm_config;
+
+void bfmmm_config_defaults(bfmmm_config* cfg);
+
+/* Creates a sampler for one data set and uploads it to the GPU `device`.
+ *   functional:   y, t are the concatenated observations / time points of all curves,
+ *                 offsets[n_funct+1] delimits curve i as [offsets[i], offsets[i+1]) -- the CSR form
+ *                 of the R lists `Y` and `time` (arma::field<arma::vec>, UserFunctions.cpp:169-170);
+ *                 internal_knots[n_internal_knots], boundary_knots[2] as in UserFunctions.cpp:174-175.
+ *   multivariate: y is the n_funct x P column-major matrix `Y` (UserFunctions.cpp:4582);
+ *                 t, offsets, knots are ignored (may be NULL).
+ * The B-spline basis S(t_i) and the per-curve statistics S_i S_i', S_i y_i, y_i'y_i are computed on
+ * the device (replacing BFMMM.h:1017-1025).  The caller's arrays are not retained. */
+int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                 const double* internal_knots, const double* boundary_knots, bfmmm_handle** out);
+void bfmmm_destroy(bfmmm_handle* h);
+
+/* Basis matrices "B" returned by the reference's entry points (UserFunctions.cpp:327): the rows of
+ * all curves concatenated, each row P doubles (row-major: out[(offsets[i]+l)*P + p] = B_i(l,p)). */
+int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity);
+
+/* Current state (the chain's working slot).  Names and layouts are the reference's
+ * (column-major Armadillo objects):
+ *   "nu" K x P, "Phi" K x P x M, "chi" n x M, "Z" n x K, "pi" K, "alpha_3" 1, "delta" K x M,
+ *   "A" K x 2, "gamma" K x P x M, "tau" K, "sigma_sq" 1 (a variance, as everywhere in the reference). */
+int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* values, int64_t count);
+int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, int64_t capacity);
+
+/* Initial states of the chain drivers, drawn from the keyed RNG:
+ *   stage 0: BFMMM_Nu_Z   (BFMMM.h:1039-1071)  nu ~ N(0,1), chi = 0, Phi = 0, pi ~ Dir(c), Z_i ~ Dir(100 pi), rest 1
+ *   stage 1: BFMMM_Theta  (BFMMM.h:1210-1235)  as stage 0 but chi ~ N(0,1), Phi ~ N(0,1)
+ * (the caller then pins Z / nu with bfmmm_set_state as BFMMM.h:1244-1250 does). */
+int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain);
+
+/* Runs n_iters Gibbs iterations with the updates selected by `mask`, starting at chain iteration
+ * `first_iter` (which is also the chain slot written, and the RNG counter word).  `phi_chi_zero`
+ * != 0 declares Phi = 0 and chi = 0 (stage 1 of the pipeline, BFMMM.h:1040,1063) so that their
+ * directions are skipped.  beta = tempering temperature of the *Tempered kernels (1 = untempered). */
+int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+              int phi_chi_zero, double beta);
+
+/* Copies chain draws to the host: slots [0, n_slots) of `name`, laid out as the reference returns
+ * them: "nu" K x P x T, "chi" n x M x T, "Z" n x K x T, "pi" K x T, "alpha_3" T, "A" K x 2 x T,
+ * "delta" K x M x T, "sigma_sq" T, "tau" T x K, "gamma"/"Phi" T arrays of K x P x M, "loglik" T. */
+int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, double* out, int64_t capacity);
+
+/* Diagnostics for the parity tests: "rec" (n x LREC per-curve statistics), "H", "tvec", "Cmat", "Lmat",
+ * "dims" (as doubles).  Returns the number of doubles written through *count. */
+int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, int64_t capacity, int64_t* count);
+
+/* Timing of the last bfmmm_run: milliseconds between HIP events recorded on the sampler's stream
+ * around the whole run and, per kernel family, accumulated over iterations when `profile` was
+ * enabled with bfmmm_set_profile (which disables graph replay).
+ * names: "total", "curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik". */
+int bfmmm_set_profile(bfmmm_handle* h, int enable);
+int bfmmm_get_timing(bfmmm_handle* h, const char* name, double* ms, int64_t* launches);
+
+const char* bfmmm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
