@@ -162,7 +162,7 @@ __device__ inline double block_sum256(double v, double* scratch) {
 __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
-  const int P = d.P, MD = d.MD, K = d.K, M = d.M;
+  const int P = d.P, MD = d.MD, K = d.K;
   const int a = blockIdx.x;
   const int j = a / MD, mt = a - j * MD;
   if (mt == 0 && !(c.mask & U_NU)) return;
@@ -397,13 +397,15 @@ __global__ __launch_bounds__(256) void k_sweep(Ctx c) {
   }
 
   const bool need_gauss = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
+  // ---------------- load theta (always: delta / gamma / tau read it) --------------------------
+  for (int e = tid; e < A * P; e += 256) {
+    const int a = e / P, p = e - a * P;
+    L.th[e] = c.theta[(size_t)full_dir(d, a) * P + p];
+  }
+  __syncthreads();
   if (need_gauss) {
-    // ---------------- load theta, t; r = t - H theta ------------------------------------------
-    for (int e = tid; e < A * P; e += 256) {
-      const int a = e / P, p = e - a * P;
-      L.th[e] = c.theta[(size_t)full_dir(d, a) * P + p];
-      L.tv[e] = c.tvec[e];
-    }
+    // ---------------- t; r = t - H theta ------------------------------------------------------
+    for (int e = tid; e < A * P; e += 256) L.tv[e] = c.tvec[e];
     __syncthreads();
     for (int e = tid; e < A * P; e += 256) {
       const int a = e / P, p = e - a * P;
@@ -520,15 +522,12 @@ __global__ __launch_bounds__(256) void k_sweep(Ctx c) {
     for (int k = 0; k < K; ++k) {
       double acc = 0.0;
       if (tid < P) {
-        const double* nu = need_gauss ? (L.th + (k * MD) * P) : nullptr;
-        const double vp = nu ? nu[tid] : c.theta[(size_t)(k * (M + 1)) * P + tid];
+        const double* nu = L.th + (k * MD) * P;
+        const double vp = nu[tid];
         double s = 0.0;
         if (d.mv) s = vp;
         else
-          for (int q = 0; q < P; ++q) {
-            const double vq = nu ? nu[q] : c.theta[(size_t)(k * (M + 1)) * P + q];
-            s += c.Pmat[tid + (size_t)P * q] * vq;
-          }
+          for (int q = 0; q < P; ++q) s += c.Pmat[tid + (size_t)P * q] * nu[q];
         acc = vp * s;
       }
       const double qf = block_sum256(acc, L.red);
