@@ -21,9 +21,13 @@ void launch_stats_totals(int n, int LREC, int yy_off, const double* rec, const i
                          long long* out_counts, hipStream_t st);
 int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st);
 int curve_blocks(int n, int P);
+void prepare_curve_kernels();
+void prepare_sweep_kernels();
 void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
-void launch_sweep(const Ctx& c, hipStream_t st);
+int launch_sweep(const Ctx& c, hipStream_t st);
+void launch_pi_alpha(const Ctx& c, hipStream_t st);
+void launch_hyper(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 }  // namespace bfmmm
@@ -49,7 +53,8 @@ static const char* kFamNames[FAM_COUNT] = {"total", "curve_z", "pair_gram", "fac
 struct bfmmm_handle {
   bfmmm_config cfg;
   int device = 0;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr;
   Ctx c;                       // template context (full MD)
   int T = 0;
   int64_t n_obs = 0;
@@ -61,6 +66,7 @@ struct bfmmm_handle {
   hipGraphExec_t gexec = nullptr;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
+  int launch_error = 0;
   int profile = 0;
   double fam_ms[FAM_COUNT] = {0};
   int64_t fam_launches[FAM_COUNT] = {0};
@@ -148,11 +154,18 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   if (P > PMAX) return fail("P larger than 64 is not supported by this build");
 
   HIPCHK(hipSetDevice(device));
+  prepare_curve_kernels();
+  prepare_sweep_kernels();
+  { hipError_t e0 = hipGetLastError(); if (e0 != hipSuccess) fprintf(stderr, "[bfmmm] note: kernel attribute setup reported %s\n", hipGetErrorString(e0)); }
   bfmmm_handle* h = new bfmmm_handle();
   h->cfg = *cfg;
   h->device = device;
   h->T = cfg->tot_mcmc_iters;
   HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->evA));
+  HIPCHK(hipEventCreate(&h->evB));
+  HIPCHK(hipEventCreate(&h->evC));
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
   Ctx& c = h->c;
@@ -161,6 +174,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   d.n = n; d.K = K; d.P = P; d.M = M; d.D = 0; d.BW = BW; d.LG = (BW + 1) * P;
   d.LREC = (d.LG + P + 1 + 1) / 2 * 2;
   d.mv = mv ? 1 : 0;
+  d.BWP = mv ? 0 : std::max(BW, 1);   // RW1 penalty is tridiagonal
   set_md(d, M + 1);
   for (int k = 0; k < KMAX; ++k) c.h.c[k] = (k < 8) ? cfg->c[k] : 10.0;
   c.h.b = cfg->b; c.h.nu_1 = cfg->nu_1;
@@ -187,7 +201,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -263,6 +277,10 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->evA) (void)hipEventDestroy(h->evA);
+  if (h->evB) (void)hipEventDestroy(h->evB);
+  if (h->evC) (void)hipEventDestroy(h->evC);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->st) (void)hipStreamDestroy(h->st);
   delete h;
 }
@@ -382,6 +400,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   else if (s == "sigma_sq") { if (need(1)) return 1; out[0] = dyn.sigma2; }
   else if (s == "loglik") { if (need(1)) return 1; out[0] = dyn.loglik; }
   else if (s == "status") { if (need(1)) return 1; out[0] = (double)dyn.status; }
+  else if (s == "stamps") { if (need(16)) return 1; for (int q = 0; q < 16; ++q) out[q] = (double)(dyn.stamps[q] - dyn.stamps[0]); }
   else return fail("bfmmm_get_state: unknown name '" + s + "'");
   return 0;
 }
@@ -440,29 +459,42 @@ static Plan make_plan(uint32_t mask, int MD) {
   p.z = (mask & (U_Z | U_PI | U_ALPHA3)) != 0;
   p.z_update = (mask & U_Z) ? 1 : 0;
   p.pg = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
-  p.factor = (mask & (U_PHI | U_NU)) != 0;
+  p.factor = p.pg;   // k_factor also prepares r = t - H theta for the sweep
   p.chi_update = ((mask & U_CHI) && MD > 1) ? 1 : 0;
   p.chi = p.chi_update || ((mask & U_LOGLIK) && !(mask & U_SIGMA));
   p.use_rss_part = p.chi ? 1 : 0;
   return p;
 }
 
+// One Gibbs iteration.  Critical chain on `st`:  Z -> pair-Gram -> factor -> sweep -> chi -> loglik.
+// pi/alpha_3 (needed by the next Z update) and delta/A/gamma/tau (needed by the next factor) run on
+// the side stream `st2`, forked and joined with events; under stream capture this becomes a graph
+// with two parallel branches.
 static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NTG, int NKS, int KS, hipStream_t st,
                              std::vector<hipEvent_t>* evs) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
+  hipStream_t st2 = h->st2;
   mark();
   if (p.z) launch_curve(c, 0, p.z_update, st);
   mark();
+  (void)hipEventRecord(h->evA, st);
+  (void)hipStreamWaitEvent(st2, h->evA, 0);
+  launch_pi_alpha(c, st2);
   if (p.pg) launch_pair_gram(c, NTG, NKS, KS, st);
   mark();
   if (p.factor) launch_factor(c, st);
   mark();
-  launch_sweep(c, st);
+  if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
+  (void)hipEventRecord(h->evB, st);
+  (void)hipStreamWaitEvent(st2, h->evB, 0);
+  launch_hyper(c, st2);
+  (void)hipEventRecord(h->evC, st2);
   if (p.chi) launch_curve(c, 1, p.chi_update, st);
   mark();
+  (void)hipStreamWaitEvent(st, h->evC, 0);
   launch_loglik(c, p.use_rss_part, 0, st);
   mark();
 }
@@ -520,6 +552,7 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter, first_iter + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
+  if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS staging (A*LG + 2*P*P > 6144 doubles)"); }
   HIPCHK(hipGetLastError());
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));

@@ -8,30 +8,26 @@
 //
 // Mapping: curves are independent, so a group of LPC lanes (32 or 64, one lane per basis
 // function) owns one curve; a 256-thread workgroup holds 256/LPC curves.  The banded Gram matrix
-// G_i sits in registers (2*BW+1 values per lane); matrix-vector products exchange neighbours with
-// wave shuffles, quadratic forms are butterfly reductions inside the group, so nothing but the
-// shared parameter block theta goes through LDS.  All reductions have a fixed order: results do
-// not depend on the launch geometry.
+// G_i sits in registers (2*BW+1 values per lane).  The handful of P-vectors a curve needs
+// (u_k = nu_k + sum_m chi_im phi_km, G u_k, ...) are staged in a per-group LDS tile; banded
+// matrix-vector products read neighbours from that tile and every quadratic form u'Gv is ONE
+// lane's serial dot product over the tile (K + K(K+1)/2 <= 27 of them for Z, M(M+1)/2 + M + 2
+// for chi), so there are no cross-lane reduction chains.  The chi update is Gauss-Seidel in m
+// inside a curve; with A = U'GU and b = U'(s - G c) precomputed it becomes a scalar recursion.
+// All sums have a fixed order: results do not depend on the launch geometry.
 #include "model.hpp"
 #include "rng.hpp"
 
 namespace bfmmm {
 
-template <int LPC>
-__device__ inline double gsum(double v) {
-#pragma unroll
-  for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPC);
-  return v;
-}
+constexpr int MMAX = 16;   // eigenfunctions supported by the per-curve tiles
 
 template <int BW, int LPC>
 struct Curve {
   double g[BW + 1];    // g[d]  = G[p][p+d]
   double gl[BW + 1];   // gl[d] = G[p-d][p]
   double s, yy;
-  int p;
-  __device__ inline void load(const double* __restrict__ rec, int P, int LG, int lane_in_group) {
-    p = lane_in_group;
+  __device__ inline void load(const double* __restrict__ rec, int P, int LG, int p) {
     const bool act = p < P;
 #pragma unroll
     for (int d = 0; d <= BW; ++d) {
@@ -41,66 +37,105 @@ struct Curve {
     s = act ? rec[LG + p] : 0.0;
     yy = rec[LG + P];
   }
-  // (G u)[p]; u must be 0 on lanes p >= P
-  __device__ inline double matvec(double u) const {
-    double v = g[0] * u;
+  // (G u)[p] with u staged in an LDS row padded by BW zeros on both sides (row points at element 0)
+  __device__ inline double matvec(const double* row, int p) const {
+    double v = g[0] * row[p];
 #pragma unroll
-    for (int d = 1; d <= BW; ++d) {
-      v += g[d] * __shfl(u, p + d, LPC);
-      v += gl[d] * __shfl(u, p - d, LPC);
-    }
+    for (int d = 1; d <= BW; ++d) v += g[d] * row[p + d] + gl[d] * row[p - d];
     return v;
   }
 };
 
+template <int BW, int LPC>
+struct Tile {
+  static constexpr int STR = LPC + 2 * BW;     // padded row stride
+  double* base;
+  __device__ inline double* row(int r) const { return base + r * STR + BW; }
+  __device__ inline void zero_pads(int rows, int lp) const {
+    if (lp < 2 * BW)
+      for (int r = 0; r < rows; ++r) base[r * STR + ((lp < BW) ? lp : (LPC + lp))] = 0.0;
+  }
+};
+
+__device__ inline double dotP(const double* a, const double* b, int P) {
+  double s = 0.0;
+  for (int p = 0; p < P; ++p) s += a[p] * b[p];
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Z update.  do_update == 0 only recomputes the partial sums of log Z (used when pi / alpha_3 are
 // sampled with Z held fixed).
+// LDS per group: U[K], GU[K], S (1 row), chi (MMAX), res (32)
 // ------------------------------------------------------------------------------------------------
 template <int BW, int LPC>
 __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
+  using T = Tile<BW, LPC>;
   const Dims& d = c.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
-  double* sTh = smem;                       // K*(M+1)*P
-  double* sLog = smem + (size_t)K * (M + 1) * P;   // GPB*KMAX
-  for (int q = threadIdx.x; q < K * (M + 1) * P; q += 256) sTh[q] = c.theta[q];
-  __syncthreads();
+  const int nth = K * (M + 1) * P;
+  double* sTh = smem;
+  double* sLog = sTh + nth;                          // GPB*KMAX
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
+  const int per_group = (2 * K + 1) * T::STR + MMAX + 32;
+  double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
+  T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};
+  double* sChi = gbase + (2 * K + 1) * T::STR;
+  double* sRes = sChi + MMAX;
+  for (int q = threadIdx.x; q < nth; q += 256) sTh[q] = c.theta[q];
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
   const double sigma2 = dyn->sigma2, alpha3 = dyn->alpha3, beta = dyn->beta;
+  Curve<BW, LPC> cv;
+  if (valid) {
+    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
+    tU.zero_pads(2 * K + 1, lp);
+    if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
+    tS.row(0)[lp] = cv.s;
+  }
+  __syncthreads();
   double logz_mine = 0.0;
   if (valid) {
-    Curve<BW, LPC> cv;
-    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
-    double Zold[KMAX], u[KMAX], Gu[KMAX];
+    double Zold[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int k = 0; k < K; ++k) {
       double v = 0.0;
-      if (k < K && act) {
+      if (act) {
         const double* th = sTh + (size_t)k * (M + 1) * P;
         v = th[lp];
         if (MD > 1)
-          for (int m = 0; m < M; ++m) v += c.chi[i + (size_t)n * m] * th[(m + 1) * P + lp];
+          for (int m = 0; m < M; ++m) v += sChi[m] * th[(m + 1) * P + lp];
       }
-      u[k] = v;
+      tU.row(k)[lp] = v;
     }
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) Gu[k] = (k < K) ? cv.matvec(u[k]) : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
+    __builtin_amdgcn_wave_barrier();
+    // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2
+    const int ntask = K + K * (K + 1) / 2;
+    for (int q = lp; q < ntask; q += LPC) {
+      double r;
+      if (q < K) r = dotP(tU.row(q), tS.row(0), P);
+      else {
+        int a = 0, rem = q - K;
+        while (rem >= K - a) { rem -= K - a; ++a; }
+        r = dotP(tU.row(a), tG.row(a + rem), P);
+      }
+      sRes[q] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-      av[k] = (k < K) ? gsum<LPC>(u[k] * cv.s) : 0.0;
+      av[k] = (k < K) ? sRes[k] : 0.0;
 #pragma unroll
-      for (int k2 = 0; k2 < KMAX; ++k2) {
-        if (k2 >= k) Q[k][k2] = (k2 < K) ? gsum<LPC>(u[k] * Gu[k2]) : 0.0;
-      }
+      for (int k2 = 0; k2 < KMAX; ++k2)
+        if (k2 >= k) Q[k][k2] = (k2 < K) ? sRes[K + tri_index(K, k, k2)] : 0.0;
     }
     double Zfin[KMAX];
 #pragma unroll
@@ -109,23 +144,38 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
       // proposal: Dirichlet(a_Z_PM * Z_old) through K gamma draws, lane k draws component k
       double a_old[KMAX], a_new[KMAX], Znew[KMAX];
-      double mygam = 0.0;
+      double mygam = 0.0, mylg = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         a_old[k] = c.h.a_Z_PM * Zold[k];
         if (k < K && lp == k) {
           const double a = (a_old[k] <= 0) ? 10.0 : a_old[k];            // Distributions.h:24-28
           mygam = rgamma(key, UPD_Z_PROP, (uint32_t)(i * K + k), a, 1.0);
+          mylg = lgamma(a_old[k]);
         }
       }
-      double gsum_ = 0.0;
+      double gs = 0.0, lB_old = 0.0, sa_old = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         Znew[k] = (k < K) ? __shfl(mygam, k, LPC) : 0.0;
-        if (k < K) gsum_ += Znew[k];
+        if (k < K) { gs += Znew[k]; lB_old += __shfl(mylg, k, LPC); sa_old += a_old[k]; }
       }
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) { Znew[k] = Znew[k] / gsum_; a_new[k] = c.h.a_Z_PM * Znew[k]; }
+      for (int k = 0; k < KMAX; ++k) { Znew[k] = Znew[k] / gs; a_new[k] = c.h.a_Z_PM * Znew[k]; }
+      // lane k: lgamma(a_new_k); lane K: lgamma(sum a_old); lane K+1: lgamma(sum a_new)
+      double sa_new = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K) sa_new += a_new[k];
+      double lgv = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) lgv = lgamma(a_new[k]);
+      if (lp == K) lgv = lgamma(sa_old);
+      if (lp == K + 1) lgv = lgamma(sa_new);
+      double lB_new = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K) lB_new += __shfl(lgv, k, LPC);
+      lB_old -= __shfl(lgv, K, LPC);
+      lB_new -= __shfl(lgv, K + 1, LPC);
       // quadratic form of the residual sum of squares in Z
       double q_old = cv.yy, q_new = cv.yy, pr_old = 0.0, pr_new = 0.0, dn = 0.0, dold = 0.0;
 #pragma unroll
@@ -150,8 +200,8 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       }
       const double z_lpdf = pr_old - beta * (q_old / (2.0 * sigma2));
       const double z_new_lpdf = pr_new - beta * (q_new / (2.0 * sigma2));
-      const double lpdf_propose_new = dn - calc_lB(K, a_old);
-      const double lpdf_propose_old = dold - calc_lB(K, a_new);
+      const double lpdf_propose_new = dn - lB_old;
+      const double lpdf_propose_old = dold - lB_new;
       double acceptance = z_new_lpdf - z_lpdf + lpdf_propose_old - lpdf_propose_new;
       const double uu = runif(key, UPD_Z_ACC, (uint32_t)i);
 #pragma unroll
@@ -182,47 +232,54 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
 
 // ------------------------------------------------------------------------------------------------
 // chi update + per-curve residual sum of squares.  do_update == 0 computes only the residuals.
+// LDS per group: U[M], GU[M], C0 (1), D = s - G c0 (1), chi (MMAX), z (MMAX), res (MMAX(MMAX+1)/2 + MMAX + 2)
 // ------------------------------------------------------------------------------------------------
 template <int BW, int LPC>
 __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
+  using T = Tile<BW, LPC>;
   const Dims& d = c.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
+  const int nth = K * (M + 1) * P;
+  const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
+  const int ntask = Mu * (Mu + 1) / 2 + Mu + 2;
   double* sTh = smem;
-  double* sRss = smem + (size_t)K * (M + 1) * P;
-  for (int q = threadIdx.x; q < K * (M + 1) * P; q += 256) sTh[q] = c.theta[q];
-  __syncthreads();
+  double* sRss = sTh + nth;                         // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
+  const int per_group = (2 * M + 3) * T::STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2);
+  double* gbase = sRss + GPB + (size_t)grp * per_group;
+  T tU{gbase}, tG{gbase + M * T::STR}, tX{gbase + 2 * M * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
+  double* sChi = gbase + (2 * M + 3) * T::STR;
+  double* sZn = sChi + MMAX;
+  double* sRes = sZn + MMAX;
+  for (int q = threadIdx.x; q < nth; q += 256) sTh[q] = c.theta[q];
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
   const double sigma2 = dyn->sigma2, beta = dyn->beta;
+  Curve<BW, LPC> cv;
+  if (valid) {
+    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
+    tU.zero_pads(2 * M + 3, lp);
+    if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
+    tX.row(2)[lp] = cv.s;
+  }
+  __syncthreads();
   double rss = 0.0;
   if (valid) {
-    Curve<BW, LPC> cv;
-    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
     double Zi[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zi[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
-    // fitted coefficient c_i and g = G c_i
+    // u_m = sum_k Z_k phi_km ;  c0 = sum_k Z_k nu_k + sum_m chi_m u_m
     double cf = 0.0;
     if (act) {
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
-        if (k < K) {
-          const double* th = sTh + (size_t)k * (M + 1) * P;
-          double v = th[lp];
-          if (MD > 1)
-            for (int m = 0; m < M; ++m) v += c.chi[i + (size_t)n * m] * th[(m + 1) * P + lp];
-          cf += Zi[k] * v;
-        }
+        if (k < K) cf += Zi[k] * sTh[(size_t)k * (M + 1) * P + lp];
     }
-    double gv = cv.matvec(cf);
-    if (do_update && MD > 1) {
-      const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-      double* cslot = c.c_chi + (size_t)dyn->slot * n * M;
+    if (MD > 1) {
       for (int m = 0; m < M; ++m) {
         double um = 0.0;
         if (act) {
@@ -230,20 +287,72 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
           for (int k = 0; k < KMAX; ++k)
             if (k < K) um += Zi[k] * sTh[((size_t)k * (M + 1) + m + 1) * P + lp];
         }
-        const double Gum = cv.matvec(um);
-        const double W0 = gsum<LPC>(um * Gum);
-        const double r1 = gsum<LPC>(um * (cv.s - gv));
-        const double chi_old = c.chi[i + (size_t)n * m];
-        const double w = ((r1 + chi_old * W0) * beta) / sigma2;
-        const double W = 1.0 / (1.0 + ((W0 * beta) / sigma2));
-        const double chi_new = W * w + sqrt(W) * rnorm(key, UPD_CHI, (uint32_t)(i * M + m));
-        const double dl = chi_new - chi_old;
-        cf += dl * um;
-        gv += dl * Gum;
-        if (lp == 0) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; }
+        if (m < Mu) tU.row(m)[lp] = um;
+        cf += sChi[m] * um;
       }
     }
-    rss = cv.yy - 2.0 * gsum<LPC>(cf * cv.s) + gsum<LPC>(cf * gv);
+    tX.row(0)[lp] = cf;
+    __builtin_amdgcn_wave_barrier();
+    const double g0 = cv.matvec(tX.row(0), lp);
+    tX.row(1)[lp] = cv.s - g0;
+    for (int m = 0; m < Mu; ++m) tG.row(m)[lp] = cv.matvec(tU.row(m), lp);
+    __builtin_amdgcn_wave_barrier();
+    // tasks: [0, Mu(Mu+1)/2): A_{m,m2} = u_m' G u_m2 (m <= m2);  then Mu of b_m = u_m'(s - G c0);
+    //        then  c0's  and  c0'(s - G c0)
+    const int nA = Mu * (Mu + 1) / 2;
+    for (int q = lp; q < ntask; q += LPC) {
+      double r;
+      if (q < nA) {
+        int a = 0, rem = q;
+        while (rem >= Mu - a) { rem -= Mu - a; ++a; }
+        r = dotP(tU.row(a), tG.row(a + rem), P);
+      } else if (q < nA + Mu) {
+        r = dotP(tU.row(q - nA), tX.row(1), P);
+      } else if (q == nA + Mu) {
+        r = dotP(tX.row(0), tX.row(2), P);
+      } else {
+        r = dotP(tX.row(0), tX.row(1), P);
+      }
+      sRes[q] = r;
+    }
+    if (Mu > 0) {
+      const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+      if (lp < M) sZn[lp] = rnorm(key, UPD_CHI, (uint32_t)(i * M + lp));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)
+    rss = cv.yy - sRes[nA + Mu] - sRes[nA + Mu + 1];
+    if (Mu > 0) {
+      // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
+      double dl[MMAX];
+      double* cslot = c.c_chi + (size_t)dyn->slot * n * M;
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
+        dl[m] = 0.0;
+        if (m < M) {
+          double r1 = sRes[nA + m];
+#pragma unroll
+          for (int m2 = 0; m2 < MMAX; ++m2)
+            if (m2 < m) r1 -= sRes[tri_index(M, m2, m)] * dl[m2];
+          const double W0 = sRes[tri_index(M, m, m)];
+          const double chi_old = sChi[m];
+          const double w = ((r1 + chi_old * W0) * beta) / sigma2;
+          const double W = 1.0 / (1.0 + ((W0 * beta) / sigma2));
+          const double chi_new = W * w + sqrt(W) * sZn[m];
+          dl[m] = chi_new - chi_old;
+          if (lp == m) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; }
+        }
+      }
+      // rss(c0 + sum_m dl_m u_m) = rss0 - 2 sum_m dl_m b_m + sum_{m,m2} dl_m dl_m2 A_{m,m2}
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m)
+        if (m < M) {
+          rss -= 2.0 * dl[m] * sRes[nA + m];
+#pragma unroll
+          for (int m2 = 0; m2 < MMAX; ++m2)
+            if (m2 < M) rss += dl[m] * dl[m2] * sRes[tri_index(M, min(m, m2), max(m, m2))];
+        }
+    }
   }
   if (lp == 0) sRss[grp] = rss;
   __syncthreads();
@@ -260,7 +369,13 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int LPC = (c.d.P <= 32) ? 32 : 64;
   const int GPB = 256 / LPC;
   const int nblk = (c.d.n + GPB - 1) / GPB;
-  const size_t lds = ((size_t)c.d.K * (c.d.M + 1) * c.d.P + GPB * KMAX + 8) * sizeof(double);
+  const int K = c.d.K, M = c.d.M;
+  const int STR = LPC + 2 * BW;
+  const size_t nth = (size_t)K * (M + 1) * c.d.P;
+  size_t lds;
+  if (which == 0) lds = nth + GPB * KMAX + (size_t)GPB * ((2 * K + 1) * STR + MMAX + 32);
+  else lds = nth + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2));
+  lds = (lds + 8) * sizeof(double);
   if (LPC == 32) {
     if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);
     else hipLaunchKernelGGL((k_curve_chi<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);
@@ -270,7 +385,20 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   }
 }
 
+template <int BW>
+static void prepare_bw() {
+  set_max_lds((const void*)k_curve_z<BW, 32>);
+  set_max_lds((const void*)k_curve_z<BW, 64>);
+  set_max_lds((const void*)k_curve_chi<BW, 32>);
+  set_max_lds((const void*)k_curve_chi<BW, 64>);
+}
+
+void prepare_curve_kernels() {
+  prepare_bw<0>(); prepare_bw<1>(); prepare_bw<2>(); prepare_bw<3>(); prepare_bw<4>(); prepare_bw<5>();
+}
+
 int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st) {
+  if (c.d.M > MMAX) return 2;
   switch (c.d.BW) {
     case 0: launch_curve_bw<0>(c, which, do_update, st); break;
     case 1: launch_curve_bw<1>(c, which, do_update, st); break;

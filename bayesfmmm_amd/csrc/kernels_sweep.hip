@@ -13,11 +13,15 @@
 //
 //   k_pair_gram : [R pair weights x n] * [n x LG record columns]  -> v_mfma_f64_16x16x4_f64, split-K
 //   k_pg_reduce : fixed-order sum of the split-K partial tiles -> H (R x LG), t (A x P)
-//   k_factor    : one workgroup per direction: C_a (Gauss-Jordan inverse), chol_lower(C_a)
-//   k_sweep     : pi, alpha_3, Phi sweep, delta, A, gamma, nu sweep, tau, sigma^2 in reference order
+//   k_factor    : one workgroup per direction: reverse Cholesky of Prec_a -> chol_lower(C_a), C_a, L_a z_a
+//   k_sweep     : Phi sweep, nu sweep, sigma^2 (the critical chain)
+//   k_pi_alpha  : pi, alpha_3          (off the critical path)
+//   k_hyper     : delta, A, gamma, tau (off the critical path)
 //   k_loglik    : calcLikelihood (CalculateLikelihood.h:19-44) from the per-curve residual sums
 #include "model.hpp"
 #include "rng.hpp"
+
+#include <algorithm>
 
 namespace bfmmm {
 
@@ -26,16 +30,25 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // pair-Gram
 // ---------------------------------------------------------------------------------------------
-// grid = (NTG tile groups, NKS k-slices); block = 256 (4 waves).  Tile t of the NT output tiles
-// belongs to group t % NTG and, inside the group, to wave (t / NTG) % 4.
-__global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int NTG, int KS) {
+// grid = (CTG + 1, NKS); block = 256 (4 waves).  Workgroup (ct, ks) owns the 16 record columns
+// [16 ct, 16 ct + 16) of the G part for the KS curves of k-slice ks: it stages them once in LDS
+// (coalesced 128-byte segments) and its four waves walk the RT row tiles of pair weights, each
+// wave issuing one v_mfma_f64_16x16x4_f64 per 4 curves and row tile; the weights w_ai w_bi are
+// rebuilt on the fly from Z and chi (also staged in LDS).  Workgroup (CTG, ks) does the same for the
+// single-weight rows against the s part of the records (t_a = sum_i w_ai s_i).
+__global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
-  const int n = d.n, K = d.K, M = d.M, MD = d.MD;
-  const int ks = blockIdx.y, tg = blockIdx.x;
+  const int n = d.n, K = d.K, MD = d.MD;
+  const int ks = blockIdx.y, ct = blockIdx.x;
+  const bool single = ct == d.CTG;
+  const int ncol = single ? d.CTS * 16 : 16;
+  const int col0 = single ? d.LG : ct * 16;
+  const int colend = single ? d.LG + d.P : d.LG;
   const int i0 = ks * KS;
-  double* sZ = smem;                 // KS x K
-  double* sC = smem + (size_t)KS * K;  // KS x MD   (chit: 1, chi_1..chi_M)
+  double* sZ = smem;                         // KS x K
+  double* sC = sZ + (size_t)KS * K;          // KS x MD   (chit: 1, chi_1..chi_M)
+  double* sB = sC + (size_t)KS * MD;         // KS x ncol
   for (int q = threadIdx.x; q < KS * K; q += 256) {
     const int il = q / K, k = q - il * K, i = i0 + il;
     sZ[q] = (i < n) ? c.Z[i + (size_t)n * k] : 0.0;
@@ -44,25 +57,26 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int NTG, int KS) {
     const int il = q / MD, mt = q - il * MD, i = i0 + il;
     sC[q] = (i < n) ? ((mt == 0) ? 1.0 : c.chi[i + (size_t)n * (mt - 1)]) : 0.0;
   }
+  for (int q = threadIdx.x; q < KS * ncol; q += 256) {
+    const int il = q / ncol, cc = q - il * ncol, i = i0 + il, col = col0 + cc;
+    sB[q] = (i < n && col < colend) ? c.rec[(size_t)i * d.LREC + col] : 0.0;
+  }
   __syncthreads();
-  (void)M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
-  const int n_pair_tiles = d.RT * d.CTG;
-  for (int t = tg + NTG * wave; t < d.NT; t += NTG * 4) {
-    int row, col;
-    bool rvalid, cvalid;
+  const int ntile = single ? d.AT * d.CTS : d.RT;
+  for (int tt = wave; tt < ntile; tt += 4) {
+    int row, t, bcol;
+    bool rvalid;
     int j1 = 0, j2 = 0, m1 = 0, m2 = 0;
-    if (t < n_pair_tiles) {
-      const int rt = t / d.CTG, ct = t - rt * d.CTG;
-      row = rt * 16 + lr;
-      col = ct * 16 + lr;
+    if (!single) {
+      row = tt * 16 + lr;
+      t = tt * d.CTG + ct;
+      bcol = lr;
       rvalid = row < d.R;
-      cvalid = col < d.LG;
       if (rvalid) {
         const int zz = row / d.NCC, cc = row - zz * d.NCC;
-        // invert the packed-upper-triangle indices
-        int a = 0, rem = zz;
+        int a = 0, rem = zz;                       // invert the packed-upper-triangle indices
         while (rem >= K - a) { rem -= K - a; ++a; }
         j1 = a; j2 = a + rem;
         a = 0; rem = cc;
@@ -70,26 +84,28 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int NTG, int KS) {
         m1 = a; m2 = a + rem;
       }
     } else {
-      const int t2 = t - n_pair_tiles;
-      const int at = t2 / d.CTS, cs = t2 - at * d.CTS;
+      const int at = tt / d.CTS, cs = tt - at * d.CTS;
       row = at * 16 + lr;
-      col = d.LG + cs * 16 + lr;
+      t = d.RT * d.CTG + tt;
+      bcol = cs * 16 + lr;
       rvalid = row < d.A;
-      cvalid = col < d.LG + d.P;
       if (rvalid) { j1 = row / MD; m1 = row - j1 * MD; }
     }
-    const bool single = t >= n_pair_tiles;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    const double* recp = c.rec + (size_t)(i0 + kq) * d.LREC + col;
-    for (int kk = 0; kk < KS; kk += 4) {
-      const int il = kk + kq;
-      double a = 0.0, b = 0.0;
-      if (rvalid) {
-        a = sZ[il * K + j1] * sC[il * MD + m1];
-        if (!single) a *= sZ[il * K + j2] * sC[il * MD + m2];
+    if (single) {
+#pragma unroll 4
+      for (int kk = 0; kk < KS; kk += 4) {
+        const int il = kk + kq;
+        const double a = rvalid ? sZ[il * K + j1] * sC[il * MD + m1] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[il * ncol + bcol], acc, 0, 0, 0);
       }
-      if (cvalid && (i0 + il) < n) b = recp[(size_t)kk * d.LREC];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < KS; kk += 4) {
+        const int il = kk + kq;
+        const double a = rvalid ? (sZ[il * K + j1] * sZ[il * K + j2]) * (sC[il * MD + m1] * sC[il * MD + m2]) : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[il * 16 + bcol], acc, 0, 0, 0);
+      }
     }
     double* out = c.pg_part + ((size_t)ks * d.NT + t) * 256 + lane;
     out[0] = acc[0]; out[64] = acc[1]; out[128] = acc[2]; out[192] = acc[3];
@@ -97,6 +113,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int NTG, int KS) {
 }
 
 // one thread per element of every output tile; fixed summation order over the k-slices
+// (four interleaved partial sums, combined in a fixed order)
 __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c, int NKS) {
   const Dims& d = c.d;
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -104,8 +121,18 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c, int NKS) {
   const int t = gid >> 8, q = gid & 255;
   const int r = q >> 6, lane = q & 63;
   const int rit = (lane >> 4) + 4 * r, cit = lane & 15;   // D layout of v_mfma_f64_16x16x4_f64
-  double s = 0.0;
-  for (int ks = 0; ks < NKS; ++ks) s += c.pg_part[((size_t)ks * d.NT + t) * 256 + q];
+  const double* src = c.pg_part + (size_t)t * 256 + q;
+  const size_t stride = (size_t)d.NT * 256;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int ks = 0;
+  for (; ks + 4 <= NKS; ks += 4) {
+    s0 += src[(size_t)(ks + 0) * stride];
+    s1 += src[(size_t)(ks + 1) * stride];
+    s2 += src[(size_t)(ks + 2) * stride];
+    s3 += src[(size_t)(ks + 3) * stride];
+  }
+  for (; ks < NKS; ++ks) s0 += src[(size_t)ks * stride];
+  const double s = (s0 + s1) + (s2 + s3);
   const int n_pair_tiles = d.RT * d.CTG;
   if (t < n_pair_tiles) {
     const int rt = t / d.CTG, ct = t - rt * d.CTG;
@@ -127,6 +154,11 @@ __device__ inline int hrow(const Dims& d, int a, int b) {   // a, b: active dire
   const int zz = tri_index(d.K, min(ja, jb), max(ja, jb));
   const int cc = tri_index(d.MD, min(ma, mb), max(ma, mb));
   return zz * d.NCC + cc;
+}
+
+__device__ inline int full_dir(const Dims& d, int a) {   // active direction -> row of c.theta
+  const int j = a / d.MD, mt = a - j * d.MD;
+  return j * (d.M + 1) + mt;
 }
 
 // (H_block * v)[p] for a band-packed symmetric block
@@ -154,22 +186,50 @@ __device__ inline double block_sum256(double v, double* scratch) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_factor: one workgroup per active direction.
-//   Prec = (beta/sigma^2) H_aa + Prior;  C = Prec^-1 (in-place Gauss-Jordan; SPD so no pivoting);
-//   C <- (C + C')/2 (UpdateNu.h:68);  L = chol_lower(C) (what arma::mvnrnd factors, UpdateNu.h:69).
-// Non-positive pivots set dyn->status bit 0: the reference would fall back to pinv / eig there.
+// k_factor: one workgroup per active direction a.
+//   r_a  = t_a - sum_b H_ab theta_b,  hq_a = H_aa theta_a      (always: the sweep starts from these)
+//   Prec = (beta/sigma^2) H_aa + Prior_a                        (banded: half-width BWP)
+//   Prec = U U'  with U UPPER triangular ("reverse" Cholesky, processed from the last row up).
+//   Then  C = Prec^-1 = U^-T U^-1  and, because U^-T is lower triangular with positive diagonal,
+//   chol_lower(C) = U^-T  exactly -- the factor arma::mvnrnd(C b, C) multiplies z by
+//   (UpdateNu.h:67-69, UpdatePhi.h:79-82).  So one banded factorisation + one triangular inverse
+//   give both the reference's covariance C and its Cholesky factor L; no dense inverse is formed
+//   by elimination.  The direction's normal variates z and L z are produced here as well, so the
+//   sequential sweep only has to apply C.
+// A non-positive pivot sets dyn->status bit 0 (the reference would take arma::pinv / the
+// eigen-decomposition fallback of mvnrnd there).
 // ---------------------------------------------------------------------------------------------
+template <int PP>
 __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
-  const int P = d.P, MD = d.MD, K = d.K;
-  const int a = blockIdx.x;
+  const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
+  const int a = blockIdx.x, tid = threadIdx.x;
   const int j = a / MD, mt = a - j * MD;
-  if (mt == 0 && !(c.mask & U_NU)) return;
-  if (mt > 0 && !(c.mask & U_PHI)) return;
-  double* S = smem;               // P x P column-major
-  double* rowk = smem + (size_t)P * P;
-  double* colk = rowk + P;
+  double* S = smem;                 // PP x PP : Prec, then U in its upper triangle (col-major, S[i + PP*k])
+  double* X = S + PP * PP;          // PP x PP : U^-1, row-major X[i*PP + c]
+  double* th = X + PP * PP;         // A x P
+  double* part = th + A * P;        // A x P
+  double* zv = part + A * P;        // PP
+  for (int e = tid; e < A * P; e += 256) {
+    const int b = e / P, p = e - b * P;
+    th[e] = c.theta[(size_t)full_dir(d, b) * P + p];
+  }
+  __syncthreads();
+  for (int e = tid; e < A * P; e += 256) {
+    const int b = e / P, p = e - b * P;
+    part[e] = band_mv(c.H + (size_t)hrow(d, a, b) * d.LG, th + b * P, P, d.BW, p);
+  }
+  __syncthreads();
+  if (tid < P) {
+    double acc = c.tvec[a * P + tid];
+    for (int b = 0; b < A; ++b) acc -= part[b * P + tid];
+    c.rvec[a * P + tid] = acc;
+    c.hq[a * P + tid] = part[a * P + tid];
+  }
+  const bool upd_nu = (mt == 0) && (c.mask & U_NU);
+  const bool upd_phi = (mt > 0) && (c.mask & U_PHI);
+  if (!upd_nu && !upd_phi) return;
   const Dyn* dyn = c.dyn;
   const double f = dyn->beta / dyn->sigma2;
   const double* Hb = c.H + (size_t)hrow(d, a, a) * d.LG;
@@ -178,351 +238,487 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   if (mt > 0)
     for (int m2 = 0; m2 < mt; ++m2) tt *= c.delta[j + (size_t)K * m2];
   const double tau_j = dyn->tau[j];
-  for (int e = threadIdx.x; e < P * P; e += 256) {
-    const int p = e % P, q = e / P;
-    const int lo = min(p, q), dd = max(p, q) - lo;
-    double v = (dd <= d.BW) ? f * Hb[dd * P + lo] : 0.0;
-    if (mt == 0) {
-      if (d.mv) { if (p == q) v += 1.0 / tau_j; }               // UpdateNu.h:197 (MV)
-      else v += tau_j * c.Pmat[p + (size_t)P * q];                // UpdateNu.h:66
-    } else if (p == q) {
-      v += tt * c.gamma[j + (size_t)K * (p + (size_t)P * (mt - 1))];   // UpdatePhi.h:76-78
+  for (int e = tid; e < PP * PP; e += 256) {
+    const int p = e & (PP - 1), q = e / PP;
+    double v = 0.0;
+    if (p < P && q < P) {
+      const int lo = min(p, q), dd = max(p, q) - lo;
+      v = (dd <= d.BW) ? f * Hb[dd * P + lo] : 0.0;
+      if (mt == 0) {
+        if (d.mv) { if (p == q) v += 1.0 / tau_j; }               // UpdateNu.h:197 (MV)
+        else v += tau_j * c.Pmat[p + (size_t)P * q];                // UpdateNu.h:66
+      } else if (p == q) {
+        v += tt * c.gamma[j + (size_t)K * (p + (size_t)P * (mt - 1))];   // UpdatePhi.h:76-78
+      }
     }
     S[e] = v;
+    X[e] = 0.0;
+  }
+  if (tid >= 64 && tid < 64 + P) {
+    const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+    const uint32_t idx0 = (mt == 0) ? (uint32_t)(j * P) : (uint32_t)((j * M + (mt - 1)) * P);
+    zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
   }
   __syncthreads();
+  const int bw = d.BWP;
   bool bad = false;
-  // in-place Gauss-Jordan inversion
-  for (int k = 0; k < P; ++k) {
-    if ((int)threadIdx.x < P) { rowk[threadIdx.x] = S[k + (size_t)P * threadIdx.x]; colk[threadIdx.x] = S[threadIdx.x + (size_t)P * k]; }
-    __syncthreads();
-    const double piv = rowk[k];
-    if (!(piv > 0.0)) bad = true;
-    const double inv = 1.0 / piv;
-    for (int e = threadIdx.x; e < P * P; e += 256) {
-      const int p = e % P, q = e / P;
-      double v;
-      if (p == k && q == k) v = inv;
-      else if (p == k) v = rowk[q] * inv;
-      else if (q == k) v = -colk[p] * inv;
-      else v = S[e] - colk[p] * rowk[q] * inv;
-      S[e] = v;
+  if (tid < 64) {
+    // reverse Cholesky Prec = U U', one wave, LDS traffic is wave-ordered
+    for (int k = P - 1; k >= 0; --k) {
+      const int jhi = min(k + bw, P - 1);
+      double dkk = S[k + PP * k];
+      for (int jj = k + 1; jj <= jhi; ++jj) { const double u = S[k + PP * jj]; dkk -= u * u; }
+      if (!(dkk > 0.0)) bad = true;
+      const double ukk = sqrt(dkk);
+      const int i = k - 1 - tid;
+      double uik = 0.0;
+      if (tid < bw && i >= 0) {
+        double acc = S[i + PP * k];
+        const int j2 = min(i + bw, P - 1);
+        for (int jj = k + 1; jj <= j2; ++jj) acc -= S[i + PP * jj] * S[k + PP * jj];
+        uik = acc / ukk;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) S[k + PP * k] = ukk;
+      if (tid < bw && i >= 0) S[i + PP * k] = uik;
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-  }
-  // symmetrise and store C
-  double* Cg = c.Cmat + (size_t)a * P * P;
-  for (int e = threadIdx.x; e < P * P; e += 256) {
-    const int p = e % P, q = e / P;
-    Cg[e] = 0.5 * (S[p + (size_t)P * q] + S[q + (size_t)P * p]);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < P * P; e += 256) S[e] = Cg[e];
-  __syncthreads();
-  // right-looking Cholesky, lower triangle in place
-  for (int k = 0; k < P; ++k) {
-    const double piv = S[k + (size_t)P * k];
-    if (!(piv > 0.0)) bad = true;
-    __syncthreads();
-    const double lkk = sqrt(piv);
-    if ((int)threadIdx.x < P) {
-      const int p = threadIdx.x;
-      if (p == k) S[k + (size_t)P * k] = lkk;
-      else if (p > k) S[p + (size_t)P * k] = S[p + (size_t)P * k] / lkk;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < P * P; e += 256) {
-      const int p = e % P, q = e / P;
-      if (q > k && p >= q) S[e] -= S[p + (size_t)P * k] * S[q + (size_t)P * k];
-    }
-    __syncthreads();
-  }
-  double* Lg = c.Lmat + (size_t)a * P * P;
-  for (int e = threadIdx.x; e < P * P; e += 256) {
-    const int p = e % P, q = e / P;
-    Lg[e] = (p >= q) ? S[e] : 0.0;
-  }
-  if (bad && threadIdx.x == 0) atomicOr(&c.dyn->status, 1u);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_sweep: the sequentially dependent part of one Gibbs iteration, one workgroup of 256 threads.
-// ---------------------------------------------------------------------------------------------
-struct SweepLds {
-  double* th;     // A x P   current theta of the active directions
-  double* tv;     // A x P   t_a
-  double* r;      // A x P   r_a = t_a - sum_b H_ab theta_b
-  double* rhs;    // P
-  double* z;      // P
-  double* nw;     // P
-  double* dl;     // P
-  double* red;    // 256
-  double* sm;     // small scratch (64)
-};
-
-__device__ inline int full_dir(const Dims& d, int a) {   // active direction -> row of c.theta
-  const int j = a / d.MD, mt = a - j * d.MD;
-  return j * (d.M + 1) + mt;
-}
-
-// one Gaussian block draw for direction a (UpdateNu.h:64-69 / UpdatePhi.h:72-82)
-__device__ inline void gauss_step(const Ctx& c, const SweepLds& L, int a, uint32_t upd, uint32_t idx0,
-                                  const RngKey& key, double f) {
-  const Dims& d = c.d;
-  const int P = d.P, A = d.A, tid = threadIdx.x;
-  const double* Haa = c.H + (size_t)hrow(d, a, a) * d.LG;
   if (tid < P) {
-    L.rhs[tid] = f * (L.r[a * P + tid] + band_mv(Haa, L.th + a * P, P, d.BW, tid));
-  } else if (tid >= 64 && tid < 64 + P) {
-    L.z[tid - 64] = rnorm(key, upd, idx0 + (uint32_t)(tid - 64));
-  }
-  __syncthreads();
-  // new = C rhs + L z : 8 threads per row, fixed-order combine
-  const double* Cg = c.Cmat + (size_t)a * P * P;
-  const double* Lg = c.Lmat + (size_t)a * P * P;
-  for (int p = tid >> 3; p < P; p += 32) {
-    const int seg = tid & 7;
-    double acc = 0.0;
-    for (int q = seg; q < P; q += 8) {
-      acc += Cg[p + (size_t)P * q] * L.rhs[q];
-      if (q <= p) acc += Lg[p + (size_t)P * q] * L.z[q];
+    // column c of X = U^-1 by back substitution (banded U)
+    const int cc = tid;
+    X[cc * PP + cc] = 1.0 / S[cc + PP * cc];
+    for (int i = cc - 1; i >= 0; --i) {
+      double acc = 0.0;
+      const int j2 = min(i + bw, cc);
+      for (int jj = i + 1; jj <= j2; ++jj) acc += S[i + PP * jj] * X[jj * PP + cc];
+      X[i * PP + cc] = -acc / S[i + PP * i];
     }
-    // combine the 8 segment partials in a fixed order (lanes tid..tid+7 share a wave)
-    acc += __shfl_xor(acc, 1, 8);
-    acc += __shfl_xor(acc, 2, 8);
-    acc += __shfl_xor(acc, 4, 8);
-    if (seg == 0) { L.nw[p] = acc; L.dl[p] = acc - L.th[a * P + p]; }
   }
   __syncthreads();
-  if (tid < P) L.th[a * P + tid] = L.nw[tid];
-  // r_b -= H_ba (theta_new - theta_old) for every direction b
-  for (int e = tid; e < A * P; e += 256) {
-    const int b = e / P, p = e - b * P;
-    const double* Hb = c.H + (size_t)hrow(d, b, a) * d.LG;
-    L.r[e] -= band_mv(Hb, L.dl, P, d.BW, p);
+  // L = X' (lower), C = L L', L z
+  double* Cg = c.Cmat + (size_t)a * P * P;
+  double* Lg = c.Lmat + (size_t)a * P * P;
+  for (int e = tid; e < PP * PP; e += 256) {
+    const int p = e & (PP - 1), q = e / PP;
+    if (p < P && q < P) {
+      const int kmax = min(p, q);
+      double acc = 0.0;
+      for (int k = 0; k <= kmax; ++k) acc += X[k * PP + p] * X[k * PP + q];
+      Cg[p + (size_t)P * q] = acc;
+      Lg[p + (size_t)P * q] = (q <= p) ? X[q * PP + p] : 0.0;
+    }
   }
-  __syncthreads();
+  if (tid < P) {
+    double acc = 0.0;
+    for (int q = 0; q <= tid; ++q) acc += X[q * PP + tid] * zv[q];
+    c.Lz[a * P + tid] = acc;
+  }
+  if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 
-__device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
+// ---------------------------------------------------------------------------------------------
+// k_sweep: the sequentially dependent Gaussian block draws of one Gibbs iteration
+// (updatePhi: j outer, m inner, UpdatePhi.h:40-84; then updateNu, UpdateNu.h:39-70) and sigma^2
+// (UpdateSigma.h:22-58).  One workgroup of 1024 threads; two barriers per draw:
+//   phase A  theta_a <- C_a rhs_a + (L z)_a                          (8 threads per row)
+//   phase B  r_b -= H_ba (theta_a_new - theta_a_old) for every b     (one thread per element)
+//            and, for the next direction a', rhs_a' = (beta/sigma^2)(r_a' + H_a'a' theta_a')
+// The column blocks H_{.,a} and C_a of the NEXT step are fetched into registers while the
+// current step runs and parked in the other half of an LDS double buffer, so no step waits on
+// global memory.
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_THREADS = 1024;
+constexpr int NPF = 6;            // staged doubles per thread and step: A*LG + P*P <= 6144
 
-__device__ inline double lpdf_a1(const Hyper& h, double a, double delta) {    // UpdateA.h:17-24
-  return -logGamma_ref(a) + (a - 1) * log(delta) + (h.alpha1l - 1) * log(a) - (a * h.beta1l);
-}
-__device__ inline double lpdf_a2(const Hyper& h, double a, int M, const double* delta_row, int stride) {  // :33-44
-  const double x = M - 1;
-  double lpdf = -x * logGamma_ref(a) + (h.alpha2l - 1) * log(a) - (a * h.beta2l);
-  for (int i = 1; i < M; ++i) lpdf = lpdf + (a - 1) * log(delta_row[(size_t)i * stride]);
-  return lpdf;
+__device__ inline int step_dir(const Dims& d, int s, int n_phi) {
+  if (s < n_phi) {
+    const int j = s / d.M, m = s - j * d.M;
+    return j * d.MD + m + 1;
+  }
+  return (s - n_phi) * d.MD;
 }
 
-__global__ __launch_bounds__(256) void k_sweep(Ctx c) {
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
-  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD, n = d.n;
+  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD, BW = d.BW, LG = d.LG;
   const int tid = threadIdx.x;
   Dyn* dyn = c.dyn;
-  SweepLds L;
-  L.th = smem; L.tv = L.th + A * P; L.r = L.tv + A * P; L.rhs = L.r + A * P;
-  L.z = L.rhs + PMAX; L.nw = L.z + PMAX; L.dl = L.nw + PMAX; L.red = L.dl + PMAX; L.sm = L.red + 256;
+  const int AP = A * P;
+  const int PS = P + 2 * BW;                 // padded vector stride
+  double* th = smem;                         // A x PS (zero pads)
+  double* tv = th + A * PS;                  // A x P
+  double* r = tv + AP;                       // A x P
+  double* hq = r + AP;                       // A x P   H_aa theta_a
+  double* lz = hq + AP;                      // A x P   L_a z_a
+  double* rhs = lz + AP;                     // PMAX
+  double* dlp = rhs + PMAX;                  // PMAX + 2*BWMAX (zero pads)
+  double* red = dlp + PMAX + 2 * BWMAX;      // 32
+  const int pf_len = A * LG + P * P;
+  double* pbuf0 = red + 32;
+  double* pbuf1 = pbuf0 + pf_len;
+  int* htab = (int*)(pbuf1 + pf_len);        // A x A : H row of block (b, a)
   const uint32_t slot = dyn->slot;
-  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-  const double beta = dyn->beta;
   const uint32_t mask = c.mask;
+  const double beta = dyn->beta;
+  const double f = beta / dyn->sigma2;
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
+  const int n_nu = (mask & U_NU) ? K : 0;
+  const int n_steps = n_phi + n_nu;
 
-  // ---------------- pi (updatePi_PM, UpdatePi.h:84-116) and alpha_3 (UpdateAlpha3.h:36-63) -------
-  if (mask & (U_PI | U_ALPHA3)) {
-    // S_k = sum_i log Z_ik from the block partials of k_curve_z, fixed order
-    for (int k = 0; k < K; ++k) {
-      double acc = 0.0;
-      const int per = (c.nblk_curve + 255) / 256;
-      for (int b = tid * per; b < min(c.nblk_curve, (tid + 1) * per); ++b) acc += c.logz_part[(size_t)b * K + k];
-      const double s = block_sum256(acc, L.red);
-      if (tid == 0) L.sm[k] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double pi[KMAX], pi_ph[KMAX], a_old[KMAX], a_new[KMAX], ap[KMAX];
-      double alpha3 = dyn->alpha3;
-      for (int k = 0; k < K; ++k) pi[k] = dyn->pi[k];
-      if (mask & U_PI) {
-        double sum = 0.0;
-        for (int k = 0; k < K; ++k) {
-          a_old[k] = c.h.a_pi_PM * pi[k];
-          const double aa = (a_old[k] <= 0) ? 10.0 : a_old[k];
-          pi_ph[k] = rgamma(key, UPD_PI_PROP, (uint32_t)k, aa, 1.0);
-          sum += pi_ph[k];
-        }
-        for (int k = 0; k < K; ++k) { pi_ph[k] /= sum; a_new[k] = c.h.a_pi_PM * pi_ph[k]; }
-        double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
-        for (int k = 0; k < K; ++k) {
-          lpdf_new += (c.h.c[k] - 1) * log(pi_ph[k]) + ((alpha3 * pi_ph[k]) - 1) * L.sm[k];
-          lpdf_old += (c.h.c[k] - 1) * log(pi[k]) + ((alpha3 * pi[k]) - 1) * L.sm[k];
-          pn += (a_old[k] - 1) * log(pi_ph[k]);
-          po += (a_new[k] - 1) * log(pi[k]);
-        }
-        for (int k = 0; k < K; ++k) ap[k] = alpha3 * pi_ph[k];
-        lpdf_new -= n * calc_lB(K, ap);
-        for (int k = 0; k < K; ++k) ap[k] = alpha3 * pi[k];
-        lpdf_old -= n * calc_lB(K, ap);
-        const double lpn = pn - calc_lB(K, a_old);
-        const double lpo = po - calc_lB(K, a_new);
-        const double acc = lpdf_new - lpdf_old + lpo - lpn;
-        const double u = runif(key, UPD_PI_ACC, 0);
-        if (log(u) < acc)
-          for (int k = 0; k < K; ++k) pi[k] = pi_ph[k];
-        for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
-      }
-      if (mask & U_ALPHA3) {
-        const double sd = c.h.var_alpha3;
-        const double ph = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
-        double l_old = (-c.h.b) * alpha3, l_new = (-c.h.b) * ph;
-        for (int k = 0; k < K; ++k) {
-          l_old += ((alpha3 * pi[k]) - 1) * L.sm[k];
-          l_new += ((ph * pi[k]) - 1) * L.sm[k];
-        }
-        for (int k = 0; k < K; ++k) ap[k] = alpha3 * pi[k];
-        l_old -= n * calc_lB(K, ap);
-        for (int k = 0; k < K; ++k) ap[k] = ph * pi[k];
-        l_new -= n * calc_lB(K, ap);
-        // d_truncnorm(x, x, sd, 0, Inf, log) with x = the *other* state (UpdateAlpha3.h:23-24)
-        l_old += dtruncnorm_lo_log(ph, ph, sd, 0.0);
-        l_new += dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
-        const double u = runif(key, UPD_A3_ACC, 0);
-        if (log(u) < l_new - l_old) alpha3 = ph;
-        dyn->alpha3 = alpha3;
-      }
-    }
-    __syncthreads();
+  // standard gamma variate of the sigma^2 draw: its shape does not depend on the sweep
+  double sig_shape = 0.0, sig_g = 0.0;
+  if ((mask & U_SIGMA) && tid == SW_THREADS - 1) {
+    const bool tempered = (dyn->tt_step != 0);
+    sig_shape = tempered ? (beta * (double)d.n_obs_total) / 2
+                         : (d.mv ? (double)(d.n_obs_total / 2) : (double)d.half_sum);   // UpdateSigma.h:49 / :150
+    sig_shape += c.h.alpha_0;
+    sig_g = rgamma(key, UPD_SIGMA, 0, sig_shape, 1.0);
   }
+  for (int e = tid; e < A * PS; e += SW_THREADS) {
+    const int b = e / PS, pp = e - b * PS - BW;
+    th[e] = (pp >= 0 && pp < P) ? c.theta[(size_t)full_dir(d, b) * P + pp] : 0.0;
+  }
+  for (int e = tid; e < AP; e += SW_THREADS) { tv[e] = c.tvec[e]; r[e] = c.rvec[e]; hq[e] = c.hq[e]; lz[e] = c.Lz[e]; }
+  for (int e = tid; e < PMAX + 2 * BWMAX; e += SW_THREADS) dlp[e] = 0.0;
+  for (int e = tid; e < A * A; e += SW_THREADS) htab[e] = hrow(d, e / A, e % A);
+  __syncthreads();
 
-  const bool need_gauss = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
-  // ---------------- load theta (always: delta / gamma / tau read it) --------------------------
-  for (int e = tid; e < A * P; e += 256) {
-    const int a = e / P, p = e - a * P;
-    L.th[e] = c.theta[(size_t)full_dir(d, a) * P + p];
+  // per-thread prefetch map: element e of [ H column blocks | C ] of a step
+  int pf_b[NPF], pf_off[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int e = tid + SW_THREADS * k;
+    pf_b[k] = -2; pf_off[k] = 0;
+    if (e < A * LG) { pf_b[k] = e / LG; pf_off[k] = e - pf_b[k] * LG; }
+    else if (e < pf_len) { pf_b[k] = -1; pf_off[k] = e - A * LG; }
+  }
+  double preg[NPF];
+  auto pf_load = [&](int a) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      double v = 0.0;
+      if (pf_b[k] >= 0) v = c.H[(size_t)htab[pf_b[k] * A + a] * LG + pf_off[k]];
+      else if (pf_b[k] == -1) v = c.Cmat[(size_t)a * P * P + pf_off[k]];
+      preg[k] = v;
+    }
+  };
+  auto pf_store = [&](double* buf) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (pf_b[k] >= -1) buf[tid + SW_THREADS * k] = preg[k];
+  };
+  if (n_steps > 0) {
+    const int a0 = step_dir(d, 0, n_phi);
+    pf_load(a0);
+    pf_store(pbuf0);
+    if (tid < P) rhs[tid] = f * (r[a0 * P + tid] + hq[a0 * P + tid]);
   }
   __syncthreads();
-  if (need_gauss) {
-    // ---------------- t; r = t - H theta ------------------------------------------------------
-    for (int e = tid; e < A * P; e += 256) L.tv[e] = c.tvec[e];
-    __syncthreads();
-    for (int e = tid; e < A * P; e += 256) {
-      const int a = e / P, p = e - a * P;
-      double acc = L.tv[e];
-      for (int b = 0; b < A; ++b) acc -= band_mv(c.H + (size_t)hrow(d, a, b) * d.LG, L.th + b * P, P, d.BW, p);
-      L.r[e] = acc;
+
+  for (int st = 0; st < n_steps; ++st) {
+    const int a = step_dir(d, st, n_phi);
+    const bool more = st + 1 < n_steps;
+    const int an = more ? step_dir(d, st + 1, n_phi) : -1;
+    const double* buf = (st & 1) ? pbuf1 : pbuf0;
+    const double* Cg = buf + (size_t)A * LG;
+    if (more) pf_load(an);
+    // phase A: new = C rhs + L z
+    for (int p = tid >> 3; p < P; p += SW_THREADS / 8) {
+      const int seg = tid & 7;
+      double acc = 0.0;
+      for (int q = seg; q < P; q += 8) acc += Cg[p + P * q] * rhs[q];
+      acc += __shfl_xor(acc, 1, 8);
+      acc += __shfl_xor(acc, 2, 8);
+      acc += __shfl_xor(acc, 4, 8);
+      if (seg == 0) {
+        const double nw = acc + lz[a * P + p];
+        dlp[BW + p] = nw - th[a * PS + BW + p];
+        th[a * PS + BW + p] = nw;
+      }
     }
     __syncthreads();
-  }
-  const double f = beta / dyn->sigma2;
-
-  // ---------------- Phi (updatePhi: j outer, m inner) ----------------------------------------
-  if ((mask & U_PHI) && MD > 1) {
-    for (int j = 0; j < K; ++j)
-      for (int m = 0; m < M; ++m)
-        gauss_step(c, L, j * MD + m + 1, UPD_PHI, (uint32_t)((j * M + m) * P), key, f);
-    // publish Phi so that delta / gamma below read the new values
-    for (int e = tid; e < K * M * P; e += 256) {
-      const int jm = e / P, p = e - jm * P, j = jm / M, m = jm - j * M;
-      c.theta[(size_t)(j * (M + 1) + m + 1) * P + p] = L.th[(j * MD + m + 1) * P + p];
+    // phase B: r_b -= H_ba dl ; hq_a ; next rhs
+    for (int e = tid; e < AP; e += SW_THREADS) {
+      const int b = e / P, p = e - b * P;
+      const double* Hb = buf + (size_t)b * LG;
+      const double* dl = dlp + BW + p;
+      double v = Hb[p] * dl[0];
+      for (int dd = 1; dd <= BW; ++dd) v += Hb[dd * P + p] * dl[dd] + Hb[dd * P + p - dd] * dl[-dd];
+      const double rn = r[e] - v;
+      r[e] = rn;
+      if (b == a) hq[e] += v;                       // H_aa theta_a follows theta_a
+      if (b == an) rhs[p] = f * (rn + hq[e]);
     }
+    if (more) pf_store((st & 1) ? pbuf0 : pbuf1);
     __syncthreads();
   }
 
-  // ---------------- delta (updateDelta, UpdateDelta.h:17-64) ----------------------------------
-  if ((mask & U_DELTA) && MD > 1) {
-    // S_km = sum_p gamma(k,p,m) phi(k,p,m)^2
+  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
+  if (mask & U_SIGMA) {
+    // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
+    double acc = 0.0;
+    for (int e = tid; e < AP; e += SW_THREADS) {
+      const int b = e / P, p = e - b * P;
+      acc += th[b * PS + BW + p] * (tv[e] + r[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == SW_THREADS - 1) {
+      double q = 0.0;
+      for (int w = 0; w < SW_THREADS / 64; ++w) q += red[w];
+      const double rss = c.YY - q;
+      const bool tempered = (dyn->tt_step != 0);
+      const double b = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
+      const double s2 = 1.0 / (sig_g * (1.0 / b));
+      dyn->sigma2 = s2;
+      dyn->rss = rss;
+      c.c_sigma[slot] = s2;
+    }
+  } else if (tid == 0) {
+    c.c_sigma[slot] = dyn->sigma2;
+  }
+  // ---------------- publish theta and its chain slots -------------------------------------------
+  double* s_nu = c.c_nu + (size_t)slot * K * P;
+  double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
+  for (int e = tid; e < AP; e += SW_THREADS) {
+    const int b = e / P, p = e - b * P;
+    const int jj = b / MD, mt = b - jj * MD;
+    const double v = th[b * PS + BW + p];
+    c.theta[(size_t)(jj * (M + 1) + mt) * P + p] = v;
+    if (mt == 0) s_nu[jj + (size_t)K * p] = v;
+    else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = v;
+  }
+  if (MD == 1)
+    for (int e = tid; e < K * P * M; e += SW_THREADS) {
+      const int k = e % K, pm = e / K, p = pm % P, m = pm / P;
+      s_phi[e] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pi_alpha: pi (updatePi_PM, UpdatePi.h:84-116) and alpha_3 (updateAlpha3, UpdateAlpha3.h:36-63).
+// Needs S_k = sum_i log Z_ik (block partials of k_curve_z).  Off the critical path of the
+// iteration: only the next Z update reads pi and alpha_3.  The dozens of lgamma / log / gamma
+// evaluations are spread over lanes instead of being run by one thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pi_alpha(Ctx c) {
+  __shared__ double red[256];
+  __shared__ double S[KMAX], g[KMAX], lg[8 * KMAX + 8], pis[3 * KMAX + 2];
+  const Dims& d = c.d;
+  const int K = d.K, n = d.n, tid = threadIdx.x;
+  Dyn* dyn = c.dyn;
+  const uint32_t mask = c.mask;
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    const int per = (c.nblk_curve + 255) / 256;
+    for (int b = tid * per; b < min(c.nblk_curve, (tid + 1) * per); ++b) acc += c.logz_part[(size_t)b * K + k];
+    const double s = block_sum256(acc, red);
+    if (tid == 0) S[k] = s;
+  }
+  // proposals: lane k < K draws the pi gamma, lane K the alpha_3 truncated normal
+  double alpha3 = dyn->alpha3;
+  const double sd = c.h.var_alpha3;
+  if (tid < K) {
+    const double a_old = c.h.a_pi_PM * dyn->pi[tid];
+    g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
+  } else if (tid == K) {
+    pis[3 * KMAX] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
+  }
+  __syncthreads();
+  double pi_old[KMAX], pi_new[KMAX];
+  double gsum = 0.0;
+  for (int k = 0; k < K; ++k) gsum += g[k];
+  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
+  const double a3_ph = pis[3 * KMAX];
+  // lgamma table, one lane each.  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
+  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5
+  if (tid < 6 * K) {
+    const int row = tid / K, k = tid - row * K;
+    const double pk = (row & 1) ? pi_new[k] : pi_old[k];
+    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
+    lg[tid] = lgamma(sc * pk);
+  } else if (tid < 6 * K + 6) {
+    const int row = tid - 6 * K;
+    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += sc * ((row & 1) ? pi_new[k] : pi_old[k]);
+    lg[tid] = lgamma(acc);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto lB = [&](int row) {   // calc_lB of (scale_row * pi_row)
+      double s = 0.0;
+      for (int k = 0; k < K; ++k) s += lg[row * K + k];
+      return s - lg[6 * K + row];
+    };
+    double pi[KMAX];
+    for (int k = 0; k < K; ++k) pi[k] = pi_old[k];
+    int pi_is_new = 0;
+    if (mask & U_PI) {
+      double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double lo = log(pi_old[k]), ln = log(pi_new[k]);
+        lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
+        lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
+        pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
+        po += (c.h.a_pi_PM * pi_new[k] - 1) * lo;
+      }
+      lpdf_new -= n * lB(3);
+      lpdf_old -= n * lB(2);
+      const double lpn = pn - lB(0);
+      const double lpo = po - lB(1);
+      const double acc = lpdf_new - lpdf_old + lpo - lpn;
+      const double u = runif(key, UPD_PI_ACC, 0);
+      if (log(u) < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
+      for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
+    }
+    if (mask & U_ALPHA3) {
+      double l_old = (-c.h.b) * alpha3, l_new = (-c.h.b) * a3_ph;
+      for (int k = 0; k < K; ++k) {
+        l_old += ((alpha3 * pi[k]) - 1) * S[k];
+        l_new += ((a3_ph * pi[k]) - 1) * S[k];
+      }
+      l_old -= n * lB(2 + pi_is_new);
+      l_new -= n * lB(4 + pi_is_new);
+      // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
+      l_old += dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0);
+      l_new += dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
+      const double u = runif(key, UPD_A3_ACC, 0);
+      if (log(u) < l_new - l_old) alpha3 = a3_ph;
+      dyn->alpha3 = alpha3;
+    }
+    c.c_alpha3[dyn->slot] = dyn->alpha3;
+    for (int k = 0; k < K; ++k) c.c_pi[(size_t)dyn->slot * K + k] = dyn->pi[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hyper: delta (UpdateDelta.h:17-64), A (UpdateA.h:58-123), gamma (UpdateGamma.h:17-37) and
+// tau (UpdateTau.h:18-36; MV :47-63), in the reference's order.  Off the critical path: only the
+// next iteration's k_factor reads them.  Every gamma variate is scale * Gamma(shape, 1) with a
+// shape known up front, so all standard variates are drawn in parallel first and only the O(M)
+// scale recursions stay sequential.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
+
+__global__ __launch_bounds__(256) void k_hyper(Ctx c) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ double red[256];
+  const Dims& d = c.d;
+  const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
+  Dyn* dyn = c.dyn;
+  const uint32_t mask = c.mask, slot = dyn->slot;
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  double* gD = smem;                   // K*M   standard gammas for delta
+  double* Skm = gD + K * M;            // K*M   sum_p gamma phi^2
+  double* gT = Skm + K * M;            // K     standard gammas for tau
+  double* aw = gT + KMAX;              // K*2*6 work of the A update
+  const bool phi_on = MD > 1;
+  // ---- delta ----
+  if ((mask & U_DELTA) && phi_on) {
     if (tid < K * M) {
-      const int k = tid / M, m = tid - k * M;
+      const int k = tid / M, i = tid - k * M;
+      const double param1 = (i == 0) ? c.Aa[k] + ((P * M) / 2.0) : c.Aa[k + (size_t)K] + ((P * (M - i)) / 2.0);
+      gD[tid] = rgamma(key, UPD_DELTA, (uint32_t)(k * M + i), param1, 1.0);
+    } else if (tid >= 64 && tid < 64 + K * M) {
+      const int q = tid - 64, k = q / M, m = q - k * M;
       double acc = 0.0;
       for (int p = 0; p < P; ++p) {
-        const double ph = L.th[(k * MD + m + 1) * P + p];
+        const double ph = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
         acc += c.gamma[k + (size_t)K * (p + (size_t)P * m)] * (ph * ph);
       }
-      L.red[tid] = acc;
+      Skm[q] = acc;
     }
     __syncthreads();
     if (tid < K) {
       const int k = tid;
       for (int i = 0; i < M; ++i) {
-        double param1, param2 = 1.0;
+        double param2 = 1.0;
         if (i == 0) {
-          param1 = c.Aa[k] + ((P * M) / 2.0);
-          param2 += 0.5 * L.red[k * M + 0];
+          param2 += 0.5 * Skm[k * M + 0];
           for (int m = 1; m < M; ++m) {
             double tt = 1.0;
             for (int nn = 1; nn <= m; ++nn) tt *= c.delta[k + (size_t)K * nn];
-            param2 += 0.5 * tt * L.red[k * M + m];
+            param2 += 0.5 * tt * Skm[k * M + m];
           }
         } else {
-          param1 = c.Aa[k + (size_t)K] + ((P * (M - i)) / 2.0);
           for (int m = i; m < M; ++m) {
             double tt = 1.0;
             for (int nn = 0; nn <= m; ++nn)
               if (nn != i) tt *= c.delta[k + (size_t)K * nn];
-            param2 += 0.5 * tt * L.red[k * M + m];
+            param2 += 0.5 * tt * Skm[k * M + m];
           }
         }
-        c.delta[k + (size_t)K * i] = rgamma(key, UPD_DELTA, (uint32_t)(k * M + i), param1, 1.0 / param2);
+        c.delta[k + (size_t)K * i] = gD[k * M + i] * (1.0 / param2);
       }
     }
     __syncthreads();
   }
-
-  // ---------------- A (updateA, UpdateA.h:58-123) ---------------------------------------------
-  if ((mask & U_A) && MD > 1) {
-    if (tid < K * 2) {
+  // ---- A : six lanes per cell (j, i): proposal, then lpdf(cur), lpdf(new), the two proposal densities ----
+  if ((mask & U_A) && phi_on) {
+    const int ncell = K * 2;
+    if (tid < ncell) {
       const int j = tid / 2, i = tid - 2 * j;
+      const double sd = (i == 0) ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
+      aw[tid * 6 + 0] = rtruncnorm_lo(key, UPD_A_PROP, (uint32_t)(j * 2 + i), c.Aa[j + (size_t)K * i], sd, 0.0);
+    }
+    __syncthreads();
+    if (tid < ncell * 4) {
+      const int cell = tid >> 2, job = tid & 3;
+      const int j = cell / 2, i = cell - 2 * j;
       const bool first = (i == 0);
       const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
-      const double cur = c.Aa[j + (size_t)K * i];
-      const double na = rtruncnorm_lo(key, UPD_A_PROP, (uint32_t)(j * 2 + i), cur, sd, 0.0);
-      double l0, l1;
-      if (first) {
-        l0 = lpdf_a1(c.h, cur, c.delta[j]);
-        l1 = lpdf_a1(c.h, na, c.delta[j]);
-      } else {
-        l0 = lpdf_a2(c.h, cur, M, c.delta + j, K);
-        l1 = lpdf_a2(c.h, na, M, c.delta + j, K);
-      }
-      const double acc = (l1 + dtruncnorm_lo_log(cur, na, sd, 0.0)) - l0 - dtruncnorm_lo_log(na, cur, sd, 0.0);
+      const double cur = c.Aa[j + (size_t)K * i], na = aw[cell * 6 + 0];
+      double v;
+      if (job < 2) {
+        const double a = (job == 0) ? cur : na;
+        if (first) {
+          v = -logGamma_ref(a) + (a - 1) * log(c.delta[j]) + (c.h.alpha1l - 1) * log(a) - (a * c.h.beta1l);   // UpdateA.h:17-24
+        } else {
+          const double x = M - 1;                                                                             // UpdateA.h:33-44
+          v = -x * logGamma_ref(a) + (c.h.alpha2l - 1) * log(a) - (a * c.h.beta2l);
+          for (int q = 1; q < M; ++q) v = v + (a - 1) * log(c.delta[j + (size_t)K * q]);
+        }
+      } else if (job == 2) v = dtruncnorm_lo_log(cur, na, sd, 0.0);
+      else v = dtruncnorm_lo_log(na, cur, sd, 0.0);
+      aw[cell * 6 + 1 + job] = v;
+    }
+    __syncthreads();
+    if (tid < ncell) {
+      const int j = tid / 2, i = tid - 2 * j;
+      const double* w = aw + tid * 6;
+      const double acc = (w[2] + w[3]) - w[1] - w[4];
       const double u = runif(key, UPD_A_ACC, (uint32_t)(j * 2 + i));
-      if (log(u) < acc) c.Aa[j + (size_t)K * i] = na;
+      if (log(u) < acc) c.Aa[j + (size_t)K * i] = w[0];
     }
     __syncthreads();
   }
-
-  // ---------------- gamma (updateGamma, UpdateGamma.h:17-37) -----------------------------------
-  if ((mask & U_GAMMA) && MD > 1) {
+  // ---- gamma ----
+  if ((mask & U_GAMMA) && phi_on) {
     for (int e = tid; e < K * P * M; e += 256) {
       // e = (i*P + l)*M + j  (reference loop order i, l, j)
       const int jj = e % M, il = e / M, l = il % P, i = il / P;
       double ph = 1.0;
       for (int j2 = 0; j2 <= jj; ++j2) ph *= c.delta[i + (size_t)K * j2];
-      const double phi = L.th[(i * MD + jj + 1) * P + l];
+      const double phi = c.theta[(size_t)(i * (M + 1) + jj + 1) * P + l];
       c.gamma[i + (size_t)K * (l + (size_t)P * jj)] =
-          rgamma(key, UPD_GAMMA, (uint32_t)e, (c.h.nu_1 + 1) / 2, 2 / (c.h.nu_1 + ph * (phi * phi)));
+          rgamma(key, UPD_GAMMA, (uint32_t)e, (c.h.nu_1 + 1) / 2, 1.0) * (2 / (c.h.nu_1 + ph * (phi * phi)));
     }
-    __syncthreads();
   }
-
-  // ---------------- nu (updateNu) -------------------------------------------------------------
-  if (mask & U_NU) {
-    for (int j = 0; j < K; ++j) gauss_step(c, L, j * MD, UPD_NU, (uint32_t)(j * P), key, f);
-    for (int e = tid; e < K * P; e += 256) {
-      const int j = e / P, p = e - j * P;
-      c.theta[(size_t)(j * (M + 1)) * P + p] = L.th[(j * MD) * P + p];
-    }
-    __syncthreads();
-  }
-
-  // ---------------- tau (updateTau, UpdateTau.h:18-36; MV :47-63) ------------------------------
+  // ---- tau ----
   if (mask & U_TAU) {
+    if (tid < K) gT[tid] = rgamma(key, UPD_TAU, (uint32_t)tid, c.h.alpha_nu + (P / 2), 1.0);   // integer division, UpdateTau.h:29
     for (int k = 0; k < K; ++k) {
       double acc = 0.0;
       if (tid < P) {
-        const double* nu = L.th + (k * MD) * P;
+        const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
         const double vp = nu[tid];
         double s = 0.0;
         if (d.mv) s = vp;
@@ -530,67 +726,21 @@ __global__ __launch_bounds__(256) void k_sweep(Ctx c) {
           for (int q = 0; q < P; ++q) s += c.Pmat[tid + (size_t)P * q] * nu[q];
         acc = vp * s;
       }
-      const double qf = block_sum256(acc, L.red);
+      const double qf = block_sum256(acc, red);
       if (tid == 0) {
-        const double a = c.h.alpha_nu + (P / 2);                   // integer division, UpdateTau.h:29
         const double b = c.h.beta_nu + (0.5 * qf);
-        const double g = rgamma(key, UPD_TAU, (uint32_t)k, a, 1.0 / b);
-        dyn->tau[k] = d.mv ? (1.0 / g) : g;
+        const double gg = gT[k] * (1.0 / b);
+        dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
       }
     }
-    __syncthreads();
   }
-
-  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
-  if (mask & U_SIGMA) {
-    // RSS = YY - sum_a theta_a'(t_a + r_a)
-    double acc = 0.0;
-    for (int e = tid; e < A * P; e += 256) acc += L.th[e] * (L.tv[e] + L.r[e]);
-    const double q = block_sum256(acc, L.red);
-    if (tid == 0) {
-      const double rss = c.YY - q;
-      double a, b;
-      const bool tempered = (dyn->tt_step != 0);
-      if (tempered) {
-        a = (d.mv ? ((beta * (double)d.n_obs_total) / 2) : (beta * (double)d.n_obs_total) / 2);
-        b = (beta / 2) * rss;
-      } else {
-        a = d.mv ? (double)(d.n_obs_total / 2) : (double)d.half_sum;    // UpdateSigma.h:49 / :150
-        b = 0.5 * rss;
-      }
-      b += c.h.beta_0;
-      a += c.h.alpha_0;
-      dyn->sigma2 = 1.0 / rgamma(key, UPD_SIGMA, 0, a, 1.0 / b);
-      dyn->rss = rss;
-    }
-    __syncthreads();
-  }
-
-  // ---------------- chain slots ---------------------------------------------------------------
-  {
-    double* s_nu = c.c_nu + (size_t)slot * K * P;
-    double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
-    double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
-    for (int e = tid; e < K * P; e += 256) {
-      const int p = e / K, k = e - p * K;
-      s_nu[e] = c.theta[(size_t)(k * (M + 1)) * P + p];
-    }
-    for (int e = tid; e < K * P * M; e += 256) {
-      const int k = e % K, pm = e / K, p = pm % P, m = pm / P;
-      s_phi[e] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
-      s_gam[e] = c.gamma[e];
-    }
-    if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
-    if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
-    if (tid < K) {
-      c.c_pi[(size_t)slot * K + tid] = dyn->pi[tid];
-      c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
-    }
-    if (tid == 0) {
-      c.c_alpha3[slot] = dyn->alpha3;
-      c.c_sigma[slot] = dyn->sigma2;
-    }
-  }
+  __syncthreads();
+  // ---- chain slots ----
+  double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
+  for (int e = tid; e < K * P * M; e += 256) s_gam[e] = c.gamma[e];
+  if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
+  if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
+  if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,24 +778,49 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st) {
-  const size_t lds = (size_t)KS * (c.d.K + c.d.MD) * sizeof(double);
-  hipLaunchKernelGGL(k_pair_gram, dim3(NTG, NKS), dim3(256), lds, st, c, NTG, KS);
+  (void)NTG;
+  const int ncol = std::max(16, c.d.CTS * 16);
+  const size_t lds = (size_t)KS * (c.d.K + c.d.MD + ncol) * sizeof(double);
+  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 1, NKS), dim3(256), lds, st, c, KS);
   const int nthreads = c.d.NT * 256;
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, c, NKS);
 }
 
 void launch_factor(const Ctx& c, hipStream_t st) {
-  const size_t lds = ((size_t)c.d.P * c.d.P + 2 * c.d.P) * sizeof(double);
-  hipLaunchKernelGGL(k_factor, dim3(c.d.A), dim3(256), lds, st, c);
+  const int PP = (c.d.P <= 32) ? 32 : 64;
+  const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP) * sizeof(double);
+  if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(c.d.A), dim3(256), lds, st, c);
+  else hipLaunchKernelGGL(k_factor<64>, dim3(c.d.A), dim3(256), lds, st, c);
 }
 
-void launch_sweep(const Ctx& c, hipStream_t st) {
-  const size_t lds = ((size_t)3 * c.d.A * c.d.P + 4 * PMAX + 256 + 64) * sizeof(double);
-  hipLaunchKernelGGL(k_sweep, dim3(1), dim3(256), lds, st, c);
+int launch_sweep(const Ctx& c, hipStream_t st) {
+  const Dims& d = c.d;
+  const size_t pf_len = (size_t)d.A * d.LG + (size_t)d.P * d.P;
+  if (pf_len > (size_t)NPF * SW_THREADS) return 1;
+  const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf_len;
+  const size_t lds = doubles * sizeof(double) + (size_t)d.A * d.A * sizeof(int) + 16;
+  if (lds > 160 * 1024) return 1;
+  hipLaunchKernelGGL(k_sweep, dim3(1), dim3(SW_THREADS), lds, st, c);
+  return 0;
+}
+
+void launch_pi_alpha(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_pi_alpha, dim3(1), dim3(256), 0, st, c); }
+
+void launch_hyper(const Ctx& c, hipStream_t st) {
+  const size_t lds = ((size_t)2 * c.d.K * c.d.M + KMAX + (size_t)c.d.K * 2 * 6 + 8) * sizeof(double);
+  hipLaunchKernelGGL(k_hyper, dim3(1), dim3(256), lds, st, c);
 }
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
   hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, st, c, use_rss_part, r_stored);
+}
+
+void prepare_sweep_kernels() {
+  set_max_lds((const void*)k_sweep);
+  set_max_lds((const void*)k_pair_gram);
+  set_max_lds((const void*)k_factor<32>);
+  set_max_lds((const void*)k_factor<64>);
+  set_max_lds((const void*)k_hyper);
 }
 
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {

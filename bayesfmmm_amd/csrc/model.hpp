@@ -49,11 +49,13 @@ struct Dyn {
   double loglik;
   double pi[KMAX];
   double tau[KMAX];
+  unsigned long long stamps[16];   // diagnostic phase stamps of k_sweep (100 MHz wall clock)
 };
 
 struct Dims {
   int n, K, P, M, D;
   int BW;               // band half-width of G_i (= spline degree; 0 for the multivariate model)
+  int BWP;              // band half-width of the conditional precisions (max of BW and the penalty's)
   int LG;               // (BW+1)*P
   int LREC;             // record length in doubles (LG + P + 1, padded to even)
   int MD;               // active mt values: M+1, or 1 when Phi = chi = 0 (Nu_Z stage)
@@ -93,6 +95,9 @@ struct Ctx {
   double* pg_part;              // NWG x NT x 256   pair-Gram partial tiles
   double* H;                    // R x LG           pair-weighted Gram blocks (band-packed)
   double* tvec;                 // A x P            sum_i w_ai s_i
+  double* rvec;                 // A x P            r_a = t_a - sum_b H_ab theta_b at the start of the sweep
+  double* hq;                   // A x P            H_aa theta_a
+  double* Lz;                   // A x P            chol_lower(C_a) z_a, z_a the direction's N(0,I) draw
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty
@@ -104,6 +109,14 @@ struct Ctx {
 
 __host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
   return a * n - (a * (a - 1)) / 2 + (b - a);
+}
+
+// allow a kernel to use all of the CU's 160 KiB of LDS for its dynamic region
+inline void set_max_lds(const void* fn) {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, fn) != hipSuccess) { (void)hipGetLastError(); return; }
+  const int room = 160 * 1024 - (int)at.sharedSizeBytes;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) (void)hipGetLastError();
 }
 
 }  // namespace bfmmm

@@ -78,7 +78,7 @@ class Sampler:
         n, K, P, M = self.n, self.K, self.P, self.M
         return {"nu": (K, P), "Phi": (K, P, M), "chi": (n, M), "Z": (n, K), "pi": (K,), "alpha_3": (1,),
                 "delta": (K, M), "A": (K, 2), "gamma": (K, P, M), "tau": (K,), "sigma_sq": (1,),
-                "loglik": (1,), "status": (1,)}[name]
+                "loglik": (1,), "status": (1,), "stamps": (16,)}[name]
 
     def set_state(self, **kw):
         for name, v in kw.items():
