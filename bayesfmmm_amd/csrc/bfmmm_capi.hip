@@ -54,7 +54,7 @@ struct bfmmm_handle {
   bfmmm_config cfg;
   int device = 0;
   hipStream_t st = nullptr, st2 = nullptr;
-  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr, evD = nullptr;
   Ctx c;                       // template context (full MD)
   int T = 0;
   int64_t n_obs = 0;
@@ -166,6 +166,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   HIPCHK(hipEventCreate(&h->evA));
   HIPCHK(hipEventCreate(&h->evB));
   HIPCHK(hipEventCreate(&h->evC));
+  HIPCHK(hipEventCreate(&h->evD));
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
   Ctx& c = h->c;
@@ -280,6 +281,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (h->evA) (void)hipEventDestroy(h->evA);
   if (h->evB) (void)hipEventDestroy(h->evB);
   if (h->evC) (void)hipEventDestroy(h->evC);
+  if (h->evD) (void)hipEventDestroy(h->evD);
   if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->st) (void)hipStreamDestroy(h->st);
   delete h;
@@ -466,37 +468,49 @@ static Plan make_plan(uint32_t mask, int MD) {
   return p;
 }
 
-// One Gibbs iteration.  Critical chain on `st`:  Z -> pair-Gram -> factor -> sweep -> chi -> loglik.
-// pi/alpha_3 (needed by the next Z update) and delta/A/gamma/tau (needed by the next factor) run on
-// the side stream `st2`, forked and joined with events; under stream capture this becomes a graph
-// with two parallel branches.
-static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NTG, int NKS, int KS, hipStream_t st,
-                             std::vector<hipEvent_t>* evs) {
+// One Gibbs iteration is  HEAD = [Z, (pi/alpha_3), pair-Gram]  followed by
+// BODY = [factor, sweep, (delta/A/gamma/tau), chi, loglik].  pi/alpha_3 (needed by the next Z update)
+// and delta/A/gamma/tau (needed by the next factor) run on the side stream `st2`, forked and joined
+// with events.  The replayed graph is the ROTATED loop  BODY(t) + HEAD(t+1): the slow scalar
+// kernel of iteration t then overlaps chi(t), Z(t+1) and the pair-Gram of t+1 instead of
+// stalling the end of iteration t.
+static void launch_head(bfmmm_handle* h, const Ctx& c, const Plan& p, int NTG, int NKS, int KS, hipStream_t st,
+                        std::vector<hipEvent_t>* evs) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
-  hipStream_t st2 = h->st2;
   mark();
   if (p.z) launch_curve(c, 0, p.z_update, st);
   mark();
   (void)hipEventRecord(h->evA, st);
-  (void)hipStreamWaitEvent(st2, h->evA, 0);
-  launch_pi_alpha(c, st2);
+  (void)hipStreamWaitEvent(h->st2, h->evA, 0);
+  launch_pi_alpha(c, h->st2);
+  (void)hipEventRecord(h->evD, h->st2);
   if (p.pg) launch_pair_gram(c, NTG, NKS, KS, st);
   mark();
+}
+
+static void launch_body(bfmmm_handle* h, const Ctx& c, const Plan& p, hipStream_t st, std::vector<hipEvent_t>* evs) {
+  auto mark = [&]() {
+    if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
+  };
   if (p.factor) launch_factor(c, st);
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
   (void)hipEventRecord(h->evB, st);
-  (void)hipStreamWaitEvent(st2, h->evB, 0);
-  launch_hyper(c, st2);
-  (void)hipEventRecord(h->evC, st2);
+  (void)hipStreamWaitEvent(h->st2, h->evB, 0);
+  launch_hyper(c, h->st2);
+  (void)hipEventRecord(h->evC, h->st2);
   if (p.chi) launch_curve(c, 1, p.chi_update, st);
   mark();
-  (void)hipStreamWaitEvent(st, h->evC, 0);
   launch_loglik(c, p.use_rss_part, 0, st);
   mark();
+}
+
+static void join_side(bfmmm_handle* h, hipStream_t st) {
+  (void)hipStreamWaitEvent(st, h->evC, 0);
+  (void)hipStreamWaitEvent(st, h->evD, 0);
 }
 
 extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
@@ -522,7 +536,9 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   if (h->profile) {
     for (int it = 0; it < n_iters; ++it) {
       std::vector<hipEvent_t> evs;
-      launch_iteration(h, c, plan, NTG, NKS, KS, h->st, &evs);
+      launch_head(h, c, plan, NTG, NKS, KS, h->st, &evs);     // events 0,1,2
+      launch_body(h, c, plan, h->st, &evs);                   // events 3,4,5,6
+      join_side(h, h->st);
       HIPCHK(hipStreamSynchronize(h->st));
       const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
       const bool ran[6] = {plan.z, plan.pg, plan.factor, true, plan.chi, true};
@@ -534,18 +550,26 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
       for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
   } else if (n_iters > 0) {
-    const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
-    if (!reuse) {
-      if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-      hipGraph_t graph = nullptr;
-      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
-      launch_iteration(h, c, plan, NTG, NKS, KS, h->st, nullptr);
-      HIPCHK(hipStreamEndCapture(h->st, &graph));
-      HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
+    launch_head(h, c, plan, NTG, NKS, KS, h->st, nullptr);
+    join_side(h, h->st);          // (evC may be unrecorded on the first call: a no-op wait)
+    if (n_iters > 1) {
+      const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
+      if (!reuse) {
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+        launch_body(h, c, plan, h->st, nullptr);
+        launch_head(h, c, plan, NTG, NKS, KS, h->st, nullptr);
+        join_side(h, h->st);
+        HIPCHK(hipStreamEndCapture(h->st, &graph));
+        HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
+      }
+      for (int it = 0; it + 1 < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
     }
-    for (int it = 0; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+    launch_body(h, c, plan, h->st, nullptr);
+    join_side(h, h->st);
   }
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);

@@ -27,15 +27,24 @@ struct Curve {
   double g[BW + 1];    // g[d]  = G[p][p+d]
   double gl[BW + 1];   // gl[d] = G[p-d][p]
   double s, yy;
+  // unconditional loads (clamped indices) so that the 2*BW+3 loads are issued back to back
   __device__ inline void load(const double* __restrict__ rec, int P, int LG, int p) {
     const bool act = p < P;
+    const int pc = min(p, P - 1);
+    double vg[BW + 1], vl[BW + 1];
 #pragma unroll
     for (int d = 0; d <= BW; ++d) {
-      g[d] = (act && p + d < P) ? rec[d * P + p] : 0.0;
-      gl[d] = (act && d > 0 && p - d >= 0) ? rec[d * P + p - d] : 0.0;
+      vg[d] = rec[d * P + pc];                       // zero-padded where pc + d >= P
+      vl[d] = rec[d * P + max(pc - d, 0)];
     }
-    s = act ? rec[LG + p] : 0.0;
+    const double vs = rec[LG + pc];
     yy = rec[LG + P];
+#pragma unroll
+    for (int d = 0; d <= BW; ++d) {
+      g[d] = act ? vg[d] : 0.0;
+      gl[d] = (act && d > 0 && p - d >= 0) ? vl[d] : 0.0;
+    }
+    s = act ? vs : 0.0;
   }
   // (G u)[p] with u staged in an LDS row padded by BW zeros on both sides (row points at element 0)
   __device__ inline double matvec(const double* row, int p) const {
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
   T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};
   double* sChi = gbase + (2 * K + 1) * T::STR;
   double* sRes = sChi + MMAX;
-  for (int q = threadIdx.x; q < nth; q += 256) sTh[q] = c.theta[q];
+  copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
   double* sChi = gbase + (2 * M + 3) * T::STR;
   double* sZn = sChi + MMAX;
   double* sRes = sZn + MMAX;
-  for (int q = threadIdx.x; q < nth; q += 256) sTh[q] = c.theta[q];
+  copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;

@@ -27,6 +27,11 @@ namespace bfmmm {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (vmcnt(0)), which would serialise the global prefetches the sweep keeps in flight
+// across its barriers.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------
 // pair-Gram
 // ---------------------------------------------------------------------------------------------
@@ -49,17 +54,53 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS) {
   double* sZ = smem;                         // KS x K
   double* sC = sZ + (size_t)KS * K;          // KS x MD   (chit: 1, chi_1..chi_M)
   double* sB = sC + (size_t)KS * MD;         // KS x ncol
-  for (int q = threadIdx.x; q < KS * K; q += 256) {
-    const int il = q / K, k = q - il * K, i = i0 + il;
-    sZ[q] = (i < n) ? c.Z[i + (size_t)n * k] : 0.0;
-  }
-  for (int q = threadIdx.x; q < KS * MD; q += 256) {
-    const int il = q / MD, mt = q - il * MD, i = i0 + il;
-    sC[q] = (i < n) ? ((mt == 0) ? 1.0 : c.chi[i + (size_t)n * (mt - 1)]) : 0.0;
-  }
-  for (int q = threadIdx.x; q < KS * ncol; q += 256) {
-    const int il = q / ncol, cc = q - il * ncol, i = i0 + il, col = col0 + cc;
-    sB[q] = (i < n && col < colend) ? c.rec[(size_t)i * d.LREC + col] : 0.0;
+  // staging with batched loads: all of a thread's global loads are issued before its first LDS store
+  {
+    constexpr int UN = 4;
+    const int tid = threadIdx.x;
+    const int nZ = KS * K, nC = KS * MD, nB = KS * ncol;
+    for (int base = 0; base < nZ; base += 256 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = min(base + tid + 256 * u, nZ - 1);
+        const int k = q / KS, il = q - k * KS, i = min(i0 + il, n - 1);       // k-major: coalesced over curves
+        v[u] = c.Z[i + (size_t)n * k];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = base + tid + 256 * u;
+        if (q < nZ) { const int k = q / KS, il = q - k * KS; sZ[il * K + k] = (i0 + il < n) ? v[u] : 0.0; }
+      }
+    }
+    for (int base = 0; base < nC; base += 256 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = min(base + tid + 256 * u, nC - 1);
+        const int mt = q / KS, il = q - mt * KS, i = min(i0 + il, n - 1);
+        v[u] = c.chi[i + (size_t)n * max(mt - 1, 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = base + tid + 256 * u;
+        if (q < nC) { const int mt = q / KS, il = q - mt * KS; sC[il * MD + mt] = (i0 + il < n) ? ((mt == 0) ? 1.0 : v[u]) : 0.0; }
+      }
+    }
+    for (int base = 0; base < nB; base += 256 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = min(base + tid + 256 * u, nB - 1);
+        const int il = q / ncol, cc = q - il * ncol, i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
+        v[u] = c.rec[(size_t)i * d.LREC + col];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = base + tid + 256 * u;
+        if (q < nB) { const int il = q / ncol, cc = q - il * ncol; sB[q] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0; }
+      }
+    }
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -211,14 +252,38 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   double* th = X + PP * PP;         // A x P
   double* part = th + A * P;        // A x P
   double* zv = part + A * P;        // PP
-  for (int e = tid; e < A * P; e += 256) {
-    const int b = e / P, p = e - b * P;
-    th[e] = c.theta[(size_t)full_dir(d, b) * P + p];
+  double* hstage = zv + PP;         // A x LG : row blocks H_{a,.}
+  {
+    // theta of the active directions and the row blocks H_{a,b}, b = 0..A-1 (staged in X, free until later)
+    constexpr int UN = 4;
+    for (int base = 0; base < A * P; base += 256 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = min(base + tid + 256 * u, A * P - 1);
+        const int b = e / P, p = e - b * P;
+        v[u] = c.theta[(size_t)full_dir(d, b) * P + p];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int e = base + tid + 256 * u; if (e < A * P) th[e] = v[u]; }
+    }
+    double* Hrow = hstage;
+    for (int base = 0; base < A * d.LG; base += 256 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = min(base + tid + 256 * u, A * d.LG - 1);
+        const int b = e / d.LG, off = e - b * d.LG;
+        v[u] = c.H[(size_t)hrow(d, a, b) * d.LG + off];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int e = base + tid + 256 * u; if (e < A * d.LG) Hrow[e] = v[u]; }
+    }
   }
   __syncthreads();
   for (int e = tid; e < A * P; e += 256) {
     const int b = e / P, p = e - b * P;
-    part[e] = band_mv(c.H + (size_t)hrow(d, a, b) * d.LG, th + b * P, P, d.BW, p);
+    part[e] = band_mv(hstage + (size_t)b * d.LG, th + b * P, P, d.BW, p);
   }
   __syncthreads();
   if (tid < P) {
@@ -232,7 +297,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   if (!upd_nu && !upd_phi) return;
   const Dyn* dyn = c.dyn;
   const double f = dyn->beta / dyn->sigma2;
-  const double* Hb = c.H + (size_t)hrow(d, a, a) * d.LG;
+  const double* Hb = hstage + (size_t)a * d.LG;
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
   if (mt > 0)
@@ -364,10 +429,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   const uint32_t mask = c.mask;
   const double beta = dyn->beta;
   const double f = beta / dyn->sigma2;
+  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
   const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
   const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
   const int n_nu = (mask & U_NU) ? K : 0;
   const int n_steps = n_phi + n_nu;
+#define STAMP(i) do { if (tid == 0) dyn->stamps[i] = wall_clock64(); } while (0)
+  STAMP(0);
 
   // standard gamma variate of the sigma^2 draw: its shape does not depend on the sweep
   double sig_shape = 0.0, sig_g = 0.0;
@@ -387,6 +455,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   for (int e = tid; e < A * A; e += SW_THREADS) htab[e] = hrow(d, e / A, e % A);
   __syncthreads();
 
+  STAMP(1);
   // per-thread prefetch map: element e of [ H column blocks | C ] of a step
   int pf_b[NPF], pf_off[NPF];
 #pragma unroll
@@ -397,13 +466,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     else if (e < pf_len) { pf_b[k] = -1; pf_off[k] = e - A * LG; }
   }
   double preg[NPF];
+  // branch-free: every lane always loads from a valid address (dummy lanes re-read H[0]) so that the
+  // NPF loads of a step are issued back to back instead of one memory latency apart
   auto pf_load = [&](int a) {
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
-      double v = 0.0;
-      if (pf_b[k] >= 0) v = c.H[(size_t)htab[pf_b[k] * A + a] * LG + pf_off[k]];
-      else if (pf_b[k] == -1) v = c.Cmat[(size_t)a * P * P + pf_off[k]];
-      preg[k] = v;
+      const int hb = max(pf_b[k], 0);
+      const size_t offH = (size_t)htab[hb * A + a] * LG + pf_off[k];
+      const size_t offC = (size_t)a * P * P + pf_off[k];
+      const double* src = (pf_b[k] == -1) ? (c.Cmat + offC) : (c.H + ((pf_b[k] >= 0) ? offH : 0));
+      preg[k] = *src;
     }
   };
   auto pf_store = [&](double* buf) {
@@ -419,7 +491,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   }
   __syncthreads();
 
+  STAMP(2);
   for (int st = 0; st < n_steps; ++st) {
+    if (st == 1) STAMP(3);
+    if (st == 2) STAMP(6);
     const int a = step_dir(d, st, n_phi);
     const bool more = st + 1 < n_steps;
     const int an = more ? step_dir(d, st + 1, n_phi) : -1;
@@ -440,7 +515,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
         th[a * PS + BW + p] = nw;
       }
     }
-    __syncthreads();
+    if (st == 1) STAMP(4);
+    lds_barrier();
+    if (st == 1) STAMP(5);
     // phase B: r_b -= H_ba dl ; hq_a ; next rhs
     for (int e = tid; e < AP; e += SW_THREADS) {
       const int b = e / P, p = e - b * P;
@@ -454,9 +531,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
       if (b == an) rhs[p] = f * (rn + hq[e]);
     }
     if (more) pf_store((st & 1) ? pbuf0 : pbuf1);
-    __syncthreads();
+    lds_barrier();
   }
 
+  STAMP(7);
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
   if (mask & U_SIGMA) {
     // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
@@ -483,6 +561,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   } else if (tid == 0) {
     c.c_sigma[slot] = dyn->sigma2;
   }
+  STAMP(8);
   // ---------------- publish theta and its chain slots -------------------------------------------
   double* s_nu = c.c_nu + (size_t)slot * K * P;
   double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
@@ -499,6 +578,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
       const int k = e % K, pm = e / K, p = pm % P, m = pm / P;
       s_phi[e] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
     }
+  STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -614,8 +694,8 @@ __global__ __launch_bounds__(256) void k_hyper(Ctx c) {
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
-  const uint32_t mask = c.mask, slot = dyn->slot;
-  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  const uint32_t mask = c.mask, slot = dyn->slot_hyper;
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step);
   double* gD = smem;                   // K*M   standard gammas for delta
   double* Skm = gD + K * M;            // K*M   sum_p gamma phi^2
   double* gT = Skm + K * M;            // K     standard gammas for tau
@@ -788,7 +868,7 @@ void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st) {
 
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
-  const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP) * sizeof(double);
+  const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP + (size_t)c.d.A * c.d.LG) * sizeof(double);
   if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(c.d.A), dim3(256), lds, st, c);
   else hipLaunchKernelGGL(k_factor<64>, dim3(c.d.A), dim3(256), lds, st, c);
 }

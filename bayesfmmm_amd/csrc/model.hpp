@@ -42,6 +42,8 @@ struct Dyn {
   uint32_t slot;        // chain slot that sweep writes (iter % r_stored_iters)
   uint32_t tt_step;     // tempered-transition sub-step (0 outside)
   uint32_t status;      // sticky error bits (1: precision matrix not positive definite)
+  uint32_t iter_hyper;  // snapshot of iter / slot taken by k_sweep for the off-critical-path k_hyper,
+  uint32_t slot_hyper;  //   which may still be running when k_loglik advances the counters
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
   double alpha3;
@@ -109,6 +111,22 @@ struct Ctx {
 
 __host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
   return a * n - (a * (a - 1)) / 2 + (b - a);
+}
+
+// Batched global -> LDS copy: every thread issues UN independent loads before the first store, so
+// the copy costs one memory latency per UN*nthreads elements instead of one per nthreads.
+template <int UN>
+__device__ inline void copy_to_lds(double* dst, const double* __restrict__ src, int count, int tid, int nthreads) {
+  for (int base = 0; base < count; base += nthreads * UN) {
+    double v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = src[min(base + tid + nthreads * u, count - 1)];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = base + tid + nthreads * u;
+      if (idx < count) dst[idx] = v[u];
+    }
+  }
 }
 
 // allow a kernel to use all of the CU's 160 KiB of LDS for its dynamic region
