@@ -1,0 +1,193 @@
+"""The reference's R entry points for the functional model, over the C ABI of include/bfmmm_entry.h.
+
+Function names, argument names, defaults and returned names follow
+`BFMMM_Nu_Z_multiple_try`, `BFMMM_Theta_est` and `BFMMM_warm_start` of src/UserFunctions.cpp
+(:166, :684, :1341; R wrappers R/RcppExports.R:1604, 1791, 2018).  Results are dicts of numpy arrays in
+the reference's shapes (Fortran order); lists of per-curve vectors stay Python lists.
+
+Extra keyword arguments that the reference does not have: `seed` (the reference uses R's global
+RNG), `device`, `max_concurrent` (multi-try chains run concurrently on one GPU) and, for the
+multi-GPU multi-try, `group` (a torch.distributed process group: chains are dealt round-robin to
+the ranks, scores are all-gathered and the winning chain is broadcast; see parallel.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+c_double_p = _lib.c_double_p
+c_int64_p = _lib.c_int64_p
+
+
+class EntryArgs(C.Structure):
+    """Mirror of `bfmmm_entry_args` (include/bfmmm_entry.h)."""
+    _fields_ = [("n_funct", C.c_int32), ("y", c_double_p), ("t", c_double_p), ("offsets", c_int64_p),
+                ("tot_mcmc_iters", C.c_int32), ("n_try", C.c_int32), ("K", C.c_int32), ("basis_degree", C.c_int32),
+                ("n_eigen", C.c_int32), ("n_internal_knots", C.c_int32), ("boundary_knots", c_double_p),
+                ("internal_knots", c_double_p), ("c", c_double_p), ("burnin_prop", C.c_double),
+                ("b", C.c_double), ("nu_1", C.c_double), ("alpha1l", C.c_double), ("alpha2l", C.c_double),
+                ("beta1l", C.c_double), ("beta2l", C.c_double), ("a_Z_PM", C.c_double), ("a_pi_PM", C.c_double),
+                ("var_alpha3", C.c_double), ("var_epsilon1", C.c_double), ("var_epsilon2", C.c_double),
+                ("alpha_nu", C.c_double), ("beta_nu", C.c_double), ("alpha_eta", C.c_double), ("beta_eta", C.c_double),
+                ("alpha_0", C.c_double), ("beta_0", C.c_double), ("thinning_num", C.c_double), ("beta_N_t", C.c_double),
+                ("N_t", C.c_int32), ("n_temp_trans", C.c_int32), ("r_stored_iters", C.c_int32),
+                ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
+                ("max_concurrent", C.c_int32)]
+
+
+ENTRY_SYMBOLS = {
+    "bfmmm_result_create": (C.c_void_p, []),
+    "bfmmm_result_free": (None, [C.c_void_p]),
+    "bfmmm_result_set": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int64, c_int64_p, C.c_int]),
+    "bfmmm_result_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(c_double_p), c_int64_p, C.POINTER(c_int64_p),
+                                   C.POINTER(C.c_int)]),
+    "bfmmm_result_count": (C.c_int, [C.c_void_p]),
+    "bfmmm_result_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "bfmmm_entry_defaults": (None, [C.POINTER(EntryArgs), C.c_int]),
+    "bfmmm_BFMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_BFMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_BFMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_entry_last_error": (C.c_char_p, []),
+}
+
+_bound = False
+
+
+def _lib_entry():
+    global _bound
+    lib = _lib.load()
+    if not _bound:
+        for name, (res, args) in ENTRY_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bound = True
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise _lib.BfmmmError(_lib_entry().bfmmm_entry_last_error().decode())
+
+
+def _result_to_dict(lib, res, offsets, P):
+    out = {}
+    for i in range(lib.bfmmm_result_count(res)):
+        name = lib.bfmmm_result_name(res, i)
+        data, cnt, dims, nd = c_double_p(), C.c_int64(), c_int64_p(), C.c_int()
+        _check(lib.bfmmm_result_get(res, name, C.byref(data), C.byref(cnt), C.byref(dims), C.byref(nd)))
+        shape = tuple(dims[k] for k in range(nd.value))
+        arr = np.ctypeslib.as_array(data, shape=(cnt.value,)).copy()
+        key = name.decode()
+        if key in ("B", "B_obs"):
+            rows = arr.reshape(-1, P)
+            out[key] = [rows[offsets[j]:offsets[j + 1]].copy() for j in range(len(offsets) - 1)]
+        elif key in ("best_chain", "best_score"):
+            out[key] = float(arr[0])
+        else:
+            out[key] = arr.reshape(shape, order="F")
+    return out
+
+
+def _dict_to_result(lib, d):
+    res = C.c_void_p(lib.bfmmm_result_create())
+    for key, val in d.items():
+        if key in ("B", "B_obs", "best_chain", "best_score"):
+            continue
+        a = np.asfortranarray(np.asarray(val, dtype=np.float64))
+        flat = np.ascontiguousarray(a.reshape(-1, order="F"))
+        dims = (C.c_int64 * a.ndim)(*a.shape)
+        _check(lib.bfmmm_result_set(res, key.encode(), flat.ctypes.data_as(c_double_p), flat.size, dims, a.ndim))
+    return res
+
+
+class _Args:
+    """Owns the numpy buffers behind a bfmmm_entry_args."""
+
+    def __init__(self, entry, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
+                 internal_knots, X, kw):
+        if X is not None:
+            raise NotImplementedError("covariate-adjusted models (X) are not implemented in this round")
+        if len(Y) != n_funct or len(time) != n_funct:
+            raise ValueError("'Y' and 'time' must have 'n_funct' elements")
+        lib = _lib_entry()
+        self.a = EntryArgs()
+        lib.bfmmm_entry_defaults(C.byref(self.a), entry)
+        self.offsets = np.zeros(n_funct + 1, dtype=np.int64)
+        self.offsets[1:] = np.cumsum([len(v) for v in Y])
+        self.y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))
+        self.t = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in time]))
+        self.bk = np.ascontiguousarray(boundary_knots, dtype=np.float64)
+        self.ik = np.ascontiguousarray(internal_knots, dtype=np.float64)
+        a = self.a
+        a.n_funct, a.tot_mcmc_iters, a.K, a.basis_degree, a.n_eigen = n_funct, tot_mcmc_iters, K, basis_degree, n_eigen
+        a.n_internal_knots = len(self.ik)
+        a.y, a.t = self.y.ctypes.data_as(c_double_p), self.t.ctypes.data_as(c_double_p)
+        a.offsets = self.offsets.ctypes.data_as(c_int64_p)
+        a.boundary_knots, a.internal_knots = self.bk.ctypes.data_as(c_double_p), self.ik.ctypes.data_as(c_double_p)
+        self.P = len(self.ik) + basis_degree + 1
+        c = kw.pop("c", None)
+        if c is not None:
+            self.c = np.ascontiguousarray(c, dtype=np.float64)
+            if self.c.size != K:
+                raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
+            a.c = self.c.ctypes.data_as(c_double_p)
+        for k, v in kw.items():
+            if not hasattr(a, k):
+                raise TypeError(f"unexpected argument '{k}'")
+            setattr(a, k, v)
+
+
+def BFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
+                            internal_knots, X=None, group=None, **kw):
+    """src/UserFunctions.cpp:166.  Runs 1 + n_try independent chains of the (Z, pi, alpha_3, nu, tau, sigma^2)
+    sweep and returns the chain with the largest mean log-likelihood over its last 99 draws."""
+    lib = _lib_entry()
+    args = _Args(0, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
+    args.a.n_try = n_try
+    if group is not None:
+        from . import parallel
+        return parallel.multi_try(lambda: _call1(lib.bfmmm_BFMMM_Nu_Z_multiple_try, args), args, group)
+    return _call1(lib.bfmmm_BFMMM_Nu_Z_multiple_try, args)
+
+
+def _call1(fn, args, *prev):
+    lib = _lib_entry()
+    res = C.c_void_p()
+    handles = [_dict_to_result(lib, p) for p in prev]
+    try:
+        _check(fn(C.byref(args.a), *handles, C.byref(res)))
+        return _result_to_dict(lib, res, args.offsets, args.P)
+    finally:
+        for h in handles:
+            lib.bfmmm_result_free(h)
+        if res:
+            lib.bfmmm_result_free(res)
+
+
+def BFMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
+                    multiple_try, X=None, burnin_prop=0.8, group=None, **kw):
+    """src/UserFunctions.cpp:684.  Conditions on the posterior medians of Z and nu from stage 1 and samples
+    (Phi, delta, A, gamma, tau, sigma^2, chi); best of 1 + n_try chains."""
+    lib = _lib_entry()
+    args = _Args(1, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
+    args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
+    mt = {k: multiple_try[k] for k in ("Z", "nu")}
+    if group is not None:
+        from . import parallel
+        return parallel.multi_try(lambda: _call1(lib.bfmmm_BFMMM_Theta_est, args, mt), args, group)
+    return _call1(lib.bfmmm_BFMMM_Theta_est, args, mt)
+
+
+def BFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
+                     multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
+    """src/UserFunctions.cpp:1341.  Full sampler started at the posterior medians of stages 1 and 2."""
+    if dir is not None:
+        raise NotImplementedError("on-disk chain batches ('dir') are not implemented in this round")
+    lib = _lib_entry()
+    args = _Args(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
+    args.a.burnin_prop = burnin_prop
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
+    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
+    return _call1(lib.bfmmm_BFMMM_warm_start, args, mt, te)

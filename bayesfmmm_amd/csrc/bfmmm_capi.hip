@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,7 @@ void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int
 using namespace bfmmm;
 
 static thread_local std::string g_err;
+static std::mutex g_capture_mutex;   // one stream capture at a time (samplers may run on several host threads)
 static int fail(const std::string& msg) { g_err = msg; return 1; }
 
 #define HIPCHK(x)                                                                                   \
@@ -73,12 +75,20 @@ struct bfmmm_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+// Synchronous copy on the sampler's own stream: the legacy (NULL) stream must not be touched while
+// another host thread is capturing a graph.
+static hipError_t copy_sync(bfmmm_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(h->st);
+}
+
 template <typename T>
 static int dalloc(bfmmm_handle* h, T** p, size_t count) {
   void* q = nullptr;
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
   HIPCHK(hipMalloc(&q, bytes));
-  HIPCHK(hipMemset(q, 0, bytes));
+  HIPCHK(hipMemsetAsync(q, 0, bytes, h->st));
   h->allocs.push_back(q);
   *p = (T*)q;
   return 0;
@@ -216,7 +226,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
       if (j > 0) { Pm[j + (size_t)P * j] = 2; Pm[(j - 1) + (size_t)P * j] = -1; Pm[j + (size_t)P * (j - 1)] = -1; }
       Pm[(P - 1) + (size_t)P * (P - 1)] = 1;
     }
-    HIPCHK(hipMemcpy(pm, Pm.data(), sizeof(double) * Pm.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, pm, Pm.data(), sizeof(double) * Pm.size(), hipMemcpyHostToDevice));
   }
   const size_t T = (size_t)h->T;
   if (dalloc(h, &c.c_nu, T * K * P) || dalloc(h, &c.c_chi, T * n * M) || dalloc(h, &c.c_Z, T * n * K) ||
@@ -227,7 +237,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
 
   // ---- upload data, compute statistics on the device ----
   if (dalloc(h, &h->d_y, (size_t)n_obs)) return 1;
-  HIPCHK(hipMemcpy(h->d_y, y, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, h->d_y, y, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
   int* d_err;
   if (dalloc(h, &d_err, 1)) return 1;
   if (mv) {
@@ -241,9 +251,9 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
     for (int i = 0; i <= deg; ++i) knots[deg + 1 + nint + i] = boundary_knots[1];
     if (dalloc(h, &h->d_t, (size_t)n_obs) || dalloc(h, &h->d_off, (size_t)n + 1) || dalloc(h, &h->d_knots, h->n_knots))
       return 1;
-    HIPCHK(hipMemcpy(h->d_t, t, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_off, offsets, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_knots, knots.data(), sizeof(double) * knots.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, h->d_t, t, sizeof(double) * (size_t)n_obs, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, h->d_off, offsets, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, h->d_knots, knots.data(), sizeof(double) * knots.size(), hipMemcpyHostToDevice));
     if (launch_stats_functional(deg, n, P, d.LREC, h->d_off, h->d_t, h->d_y, h->d_knots, h->n_knots, rec, ni, nullptr,
                                 d_err, h->st))
       return fail("unsupported basis_degree");
@@ -254,9 +264,9 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());
   int herr = 0; long long cnt[2];
-  HIPCHK(hipMemcpy(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&c.YY, d_yy, sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, &herr, d_err, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, &c.YY, d_yy, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
   if (herr) { bfmmm_destroy(h); return fail("at least one time point lies outside 'boundary_knots'"); }
   d.n_obs_total = cnt[0];
   d.half_sum = cnt[1];
@@ -265,7 +275,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   memset(&dyn0, 0, sizeof dyn0);
   dyn0.beta = 1; dyn0.sigma2 = 1; dyn0.alpha3 = 1;
   for (int k = 0; k < KMAX; ++k) { dyn0.pi[k] = 1.0 / K; dyn0.tau[k] = 1; }
-  HIPCHK(hipMemcpy(c.dyn, &dyn0, sizeof dyn0, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, c.dyn, &dyn0, sizeof dyn0, hipMemcpyHostToDevice));
   *out = h;
   return 0;
 }
@@ -303,7 +313,7 @@ extern "C" int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity) {
   launch_stats_functional(h->cfg.basis_degree, d.n, d.P, d.LREC, h->d_off, h->d_t, h->d_y, h->d_knots, h->n_knots,
                           rec_tmp, ni_tmp, dB, err, h->st);
   HIPCHK(hipStreamSynchronize(h->st));
-  HIPCHK(hipMemcpy(out, dB, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, out, dB, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
   (void)hipFree(dB); (void)hipFree(rec_tmp); (void)hipFree(ni_tmp); (void)hipFree(err);
   return 0;
 }
@@ -311,11 +321,11 @@ extern "C" int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity) {
 // ---- state marshalling ----------------------------------------------------------------------
 static int dyn_get(bfmmm_handle* h, Dyn& dyn) {
   HIPCHK(hipStreamSynchronize(h->st));
-  HIPCHK(hipMemcpy(&dyn, h->c.dyn, sizeof dyn, hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, &dyn, h->c.dyn, sizeof dyn, hipMemcpyDeviceToHost));
   return 0;
 }
 static int dyn_put(bfmmm_handle* h, const Dyn& dyn) {
-  HIPCHK(hipMemcpy(h->c.dyn, &dyn, sizeof dyn, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, h->c.dyn, &dyn, sizeof dyn, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -329,7 +339,7 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
   HIPCHK(hipStreamSynchronize(h->st));
   if (s == "nu" || s == "Phi") {
     std::vector<double> th((size_t)K * (M + 1) * P);
-    HIPCHK(hipMemcpy(th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
     if (s == "nu") {
       if (need((int64_t)K * P)) return 1;
       for (int j = 0; j < K; ++j)
@@ -340,7 +350,7 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
         for (int m = 0; m < M; ++m)
           for (int p = 0; p < P; ++p) th[((size_t)j * (M + 1) + m + 1) * P + p] = v[j + (size_t)K * (p + (size_t)P * m)];
     }
-    HIPCHK(hipMemcpy(h->c.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, h->c.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
     return 0;
   }
   struct Arr { const char* nm; double* p; int64_t len; };
@@ -349,7 +359,7 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
   for (const Arr& a : arrs)
     if (s == a.nm) {
       if (need(a.len)) return 1;
-      HIPCHK(hipMemcpy(a.p, v, sizeof(double) * (size_t)a.len, hipMemcpyHostToDevice));
+      HIPCHK(copy_sync(h, a.p, v, sizeof(double) * (size_t)a.len, hipMemcpyHostToDevice));
       return 0;
     }
   Dyn dyn;
@@ -372,7 +382,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   HIPCHK(hipStreamSynchronize(h->st));
   if (s == "nu" || s == "Phi") {
     std::vector<double> th((size_t)K * (M + 1) * P);
-    HIPCHK(hipMemcpy(th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
     if (s == "nu") {
       if (need((int64_t)K * P)) return 1;
       for (int j = 0; j < K; ++j)
@@ -391,7 +401,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   for (const Arr& a : arrs)
     if (s == a.nm) {
       if (need(a.len)) return 1;
-      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(h, out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
       return 0;
     }
   Dyn dyn;
@@ -557,7 +567,8 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
       if (!reuse) {
         if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
         hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
+        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
         launch_body(h, c, plan, h->st, nullptr);
         launch_head(h, c, plan, NTG, NKS, KS, h->st, nullptr);
         join_side(h, h->st);
@@ -607,14 +618,14 @@ extern "C" int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, d
     if (s == a.nm) {
       const int64_t want = a.len * n_slots;
       if (capacity < want) return fail("bfmmm_get_chain(" + s + "): buffer too small");
-      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(h, out, a.p, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost));
       return 0;
     }
   if (s == "tau") {   // stored T_alloc x K column-major on the device; returned n_slots x K column-major
     const int64_t want = (int64_t)n_slots * K;
     if (capacity < want) return fail("bfmmm_get_chain(tau): buffer too small");
     for (int k = 0; k < K; ++k)
-      HIPCHK(hipMemcpy(out + (size_t)n_slots * k, c.c_tau + (size_t)h->T * k, sizeof(double) * (size_t)n_slots,
+      HIPCHK(copy_sync(h, out + (size_t)n_slots * k, c.c_tau + (size_t)h->T * k, sizeof(double) * (size_t)n_slots,
                        hipMemcpyDeviceToHost));
     return 0;
   }
@@ -645,7 +656,7 @@ extern "C" int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, i
   for (const Arr& a : arrs)
     if (s == a.nm) {
       if (capacity < a.len) return fail("bfmmm_debug_get(" + s + "): buffer too small");
-      HIPCHK(hipMemcpy(out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(h, out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
       *count = a.len;
       return 0;
     }

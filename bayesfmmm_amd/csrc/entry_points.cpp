@@ -1,0 +1,440 @@
+// Host-side mirror of the reference's user entry points (include/bfmmm_entry.h) over the sampler ABI
+// (include/bfmmm.h): argument validation with the reference's messages, posterior-median warm
+// starts, multi-try chain selection and result assembly.  No device code here.
+#include "../../include/bfmmm.h"
+#include "../../include/bfmmm_entry.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct ResArr {
+  std::vector<double> data;
+  std::vector<int64_t> dims;
+};
+
+struct bfmmm_result {
+  std::vector<std::string> names;
+  std::map<std::string, ResArr> arrs;
+};
+
+static thread_local std::string g_entry_err;
+extern "C" const char* bfmmm_last_error(void);
+// errors raised here are reported through the same channel as the sampler's: stash them in a
+// result-independent thread-local and let bfmmm_entry_last_error expose them
+extern "C" const char* bfmmm_entry_last_error(void) { return g_entry_err.c_str(); }
+static int efail(const std::string& m) { g_entry_err = m; return 1; }
+static int efail_lib() { g_entry_err = bfmmm_last_error(); return 1; }
+
+extern "C" bfmmm_result* bfmmm_result_create(void) { return new bfmmm_result(); }
+extern "C" void bfmmm_result_free(bfmmm_result* r) { delete r; }
+
+extern "C" int bfmmm_result_set(bfmmm_result* r, const char* name, const double* data, int64_t count, const int64_t* dims,
+                                int n_dims) {
+  if (!r || !name || (!data && count > 0)) return efail("bfmmm_result_set: null argument");
+  const std::string s(name);
+  if (!r->arrs.count(s)) r->names.push_back(s);
+  ResArr& a = r->arrs[s];
+  a.data.assign(data, data + count);
+  a.dims.assign(dims, dims + n_dims);
+  return 0;
+}
+
+extern "C" int bfmmm_result_get(const bfmmm_result* r, const char* name, const double** data, int64_t* count,
+                                const int64_t** dims, int* n_dims) {
+  if (!r || !name) return efail("bfmmm_result_get: null argument");
+  auto it = r->arrs.find(name);
+  if (it == r->arrs.end()) return efail(std::string("result has no element named '") + name + "'");
+  if (data) *data = it->second.data.data();
+  if (count) *count = (int64_t)it->second.data.size();
+  if (dims) *dims = it->second.dims.data();
+  if (n_dims) *n_dims = (int)it->second.dims.size();
+  return 0;
+}
+
+extern "C" int bfmmm_result_count(const bfmmm_result* r) { return r ? (int)r->names.size() : 0; }
+extern "C" const char* bfmmm_result_name(const bfmmm_result* r, int i) {
+  return (r && i >= 0 && i < (int)r->names.size()) ? r->names[i].c_str() : nullptr;
+}
+
+static void put(bfmmm_result* r, const char* name, std::vector<double>&& v, std::vector<int64_t> dims) {
+  const std::string s(name);
+  if (!r->arrs.count(s)) r->names.push_back(s);
+  ResArr& a = r->arrs[s];
+  a.data = std::move(v);
+  a.dims = std::move(dims);
+}
+
+extern "C" void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry) {
+  memset(a, 0, sizeof *a);
+  a->n_try = 1;
+  a->burnin_prop = 0.8;
+  a->b = 10; a->nu_1 = 3;
+  if (entry == 0) { a->alpha1l = 1; a->alpha2l = 2; a->beta1l = 1; a->beta2l = 1; }   // UserFunctions.cpp:179-182
+  else { a->alpha1l = 2; a->alpha2l = 3; a->beta1l = 2; a->beta2l = 2; }               // :699-702, :1363-1366
+  a->a_Z_PM = 10000; a->a_pi_PM = 1000; a->var_alpha3 = 0.05; a->var_epsilon1 = 1; a->var_epsilon2 = 1;
+  a->alpha_nu = 10; a->beta_nu = 1; a->alpha_eta = 10; a->beta_eta = 1; a->alpha_0 = 1; a->beta_0 = 1;
+  a->thinning_num = 1; a->beta_N_t = 1; a->N_t = 1; a->n_temp_trans = 0; a->r_stored_iters = 0;
+  a->seed = 1; a->device = 0; a->chain_offset = 0; a->chain_stride = 1; a->max_concurrent = 4;
+}
+
+// argument checks in the reference's order and wording (UserFunctions.cpp:198-286, 727-818, 1394-1498)
+static int validate(const bfmmm_entry_args* a, int entry) {
+  if (!a || !a->y || !a->t || !a->offsets || !a->boundary_knots) return efail("null argument");
+  if (a->tot_mcmc_iters < 100) return efail("'tot_mcmc_iters' must be an integer greater than or equal to 100");
+  if (entry != 2 && a->n_try < 1) return efail("'n_try' must be an integer greater than or equal to 1");
+  if (entry != 0) {
+    if (a->burnin_prop < 0) return efail("'burnin_prop' must be between 0 and 1");
+    if (a->burnin_prop >= 1) return efail("'burnin_prop' must be between 0 and 1");
+  }
+  if (a->K < 2) return efail("'K' must be an integer greater than or equal to 2");
+  if (a->n_funct < 1) return efail("'n_funct' must be an integer greater than or equal to 1");
+  if (a->basis_degree < 1) return efail("'basis_degree' must be an integer greater than or equal to 1");
+  if (a->n_eigen < 1) return efail("'n_eigen' must be an integer greater than or equal to 1");
+  for (int i = 0; i < a->n_internal_knots; ++i) {
+    if (a->boundary_knots[0] >= a->internal_knots[i])
+      return efail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+    if (a->boundary_knots[1] <= a->internal_knots[i])
+      return efail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+  }
+  if (a->b <= 0) return efail("'b' must be positive");
+  if (entry != 0 && a->nu_1 <= 0) return efail("'nu_1' must be positive");
+  if (a->alpha1l <= 0) return efail("'alpha1l' must be positive");
+  if (a->beta1l <= 0) return efail("'beta1l' must be positive");
+  if (a->alpha2l <= 0) return efail("'alpha2l' must be positive");
+  if (a->beta2l <= 0) return efail("'beta2l' must be positive");
+  if (a->a_Z_PM <= 0) return efail("'a_Z_PM' must be positive");
+  if (a->a_pi_PM <= 0) return efail("'a_pi_PM' must be positive");
+  if (a->var_alpha3 <= 0) return efail("'var_alpha3' must be positive");
+  if (a->var_epsilon1 <= 0) return efail("'var_epsilon1' must be positive");
+  if (a->var_epsilon2 <= 0) return efail("'var_epsilon2' must be positive");
+  if (a->alpha_nu <= 0) return efail("'alpha_nu' must be positive");
+  if (a->beta_nu <= 0) return efail("'beta_nu' must be positive");
+  if (a->alpha_0 <= 0) return efail("'alpha_0' must be positive");
+  if (a->beta_0 <= 0) return efail("'beta_0' must be positive");
+  if (a->c)
+    for (int i = 0; i < a->K; ++i)
+      if (a->c[i] <= 0) return efail("all elements of 'c' must be positive");
+  if (a->K > 6) return efail("K larger than 6 is not supported by this build");
+  if (a->chain_stride < 1 || a->chain_offset < 0) return efail("invalid chain_offset / chain_stride");
+  return 0;
+}
+
+static void make_cfg(const bfmmm_entry_args* a, int T, bfmmm_config* cfg) {
+  bfmmm_config_defaults(cfg);
+  cfg->model = BFMMM_MODEL_FUNCTIONAL;
+  cfg->n_funct = a->n_funct; cfg->K = a->K; cfg->n_eigen = a->n_eigen;
+  cfg->basis_degree = a->basis_degree; cfg->n_internal_knots = a->n_internal_knots;
+  cfg->tot_mcmc_iters = T;
+  for (int k = 0; k < a->K && k < 8; ++k) cfg->c[k] = a->c ? a->c[k] : 10.0;
+  cfg->b = a->b; cfg->nu_1 = a->nu_1;
+  cfg->alpha1l = a->alpha1l; cfg->alpha2l = a->alpha2l; cfg->beta1l = a->beta1l; cfg->beta2l = a->beta2l;
+  cfg->a_Z_PM = a->a_Z_PM; cfg->a_pi_PM = a->a_pi_PM; cfg->var_alpha3 = a->var_alpha3;
+  cfg->var_epsilon1 = a->var_epsilon1; cfg->var_epsilon2 = a->var_epsilon2;
+  cfg->alpha_nu = a->alpha_nu; cfg->beta_nu = a->beta_nu; cfg->alpha_eta = a->alpha_eta; cfg->beta_eta = a->beta_eta;
+  cfg->alpha_0 = a->alpha_0; cfg->beta_0 = a->beta_0;
+}
+
+// arma::median
+static double median_of(std::vector<double>& v) {
+  const size_t n = v.size();
+  if (n == 0) return NAN;
+  const size_t h = n / 2;
+  std::nth_element(v.begin(), v.begin() + h, v.end());
+  const double hi = v[h];
+  if (n & 1) return hi;
+  const double lo = *std::max_element(v.begin(), v.begin() + h);
+  return 0.5 * (lo + hi);
+}
+
+// median over the trailing slices [burn, T) of element e of a (len x T) slot-major chain
+static double tail_median(const double* chain, int64_t len, int64_t e, int64_t burn, int64_t T, std::vector<double>& buf) {
+  buf.clear();
+  for (int64_t l = burn; l < T; ++l) buf.push_back(chain[e + len * l]);
+  return median_of(buf);
+}
+
+struct ChainRun {
+  bfmmm_handle* h = nullptr;
+  double score = -INFINITY;
+  int chain = -1;
+  int rc = 0;
+  std::string err;
+};
+
+// mean of the last 99 log-likelihood values, UserFunctions.cpp:309,320
+static double tail_score(const std::vector<double>& ll, int T) {
+  double s = 0.0;
+  for (int i = T - 99; i <= T - 1; ++i) s += ll[i];
+  return s / 99.0;
+}
+
+typedef int (*chain_setup_fn)(bfmmm_handle* h, int chain, const void* ctx);
+
+// Runs the chains {offset, offset+stride, ...} <= n_try, at most max_concurrent at a time (each on
+// its own stream), and keeps the handle of the best one (strictly larger score wins, earlier chain
+// on ties -- the reference's `<` at UserFunctions.cpp:320).
+static int run_multi_try(const bfmmm_entry_args* a, const bfmmm_config& cfg, uint32_t mask, int phi_chi_zero,
+                         chain_setup_fn setup, const void* ctx, ChainRun* best) {
+  std::vector<int> chains;
+  for (int c = a->chain_offset; c <= a->n_try; c += a->chain_stride) chains.push_back(c);
+  const int T = cfg.tot_mcmc_iters;
+  const int conc = std::max(1, a->max_concurrent);
+  for (size_t base = 0; base < chains.size(); base += conc) {
+    const size_t cnt = std::min(chains.size() - base, (size_t)conc);
+    std::vector<ChainRun> runs(cnt);
+    std::vector<std::thread> th;
+    for (size_t q = 0; q < cnt; ++q) {
+      runs[q].chain = chains[base + q];
+      th.emplace_back([&, q]() {
+        ChainRun& r = runs[q];
+        auto lib_fail = [&]() { r.rc = 1; r.err = bfmmm_last_error(); };
+        if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &r.h)) return lib_fail();
+        if (setup(r.h, r.chain, ctx)) return lib_fail();
+        if (bfmmm_run(r.h, mask, 0, T, a->seed, (uint32_t)r.chain, phi_chi_zero, 1.0)) return lib_fail();
+        std::vector<double> ll(T);
+        if (bfmmm_get_chain(r.h, "loglik", T, ll.data(), T)) return lib_fail();
+        r.score = tail_score(ll, T);
+      });
+    }
+    for (auto& t : th) t.join();
+    for (size_t q = 0; q < cnt; ++q) {
+      ChainRun& r = runs[q];
+      if (r.rc) {
+        for (auto& x : runs) if (x.h) bfmmm_destroy(x.h);
+        if (best->h) { bfmmm_destroy(best->h); best->h = nullptr; }
+        return efail(r.err);
+      }
+      if (!best->h || best->score < r.score) {
+        if (best->h) bfmmm_destroy(best->h);
+        *best = r;
+      } else {
+        bfmmm_destroy(r.h);
+      }
+      r.h = nullptr;
+    }
+  }
+  if (!best->h) return efail("no chain index falls in this process's chain_offset / chain_stride range");
+  return 0;
+}
+
+static int fetch(bfmmm_handle* h, bfmmm_result* r, const char* chain_name, const char* out_name, int T, int64_t len,
+                 std::vector<int64_t> dims, int extra_slot = 0) {
+  std::vector<double> v((size_t)len * (T + extra_slot), 0.0);
+  if (bfmmm_get_chain(h, chain_name, T, v.data(), (int64_t)len * T)) return efail_lib();
+  if (extra_slot && std::string(chain_name) != "loglik")      // slot T carries slot T-1 (BFMMM.h:71-73 style carry)
+    std::copy(v.begin() + (size_t)len * (T - 1), v.begin() + (size_t)len * T, v.begin() + (size_t)len * T);
+  put(r, out_name, std::move(v), std::move(dims));
+  return 0;
+}
+
+static int fetch_tau(bfmmm_handle* h, bfmmm_result* r, int T, int K, int extra_slot = 0) {
+  std::vector<double> v((size_t)T * K), out((size_t)(T + extra_slot) * K, 0.0);
+  if (bfmmm_get_chain(h, "tau", T, v.data(), (int64_t)T * K)) return efail_lib();
+  const int TT = T + extra_slot;
+  for (int k = 0; k < K; ++k) {
+    for (int t = 0; t < T; ++t) out[t + (size_t)TT * k] = v[t + (size_t)T * k];
+    if (extra_slot) out[T + (size_t)TT * k] = v[(T - 1) + (size_t)T * k];
+  }
+  put(r, "tau", std::move(out), {TT, K});
+  return 0;
+}
+
+static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a, const char* name) {
+  const int P = a->n_internal_knots + a->basis_degree + 1;
+  const int64_t n_obs = a->offsets[a->n_funct];
+  std::vector<double> B((size_t)n_obs * P);
+  if (bfmmm_get_basis(h, B.data(), (int64_t)B.size())) return efail_lib();
+  put(r, name, std::move(B), {n_obs, P});
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int setup_nu_z(bfmmm_handle* h, int chain, const void* ctx) {
+  const bfmmm_entry_args* a = (const bfmmm_entry_args*)ctx;
+  return bfmmm_init_state(h, 0, a->seed, (uint32_t)chain);      // BFMMM.h:1039-1071
+}
+
+extern "C" int bfmmm_BFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out) {
+  if (!out) return efail("null argument");
+  if (validate(a, 0)) return 1;
+  const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
+  const int P = a->n_internal_knots + a->basis_degree + 1;
+  bfmmm_config cfg;
+  make_cfg(a, T, &cfg);
+  ChainRun best;
+  if (run_multi_try(a, cfg, BFMMM_SWEEP_NU_Z, 1, setup_nu_z, a, &best)) return 1;
+  bfmmm_result* r = bfmmm_result_create();
+  int rc = fetch_basis(best.h, r, a, "B") || fetch(best.h, r, "nu", "nu", T, (int64_t)K * P, {K, P, T}) ||
+           fetch(best.h, r, "pi", "pi", T, K, {K, T}) || fetch(best.h, r, "alpha_3", "alpha_3", T, 1, {T}) ||
+           fetch(best.h, r, "A", "A", T, (int64_t)K * 2, {K, 2, T}) ||
+           fetch(best.h, r, "delta", "delta", T, (int64_t)K * M, {K, M, T}) ||
+           fetch(best.h, r, "sigma_sq", "sigma_sq", T, 1, {T}) || fetch_tau(best.h, r, T, K) ||
+           fetch(best.h, r, "Z", "Z", T, (int64_t)n * K, {n, K, T}) || fetch(best.h, r, "loglik", "loglik", T, 1, {T});
+  bfmmm_destroy(best.h);
+  if (rc) { bfmmm_result_free(r); return 1; }
+  put(r, "best_chain", {(double)best.chain}, {1});
+  put(r, "best_score", {best.score}, {1});
+  *out = r;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ThetaCtx {
+  const bfmmm_entry_args* a;
+  std::vector<double> Z_est, nu_est;
+};
+
+static int setup_theta(bfmmm_handle* h, int chain, const void* ctx) {
+  const ThetaCtx* t = (const ThetaCtx*)ctx;
+  if (bfmmm_init_state(h, 1, t->a->seed, (uint32_t)chain)) return 1;             // BFMMM.h:1210-1235
+  if (bfmmm_set_state(h, "Z", t->Z_est.data(), (int64_t)t->Z_est.size())) return 1;   // BFMMM.h:1244-1250
+  return bfmmm_set_state(h, "nu", t->nu_est.data(), (int64_t)t->nu_est.size());
+}
+
+// posterior medians of Z and nu over the trailing (1 - burnin_prop) of stage 1, rows of Z
+// renormalised (UserFunctions.cpp:833-858)
+static int median_Z_nu(const bfmmm_entry_args* a, const bfmmm_result* mt, std::vector<double>& Z_est,
+                       std::vector<double>& nu_est, int64_t* n_nu_out) {
+  const double *Zs, *nus;
+  int64_t cz, cn;
+  const int64_t* dz; const int64_t* dn;
+  int ndz, ndn;
+  if (bfmmm_result_get(mt, "Z", &Zs, &cz, &dz, &ndz) || bfmmm_result_get(mt, "nu", &nus, &cn, &dn, &ndn)) return 1;
+  const int n = a->n_funct, K = a->K, P = a->n_internal_knots + a->basis_degree + 1;
+  if (cz % ((int64_t)n * K) != 0 || cn % ((int64_t)K * P) != 0) return efail("'multiple_try' arrays have the wrong shape");
+  const int64_t n_nu = cn / ((int64_t)K * P);
+  if (cz / ((int64_t)n * K) != n_nu) return efail("'multiple_try' arrays have the wrong shape");
+  const int64_t burn = (int64_t)std::round(n_nu * a->burnin_prop);
+  std::vector<double> buf;
+  Z_est.assign((size_t)n * K, 0.0);
+  nu_est.assign((size_t)K * P, 0.0);
+  for (int64_t e = 0; e < (int64_t)n * K; ++e) Z_est[e] = tail_median(Zs, (int64_t)n * K, e, burn, n_nu, buf);
+  for (int64_t e = 0; e < (int64_t)K * P; ++e) nu_est[e] = tail_median(nus, (int64_t)K * P, e, burn, n_nu, buf);
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += Z_est[i + (size_t)n * k];
+    for (int k = 0; k < K; ++k) Z_est[i + (size_t)n * k] /= s;
+  }
+  if (n_nu_out) *n_nu_out = n_nu;
+  return 0;
+}
+
+extern "C" int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, bfmmm_result** out) {
+  if (!out || !multiple_try) return efail("null argument");
+  if (validate(a, 1)) return 1;
+  const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
+  const int P = a->n_internal_knots + a->basis_degree + 1;
+  ThetaCtx tc;
+  tc.a = a;
+  if (median_Z_nu(a, multiple_try, tc.Z_est, tc.nu_est, nullptr)) return 1;
+  bfmmm_config cfg;
+  make_cfg(a, T, &cfg);
+  ChainRun best;
+  if (run_multi_try(a, cfg, BFMMM_SWEEP_THETA, 0, setup_theta, &tc, &best)) return 1;
+  bfmmm_result* r = bfmmm_result_create();
+  int rc = fetch_basis(best.h, r, a, "B") || fetch(best.h, r, "Z", "Z", T, (int64_t)n * K, {n, K, T}) ||
+           fetch(best.h, r, "nu", "nu", T, (int64_t)K * P, {K, P, T}) ||
+           fetch(best.h, r, "chi", "chi", T, (int64_t)n * M, {n, M, T}) ||
+           fetch(best.h, r, "A", "A", T, (int64_t)K * 2, {K, 2, T}) ||
+           fetch(best.h, r, "delta", "delta", T, (int64_t)K * M, {K, M, T}) ||
+           fetch(best.h, r, "sigma_sq", "sigma_sq", T, 1, {T}) || fetch_tau(best.h, r, T, K) ||
+           fetch(best.h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, T}) ||
+           fetch(best.h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, T}) ||
+           fetch(best.h, r, "loglik", "loglik", T, 1, {T});
+  bfmmm_destroy(best.h);
+  if (rc) { bfmmm_result_free(r); return 1; }
+  put(r, "best_chain", {(double)best.chain}, {1});
+  put(r, "best_score", {best.score}, {1});
+  *out = r;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* mt, const bfmmm_result* te,
+                                      bfmmm_result** out) {
+  if (!out || !mt || !te) return efail("null argument");
+  if (validate(a, 2)) return 1;
+  if (a->n_temp_trans != 0)
+    return efail("tempered transitions (n_temp_trans > 0) are not implemented in this build");
+  if (a->r_stored_iters != 0)
+    return efail("batched on-disk chains (r_stored_iters > 0 with 'dir') are not implemented in this build");
+  if (a->thinning_num != 1) return efail("thinning_num != 1 only applies to on-disk batches, which are not implemented in this build");
+  const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
+  const int P = a->n_internal_knots + a->basis_degree + 1;
+  // ---- posterior medians of every block (UserFunctions.cpp:1557-1647) ----
+  std::vector<double> Z_est, nu_est, buf;
+  int64_t n_nu = 0;
+  if (median_Z_nu(a, mt, Z_est, nu_est, &n_nu)) return 1;
+  auto get = [&](const bfmmm_result* r, const char* name, const double** p, int64_t want_per_slot, int64_t* slots) {
+    int64_t cnt;
+    if (bfmmm_result_get(r, name, p, &cnt, nullptr, nullptr)) return 1;
+    if (want_per_slot <= 0 || cnt % want_per_slot != 0) return efail(std::string("'") + name + "' has the wrong shape");
+    *slots = cnt / want_per_slot;
+    return 0;
+  };
+  const double *pis, *a3s, *taus, *deltas, *gammas, *Phis, *As, *sigmas, *chis;
+  int64_t s_pi, s_a3, s_tau, s_delta, s_gamma, s_Phi, s_A, s_sigma, s_chi;
+  if (get(mt, "pi", &pis, K, &s_pi) || get(mt, "alpha_3", &a3s, 1, &s_a3) || get(mt, "tau", &taus, K, &s_tau) ||
+      get(te, "delta", &deltas, (int64_t)K * M, &s_delta) || get(te, "gamma", &gammas, (int64_t)K * P * M, &s_gamma) ||
+      get(te, "Phi", &Phis, (int64_t)K * P * M, &s_Phi) || get(te, "A", &As, (int64_t)K * 2, &s_A) ||
+      get(te, "sigma_sq", &sigmas, 1, &s_sigma) || get(te, "chi", &chis, (int64_t)n * M, &s_chi))
+    return 1;
+  if (s_a3 != n_nu || s_pi != n_nu || s_tau != n_nu) return efail("'multiple_try' arrays have inconsistent lengths");
+  const int64_t n_Phi = s_sigma;
+  if (s_delta != n_Phi || s_gamma != n_Phi || s_Phi != n_Phi || s_A != n_Phi || s_chi != n_Phi)
+    return efail("'theta_est' arrays have inconsistent lengths");
+  const int64_t burn_nu = (int64_t)std::round(n_nu * a->burnin_prop);
+  const int64_t burn_Phi = (int64_t)std::round(n_Phi * a->burnin_prop);
+  const double alpha_3_est = tail_median(a3s, 1, 0, burn_nu, n_nu, buf);
+  std::vector<double> pi_est(K), tau_est(K);
+  double pis_sum = 0.0;
+  for (int k = 0; k < K; ++k) { pi_est[k] = tail_median(pis, K, k, burn_nu, n_nu, buf); pis_sum += pi_est[k]; }
+  for (int k = 0; k < K; ++k) pi_est[k] /= pis_sum;
+  for (int k = 0; k < K; ++k) {   // tau is T x K column-major: (l, k) at l + n_nu * k
+    buf.clear();
+    for (int64_t l = burn_nu; l < n_nu; ++l) buf.push_back(taus[l + n_nu * k]);
+    tau_est[k] = median_of(buf);
+  }
+  const double sigma_est = tail_median(sigmas, 1, 0, burn_Phi, n_Phi, buf);
+  auto med_block = [&](const double* chain, int64_t len) {
+    std::vector<double> v((size_t)len);
+    for (int64_t e = 0; e < len; ++e) v[e] = tail_median(chain, len, e, burn_Phi, n_Phi, buf);
+    return v;
+  };
+  std::vector<double> delta_est = med_block(deltas, (int64_t)K * M), gamma_est = med_block(gammas, (int64_t)K * P * M),
+                      Phi_est = med_block(Phis, (int64_t)K * P * M), A_est = med_block(As, (int64_t)K * 2),
+                      chi_est = med_block(chis, (int64_t)n * M);
+  // ---- one chain of the full sweep from the medians (BFMMM.h:1486-1498, 1500-1554) ----
+  bfmmm_config cfg;
+  make_cfg(a, T, &cfg);
+  bfmmm_handle* h = nullptr;
+  if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &h)) return efail_lib();
+  int rc = bfmmm_set_state(h, "Z", Z_est.data(), (int64_t)Z_est.size()) || bfmmm_set_state(h, "pi", pi_est.data(), K) ||
+           bfmmm_set_state(h, "alpha_3", &alpha_3_est, 1) || bfmmm_set_state(h, "delta", delta_est.data(), (int64_t)K * M) ||
+           bfmmm_set_state(h, "gamma", gamma_est.data(), (int64_t)K * P * M) ||
+           bfmmm_set_state(h, "Phi", Phi_est.data(), (int64_t)K * P * M) || bfmmm_set_state(h, "A", A_est.data(), (int64_t)K * 2) ||
+           bfmmm_set_state(h, "nu", nu_est.data(), (int64_t)K * P) || bfmmm_set_state(h, "tau", tau_est.data(), K) ||
+           bfmmm_set_state(h, "sigma_sq", &sigma_est, 1) || bfmmm_set_state(h, "chi", chi_est.data(), (int64_t)n * M) ||
+           bfmmm_run(h, BFMMM_SWEEP_WARM, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+  if (rc) { efail_lib(); bfmmm_destroy(h); return 1; }
+  // r_stored_iters defaults to tot_mcmc_iters + 1 slots (UserFunctions.cpp:1510-1541): slot T repeats slot T-1
+  const int TT = T + 1;
+  bfmmm_result* r = bfmmm_result_create();
+  rc = fetch_basis(h, r, a, "B_obs") || fetch(h, r, "Z", "Z", T, (int64_t)n * K, {n, K, TT}, 1) ||
+       fetch(h, r, "nu", "nu", T, (int64_t)K * P, {K, P, TT}, 1) || fetch(h, r, "chi", "chi", T, (int64_t)n * M, {n, M, TT}, 1) ||
+       fetch(h, r, "pi", "pi", T, K, {K, TT}, 1) || fetch(h, r, "alpha_3", "alpha_3", T, 1, {TT}, 1) ||
+       fetch(h, r, "A", "A", T, (int64_t)K * 2, {K, 2, TT}, 1) || fetch(h, r, "delta", "delta", T, (int64_t)K * M, {K, M, TT}, 1) ||
+       fetch(h, r, "sigma_sq", "sigma_sq", T, 1, {TT}, 1) || fetch_tau(h, r, T, K, 1) ||
+       fetch(h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, TT}, 1) ||
+       fetch(h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, TT}, 1) || fetch(h, r, "loglik", "loglik", T, 1, {TT}, 1);
+  bfmmm_destroy(h);
+  if (rc) { bfmmm_result_free(r); return 1; }
+  *out = r;
+  return 0;
+}

@@ -1,0 +1,92 @@
+/*
+ * bfmmm_entry.h -- C ABI of the reference's user entry points for the functional model, built
+ * on the sampler ABI of bfmmm.h.  Each function mirrors one exported C++ function of the
+ * reference (argument names, defaults, validation messages, result names and layouts):
+ *
+ *   bfmmm_BFMMM_Nu_Z_multiple_try  <-  BFMMM_Nu_Z_multiple_try  src/UserFunctions.cpp:166-498
+ *                                      (.Call symbol _BayesFMMM_BFMMM_Nu_Z_multiple_try, src/RcppExports.cpp:358)
+ *   bfmmm_BFMMM_Theta_est          <-  BFMMM_Theta_est          src/UserFunctions.cpp:684-1114   (RcppExports.cpp:396)
+ *   bfmmm_BFMMM_warm_start         <-  BFMMM_warm_start         src/UserFunctions.cpp:1341-2155  (RcppExports.cpp:438)
+ *
+ * R lists (Rcpp::List) become `bfmmm_result` objects: named, caller-readable arrays of doubles in
+ * the reference's column-major layouts.  A result produced by one stage is passed to the next
+ * stage exactly as the R lists `multiple_try` / `theta_est` are; a shim can also build one from an
+ * R list with bfmmm_result_create / bfmmm_result_set.
+ *
+ * Differences from the reference that the ABI makes explicit:
+ *   - `seed`: the reference draws from R's global RNG (Rcpp::RNGScope, RcppExports.cpp:361); here every
+ *     chain uses the keyed generator (seed, chain index).
+ *   - multi-try chains are independent (UserFunctions.cpp:302-325 runs 1 + n_try of them back to
+ *     back); `chain_offset` / `chain_stride` let one process run the subset
+ *     {chain_offset, chain_offset + chain_stride, ...} <= n_try of the chain indices so that the
+ *     chains can be spread over GPUs; the result carries "best_chain" and "best_score" for the final
+ *     selection.  With chain_offset = 0, chain_stride = 1 the call is the reference's.
+ */
+#ifndef BFMMM_ENTRY_H
+#define BFMMM_ENTRY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bfmmm_result bfmmm_result;
+
+bfmmm_result* bfmmm_result_create(void);
+void bfmmm_result_free(bfmmm_result* r);
+/* copies `count` doubles; dims (n_dims entries) record the array's shape */
+int bfmmm_result_set(bfmmm_result* r, const char* name, const double* data, int64_t count, const int64_t* dims, int n_dims);
+/* borrowed pointers, valid until the result is freed or the name is set again */
+int bfmmm_result_get(const bfmmm_result* r, const char* name, const double** data, int64_t* count,
+                     const int64_t** dims, int* n_dims);
+int bfmmm_result_count(const bfmmm_result* r);
+const char* bfmmm_result_name(const bfmmm_result* r, int index);
+
+typedef struct {
+  /* data: CSR form of the R lists `Y` and `time` */
+  int32_t n_funct;
+  const double* y;
+  const double* t;
+  const int64_t* offsets;          /* n_funct + 1 */
+  /* model */
+  int32_t tot_mcmc_iters, n_try, K, basis_degree, n_eigen, n_internal_knots;
+  const double* boundary_knots;    /* 2 */
+  const double* internal_knots;    /* n_internal_knots */
+  const double* c;                 /* K, or NULL for the default rep(10, K) (UserFunctions.cpp:272) */
+  double burnin_prop;              /* Theta_est / warm_start */
+  double b, nu_1, alpha1l, alpha2l, beta1l, beta2l, a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2;
+  double alpha_nu, beta_nu, alpha_eta, beta_eta, alpha_0, beta_0;
+  /* warm_start only (UserFunctions.cpp:1353-1359) */
+  double thinning_num, beta_N_t;
+  int32_t N_t, n_temp_trans, r_stored_iters;
+  /* execution */
+  uint64_t seed;
+  int32_t device;
+  int32_t chain_offset, chain_stride;
+  int32_t max_concurrent;          /* chains run concurrently on the device (>= 1) */
+} bfmmm_entry_args;
+
+/* fills in the reference defaults of the named entry point:
+ *   0: BFMMM_Nu_Z_multiple_try (alpha1l = 1, alpha2l = 2, beta1l = beta2l = 1; UserFunctions.cpp:178-193)
+ *   1: BFMMM_Theta_est, 2: BFMMM_warm_start (alpha1l = 2, alpha2l = 3, beta1l = beta2l = 2; :695-715, :1353-1378) */
+void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry);
+
+/* result names: "B" (all basis rows, row-major, see bfmmm_get_basis), "nu" K x P x T, "pi" K x T, "alpha_3" T,
+ * "A" K x 2 x T, "delta" K x M x T, "sigma_sq" T, "tau" T x K, "Z" n x K x T, "loglik" T, "best_chain", "best_score" */
+int bfmmm_BFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out);
+/* multiple_try must hold "Z" and "nu".  result names: "B", "Z", "nu", "chi" n x M x T, "A", "delta", "sigma_sq",
+ * "tau", "gamma" / "Phi" (T arrays K x P x M), "loglik", "best_chain", "best_score" */
+int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, bfmmm_result** out);
+/* result names: "B_obs", "Z", "nu", "chi", "pi", "alpha_3", "A", "delta", "sigma_sq", "tau", "gamma", "Phi", "loglik";
+ * every array has tot_mcmc_iters + 1 slots when r_stored_iters == 0 (UserFunctions.cpp:1510-1541, BFMMM.h:1414-1434) */
+int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, const bfmmm_result* theta_est,
+                           bfmmm_result** out);
+
+/* message of the last failing bfmmm_result_* / bfmmm_BFMMM_* call on this thread */
+const char* bfmmm_entry_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

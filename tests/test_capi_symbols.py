@@ -18,6 +18,12 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bfmmm.h but not exported"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    from bayesfmmm_amd import api
+    hdr2 = open(os.path.join(root, "include", "bfmmm_entry.h")).read()
+    declared2 = set(re.findall(r"\b(bfmmm_[A-Za-z_0-9]+)\s*\(", hdr2))
+    for name in declared2:
+        assert hasattr(lib, name), f"{name} declared in include/bfmmm_entry.h but not exported"
+    assert declared2 == set(api.ENTRY_SYMBOLS), declared2 ^ set(api.ENTRY_SYMBOLS)
 
 
 def test_no_gpu_fails_loudly():

@@ -1,0 +1,91 @@
+"""The three-stage pipeline of the reference's documentation examples (man/BFMMM_warm_start.Rd:
+K=2, cubic splines with knots 250/500/750 on (0,1000), n_eigen=3, 150 iterations, n_try=1, the
+package's own Sim_data.RDS / time.RDS) run through the entry points of include/bfmmm_entry.h,
+plus the reference's argument checks."""
+import os
+
+import numpy as np
+import pytest
+
+from rds_reader import read_rds
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def example():
+    Y = [np.asarray(v).reshape(-1) for v in read_rds(os.path.join(GOLD, "Sim_data.RDS"))]
+    t = [np.asarray(v).reshape(-1) for v in read_rds(os.path.join(GOLD, "time.RDS"))]
+    return dict(Y=Y, time=t, n_funct=40, K=2, basis_degree=3, n_eigen=3, boundary_knots=[0.0, 1000.0],
+                internal_knots=[250.0, 500.0, 750.0])
+
+
+def test_three_stage_pipeline(example):
+    from bayesfmmm_amd import api
+    e = example
+    T, n, K, P, M = 150, 40, 2, 7, 3
+    est1 = api.BFMMM_Nu_Z_multiple_try(T, 1, e["K"], e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"],
+                                       e["boundary_knots"], e["internal_knots"], seed=3)
+    assert set(est1) >= {"B", "nu", "pi", "alpha_3", "A", "delta", "sigma_sq", "tau", "Z", "loglik"}
+    assert est1["nu"].shape == (K, P, T) and est1["Z"].shape == (n, K, T) and est1["tau"].shape == (T, K)
+    assert len(est1["B"]) == n and est1["B"][0].shape == (100, P)
+    assert np.allclose(est1["Z"].sum(axis=1), 1.0)
+    assert np.isfinite(est1["loglik"]).all() and est1["loglik"][-50:].mean() > est1["loglik"][:5].mean()
+    assert est1["best_chain"] in (0.0, 1.0)
+    est2 = api.BFMMM_Theta_est(T, 1, e["K"], e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"],
+                               e["boundary_knots"], e["internal_knots"], est1, seed=4)
+    assert est2["Phi"].shape == (K, P, M, T) and est2["chi"].shape == (n, M, T) and est2["gamma"].shape == (K, P, M, T)
+    # Z and nu are pinned to the stage-1 medians in every slot (BFMMM.h:1244-1250)
+    assert np.abs(est2["Z"] - est2["Z"][:, :, :1]).max() == 0.0
+    assert np.abs(est2["nu"] - est2["nu"][:, :, :1]).max() == 0.0
+    burn = int(round(T * 0.8))
+    zmed = np.median(est1["Z"][:, :, burn:], axis=2)
+    zmed /= zmed.sum(axis=1, keepdims=True)
+    np.testing.assert_allclose(est2["Z"][:, :, 0], zmed, rtol=1e-13)
+    np.testing.assert_allclose(est2["nu"][:, :, 0], np.median(est1["nu"][:, :, burn:], axis=2), rtol=1e-13)
+    mcmc = api.BFMMM_warm_start(T, e["K"], e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"],
+                                e["boundary_knots"], e["internal_knots"], est1, est2, seed=5)
+    assert set(mcmc) >= {"B_obs", "Z", "nu", "chi", "pi", "alpha_3", "A", "delta", "sigma_sq", "tau", "gamma", "Phi", "loglik"}
+    assert mcmc["nu"].shape == (K, P, T + 1) and mcmc["chi"].shape == (n, M, T + 1)      # r_stored_iters = T + 1
+    np.testing.assert_array_equal(mcmc["nu"][:, :, T], mcmc["nu"][:, :, T - 1])
+    assert np.isfinite(mcmc["loglik"][:T]).all()
+    # the fitted curves explain the data: residual variance well below the data variance
+    ysd = np.concatenate(e["Y"]).var()
+    assert np.median(mcmc["sigma_sq"][T // 2:T]) < 0.2 * ysd
+
+
+def test_reference_argument_checks(example):
+    from bayesfmmm_amd import _lib, api
+    e = example
+    common = (e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    with pytest.raises(_lib.BfmmmError, match="'tot_mcmc_iters' must be an integer greater than or equal to 100"):
+        api.BFMMM_Nu_Z_multiple_try(50, 1, 2, *common)
+    with pytest.raises(_lib.BfmmmError, match="'n_try' must be an integer greater than or equal to 1"):
+        api.BFMMM_Nu_Z_multiple_try(150, 0, 2, *common)
+    with pytest.raises(_lib.BfmmmError, match="'K' must be an integer greater than or equal to 2"):
+        api.BFMMM_Nu_Z_multiple_try(150, 1, 1, *common)
+    with pytest.raises(_lib.BfmmmError, match="'a_Z_PM' must be positive"):
+        api.BFMMM_Nu_Z_multiple_try(150, 1, 2, *common, a_Z_PM=-1.0)
+    with pytest.raises(_lib.BfmmmError, match="all elements of 'c' must be positive"):
+        api.BFMMM_Nu_Z_multiple_try(150, 1, 2, *common, c=[1.0, -1.0])
+    with pytest.raises(_lib.BfmmmError, match="number of elements of the vector 'c' must be equal to K"):
+        api.BFMMM_Nu_Z_multiple_try(150, 1, 2, *common, c=[1.0, 1.0, 1.0])
+    with pytest.raises(_lib.BfmmmError, match="more than or equal to second boundary knot"):
+        api.BFMMM_Nu_Z_multiple_try(150, 1, 2, e["Y"], e["time"], 40, 3, 3, [0.0, 1000.0], [250.0, 1500.0])
+
+
+def test_multi_try_keeps_best_chain(example):
+    from bayesfmmm_amd import api
+    e = example
+    common = (e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    T = 120
+    multi = api.BFMMM_Nu_Z_multiple_try(T, 3, 2, *common, seed=9, max_concurrent=4)
+    scores = []
+    for c in range(4):      # the same four chains one by one
+        r = api.BFMMM_Nu_Z_multiple_try(T, 3, 2, *common, seed=9, chain_offset=c, chain_stride=100)
+        assert r["best_chain"] == c
+        scores.append(r["best_score"])
+    assert multi["best_chain"] == int(np.argmax(scores))
+    assert multi["best_score"] == max(scores)
+    assert abs(multi["best_score"] - multi["loglik"][T - 99:].mean()) < 1e-9 * abs(multi["best_score"])
