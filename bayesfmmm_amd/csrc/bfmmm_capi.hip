@@ -24,11 +24,9 @@ int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st);
 int curve_blocks(int n, int P);
 void prepare_curve_kernels();
 void prepare_sweep_kernels();
-void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st);
+void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
-void launch_pi_alpha(const Ctx& c, hipStream_t st);
-void launch_hyper(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 }  // namespace bfmmm
@@ -162,6 +160,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
     BW = std::min(cfg->basis_degree, P - 1);
   }
   if (P > PMAX) return fail("P larger than 64 is not supported by this build");
+  if (M > 16 || (long)K * P * M > 1024) return fail("n_eigen larger than 16 or K*P*n_eigen larger than 1024 is not supported by this build");
 
   HIPCHK(hipSetDevice(device));
   prepare_curve_kernels();
@@ -212,7 +211,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 5 * K + 8) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -471,56 +470,36 @@ static Plan make_plan(uint32_t mask, int MD) {
   p.z = (mask & (U_Z | U_PI | U_ALPHA3)) != 0;
   p.z_update = (mask & U_Z) ? 1 : 0;
   p.pg = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
-  p.factor = p.pg;   // k_factor also prepares r = t - H theta for the sweep
+  p.factor = true;   // k_factor prepares r = t - H theta for the sweep and draws job_hyper's variates
   p.chi_update = ((mask & U_CHI) && MD > 1) ? 1 : 0;
   p.chi = p.chi_update || ((mask & U_LOGLIK) && !(mask & U_SIGMA));
   p.use_rss_part = p.chi ? 1 : 0;
   return p;
 }
 
-// One Gibbs iteration is  HEAD = [Z, (pi/alpha_3), pair-Gram]  followed by
-// BODY = [factor, sweep, (delta/A/gamma/tau), chi, loglik].  pi/alpha_3 (needed by the next Z update)
-// and delta/A/gamma/tau (needed by the next factor) run on the side stream `st2`, forked and joined
-// with events.  The replayed graph is the ROTATED loop  BODY(t) + HEAD(t+1): the slow scalar
-// kernel of iteration t then overlaps chi(t), Z(t+1) and the pair-Gram of t+1 instead of
-// stalling the end of iteration t.
-static void launch_head(bfmmm_handle* h, const Ctx& c, const Plan& p, int NTG, int NKS, int KS, hipStream_t st,
-                        std::vector<hipEvent_t>* evs) {
+// One Gibbs iteration on the sampler's stream:
+//   k_curve_z -> k_pair_gram (+1 workgroup: pi/alpha_3) -> k_pg_reduce -> k_factor -> k_sweep
+//   -> k_curve_chi (+1 workgroup: delta/A/gamma/tau) -> k_loglik
+// The scalar updates ride inside the wide kernels, so the replayed graph is a single chain of
+// seven kernels with no cross-queue dependencies.
+static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NKS, int KS, hipStream_t st,
+                             std::vector<hipEvent_t>* evs) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
   mark();
   if (p.z) launch_curve(c, 0, p.z_update, st);
   mark();
-  (void)hipEventRecord(h->evA, st);
-  (void)hipStreamWaitEvent(h->st2, h->evA, 0);
-  launch_pi_alpha(c, h->st2);
-  (void)hipEventRecord(h->evD, h->st2);
-  if (p.pg) launch_pair_gram(c, NTG, NKS, KS, st);
+  launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
   mark();
-}
-
-static void launch_body(bfmmm_handle* h, const Ctx& c, const Plan& p, hipStream_t st, std::vector<hipEvent_t>* evs) {
-  auto mark = [&]() {
-    if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
-  };
   if (p.factor) launch_factor(c, st);
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
-  (void)hipEventRecord(h->evB, st);
-  (void)hipStreamWaitEvent(h->st2, h->evB, 0);
-  launch_hyper(c, h->st2);
-  (void)hipEventRecord(h->evC, h->st2);
-  if (p.chi) launch_curve(c, 1, p.chi_update, st);
+  launch_curve(c, 1, p.chi ? (p.chi_update ? 2 : 1) : 0, st);
   mark();
   launch_loglik(c, p.use_rss_part, 0, st);
   mark();
-}
-
-static void join_side(bfmmm_handle* h, hipStream_t st) {
-  (void)hipStreamWaitEvent(st, h->evC, 0);
-  (void)hipStreamWaitEvent(st, h->evD, 0);
 }
 
 extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
@@ -546,12 +525,10 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   if (h->profile) {
     for (int it = 0; it < n_iters; ++it) {
       std::vector<hipEvent_t> evs;
-      launch_head(h, c, plan, NTG, NKS, KS, h->st, &evs);     // events 0,1,2
-      launch_body(h, c, plan, h->st, &evs);                   // events 3,4,5,6
-      join_side(h, h->st);
+      launch_iteration(h, c, plan, NKS, KS, h->st, &evs);
       HIPCHK(hipStreamSynchronize(h->st));
       const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
-      const bool ran[6] = {plan.z, plan.pg, plan.factor, true, plan.chi, true};
+      const bool ran[6] = {plan.z, true, plan.factor, true, true, true};
       for (int q = 0; q < 6; ++q) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, evs[q], evs[q + 1]);
@@ -560,27 +537,19 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
       for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
   } else if (n_iters > 0) {
-    launch_head(h, c, plan, NTG, NKS, KS, h->st, nullptr);
-    join_side(h, h->st);          // (evC may be unrecorded on the first call: a no-op wait)
-    if (n_iters > 1) {
-      const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
-      if (!reuse) {
-        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-        hipGraph_t graph = nullptr;
-        std::lock_guard<std::mutex> lock(g_capture_mutex);
-        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
-        launch_body(h, c, plan, h->st, nullptr);
-        launch_head(h, c, plan, NTG, NKS, KS, h->st, nullptr);
-        join_side(h, h->st);
-        HIPCHK(hipStreamEndCapture(h->st, &graph));
-        HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
-      }
-      for (int it = 0; it + 1 < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+    const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
+    if (!reuse) {
+      if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+      hipGraph_t graph = nullptr;
+      std::lock_guard<std::mutex> lock(g_capture_mutex);
+      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
+      launch_iteration(h, c, plan, NKS, KS, h->st, nullptr);
+      HIPCHK(hipStreamEndCapture(h->st, &graph));
+      HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
     }
-    launch_body(h, c, plan, h->st, nullptr);
-    join_side(h, h->st);
+    for (int it = 0; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
   }
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);

@@ -17,6 +17,7 @@
 // All sums have a fixed order: results do not depend on the launch geometry.
 #include "model.hpp"
 #include "rng.hpp"
+#include "scalar_jobs.hpp"
 
 namespace bfmmm {
 
@@ -244,7 +245,15 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
 // LDS per group: U[M], GU[M], C0 (1), D = s - G c0 (1), chi (MMAX), z (MMAX), res (MMAX(MMAX+1)/2 + MMAX + 2)
 // ------------------------------------------------------------------------------------------------
 template <int BW, int LPC>
-__global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
+__global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
+  // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
+  if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
+    job_hyper(c);
+    return;
+  }
+  if (mode == 0) return;
+  const int blk = blockIdx.x - 1;
+  const int do_update = (mode == 2);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
   double* sZn = sChi + MMAX;
   double* sRes = sZn + MMAX;
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
-  const int i = blockIdx.x * GPB + grp;
+  const int i = blk * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int do_update) {
   if (threadIdx.x == 0) {
     double acc = 0.0;
     for (int g = 0; g < GPB; ++g) acc += sRss[g];
-    c.rss_part[blockIdx.x] = acc;
+    c.rss_part[blk] = acc;
   }
 }
 
@@ -387,10 +396,10 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   lds = (lds + 8) * sizeof(double);
   if (LPC == 32) {
     if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);
-    else hipLaunchKernelGGL((k_curve_chi<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);
+    else hipLaunchKernelGGL((k_curve_chi<BW, 32>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);
   } else {
     if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 64>), dim3(nblk), dim3(256), lds, st, c, do_update);
-    else hipLaunchKernelGGL((k_curve_chi<BW, 64>), dim3(nblk), dim3(256), lds, st, c, do_update);
+    else hipLaunchKernelGGL((k_curve_chi<BW, 64>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);
   }
 }
 

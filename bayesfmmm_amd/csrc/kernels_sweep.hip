@@ -15,11 +15,12 @@
 //   k_pg_reduce : fixed-order sum of the split-K partial tiles -> H (R x LG), t (A x P)
 //   k_factor    : one workgroup per direction: reverse Cholesky of Prec_a -> chol_lower(C_a), C_a, L_a z_a
 //   k_sweep     : Phi sweep, nu sweep, sigma^2 (the critical chain)
-//   k_pi_alpha  : pi, alpha_3          (off the critical path)
-//   k_hyper     : delta, A, gamma, tau (off the critical path)
+//   (pi / alpha_3 ride as an extra workgroup of k_pair_gram, delta / A / gamma / tau as an extra
+//    workgroup of k_curve_chi: scalar_jobs.hpp)
 //   k_loglik    : calcLikelihood (CalculateLikelihood.h:19-44) from the per-curve residual sums
 #include "model.hpp"
 #include "rng.hpp"
+#include "scalar_jobs.hpp"
 
 #include <algorithm>
 
@@ -41,11 +42,16 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // wave issuing one v_mfma_f64_16x16x4_f64 per 4 curves and row tile; the weights w_ai w_bi are
 // rebuilt on the fly from Z and chi (also staged in LDS).  Workgroup (CTG, ks) does the same for the
 // single-weight rows against the s part of the records (t_a = sum_i w_ai s_i).
-__global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS) {
+__global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
+  if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
+    if (ks == 0) job_pi_alpha(c);
+    return;
+  }
+  if (!do_pg) return;
   const bool single = ct == d.CTG;
   const int ncol = single ? d.CTS * 16 : 16;
   const int col0 = single ? d.LG : ct * 16;
@@ -212,20 +218,6 @@ __device__ inline double band_mv(const double* __restrict__ Hb, const double* v,
   return s;
 }
 
-// deterministic tree reduction over blockDim.x == 256 values held in LDS scratch
-__device__ inline double block_sum256(double v, double* scratch) {
-  __syncthreads();
-  scratch[threadIdx.x] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) scratch[threadIdx.x] += scratch[threadIdx.x + o];
-    __syncthreads();
-  }
-  const double r = scratch[0];
-  __syncthreads();
-  return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_factor: one workgroup per active direction a.
 //   r_a  = t_a - sum_b H_ab theta_b,  hq_a = H_aa theta_a      (always: the sweep starts from these)
@@ -245,7 +237,12 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
-  const int a = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper
+    job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
+    return;
+  }
+  const int a = blockIdx.x;
   const int j = a / MD, mt = a - j * MD;
   double* S = smem;                 // PP x PP : Prec, then U in its upper triangle (col-major, S[i + PP*k])
   double* X = S + PP * PP;          // PP x PP : U^-1, row-major X[i*PP + c]
@@ -435,7 +432,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   const int n_nu = (mask & U_NU) ? K : 0;
   const int n_steps = n_phi + n_nu;
 #define STAMP(i) do { if (tid == 0) dyn->stamps[i] = wall_clock64(); } while (0)
-  STAMP(0);
 
   // standard gamma variate of the sigma^2 draw: its shape does not depend on the sweep
   double sig_shape = 0.0, sig_g = 0.0;
@@ -454,8 +450,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   for (int e = tid; e < PMAX + 2 * BWMAX; e += SW_THREADS) dlp[e] = 0.0;
   for (int e = tid; e < A * A; e += SW_THREADS) htab[e] = hrow(d, e / A, e % A);
   __syncthreads();
-
-  STAMP(1);
   // per-thread prefetch map: element e of [ H column blocks | C ] of a step
   int pf_b[NPF], pf_off[NPF];
 #pragma unroll
@@ -490,11 +484,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     if (tid < P) rhs[tid] = f * (r[a0 * P + tid] + hq[a0 * P + tid]);
   }
   __syncthreads();
-
-  STAMP(2);
   for (int st = 0; st < n_steps; ++st) {
-    if (st == 1) STAMP(3);
-    if (st == 2) STAMP(6);
     const int a = step_dir(d, st, n_phi);
     const bool more = st + 1 < n_steps;
     const int an = more ? step_dir(d, st + 1, n_phi) : -1;
@@ -515,9 +505,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
         th[a * PS + BW + p] = nw;
       }
     }
-    if (st == 1) STAMP(4);
     lds_barrier();
-    if (st == 1) STAMP(5);
     // phase B: r_b -= H_ba dl ; hq_a ; next rhs
     for (int e = tid; e < AP; e += SW_THREADS) {
       const int b = e / P, p = e - b * P;
@@ -533,8 +521,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     if (more) pf_store((st & 1) ? pbuf0 : pbuf1);
     lds_barrier();
   }
-
-  STAMP(7);
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
   if (mask & U_SIGMA) {
     // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
@@ -561,7 +547,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   } else if (tid == 0) {
     c.c_sigma[slot] = dyn->sigma2;
   }
-  STAMP(8);
   // ---------------- publish theta and its chain slots -------------------------------------------
   double* s_nu = c.c_nu + (size_t)slot * K * P;
   double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
@@ -578,249 +563,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
       const int k = e % K, pm = e / K, p = pm % P, m = pm / P;
       s_phi[e] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
     }
-  STAMP(9);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_pi_alpha: pi (updatePi_PM, UpdatePi.h:84-116) and alpha_3 (updateAlpha3, UpdateAlpha3.h:36-63).
-// Needs S_k = sum_i log Z_ik (block partials of k_curve_z).  Off the critical path of the
-// iteration: only the next Z update reads pi and alpha_3.  The dozens of lgamma / log / gamma
-// evaluations are spread over lanes instead of being run by one thread.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pi_alpha(Ctx c) {
-  __shared__ double red[256];
-  __shared__ double S[KMAX], g[KMAX], lg[8 * KMAX + 8], pis[3 * KMAX + 2];
-  const Dims& d = c.d;
-  const int K = d.K, n = d.n, tid = threadIdx.x;
-  Dyn* dyn = c.dyn;
-  const uint32_t mask = c.mask;
-  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-  for (int k = 0; k < K; ++k) {
-    double acc = 0.0;
-    const int per = (c.nblk_curve + 255) / 256;
-    for (int b = tid * per; b < min(c.nblk_curve, (tid + 1) * per); ++b) acc += c.logz_part[(size_t)b * K + k];
-    const double s = block_sum256(acc, red);
-    if (tid == 0) S[k] = s;
-  }
-  // proposals: lane k < K draws the pi gamma, lane K the alpha_3 truncated normal
-  double alpha3 = dyn->alpha3;
-  const double sd = c.h.var_alpha3;
-  if (tid < K) {
-    const double a_old = c.h.a_pi_PM * dyn->pi[tid];
-    g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
-  } else if (tid == K) {
-    pis[3 * KMAX] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
-  }
-  __syncthreads();
-  double pi_old[KMAX], pi_new[KMAX];
-  double gsum = 0.0;
-  for (int k = 0; k < K; ++k) gsum += g[k];
-  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
-  const double a3_ph = pis[3 * KMAX];
-  // lgamma table, one lane each.  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
-  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5
-  if (tid < 6 * K) {
-    const int row = tid / K, k = tid - row * K;
-    const double pk = (row & 1) ? pi_new[k] : pi_old[k];
-    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
-    lg[tid] = lgamma(sc * pk);
-  } else if (tid < 6 * K + 6) {
-    const int row = tid - 6 * K;
-    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc += sc * ((row & 1) ? pi_new[k] : pi_old[k]);
-    lg[tid] = lgamma(acc);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    auto lB = [&](int row) {   // calc_lB of (scale_row * pi_row)
-      double s = 0.0;
-      for (int k = 0; k < K; ++k) s += lg[row * K + k];
-      return s - lg[6 * K + row];
-    };
-    double pi[KMAX];
-    for (int k = 0; k < K; ++k) pi[k] = pi_old[k];
-    int pi_is_new = 0;
-    if (mask & U_PI) {
-      double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const double lo = log(pi_old[k]), ln = log(pi_new[k]);
-        lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
-        lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
-        pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
-        po += (c.h.a_pi_PM * pi_new[k] - 1) * lo;
-      }
-      lpdf_new -= n * lB(3);
-      lpdf_old -= n * lB(2);
-      const double lpn = pn - lB(0);
-      const double lpo = po - lB(1);
-      const double acc = lpdf_new - lpdf_old + lpo - lpn;
-      const double u = runif(key, UPD_PI_ACC, 0);
-      if (log(u) < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
-      for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
-    }
-    if (mask & U_ALPHA3) {
-      double l_old = (-c.h.b) * alpha3, l_new = (-c.h.b) * a3_ph;
-      for (int k = 0; k < K; ++k) {
-        l_old += ((alpha3 * pi[k]) - 1) * S[k];
-        l_new += ((a3_ph * pi[k]) - 1) * S[k];
-      }
-      l_old -= n * lB(2 + pi_is_new);
-      l_new -= n * lB(4 + pi_is_new);
-      // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
-      l_old += dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0);
-      l_new += dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
-      const double u = runif(key, UPD_A3_ACC, 0);
-      if (log(u) < l_new - l_old) alpha3 = a3_ph;
-      dyn->alpha3 = alpha3;
-    }
-    c.c_alpha3[dyn->slot] = dyn->alpha3;
-    for (int k = 0; k < K; ++k) c.c_pi[(size_t)dyn->slot * K + k] = dyn->pi[k];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_hyper: delta (UpdateDelta.h:17-64), A (UpdateA.h:58-123), gamma (UpdateGamma.h:17-37) and
-// tau (UpdateTau.h:18-36; MV :47-63), in the reference's order.  Off the critical path: only the
-// next iteration's k_factor reads them.  Every gamma variate is scale * Gamma(shape, 1) with a
-// shape known up front, so all standard variates are drawn in parallel first and only the O(M)
-// scale recursions stay sequential.
-// ---------------------------------------------------------------------------------------------
-__device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
-
-__global__ __launch_bounds__(256) void k_hyper(Ctx c) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ double red[256];
-  const Dims& d = c.d;
-  const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
-  Dyn* dyn = c.dyn;
-  const uint32_t mask = c.mask, slot = dyn->slot_hyper;
-  const RngKey key = make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step);
-  double* gD = smem;                   // K*M   standard gammas for delta
-  double* Skm = gD + K * M;            // K*M   sum_p gamma phi^2
-  double* gT = Skm + K * M;            // K     standard gammas for tau
-  double* aw = gT + KMAX;              // K*2*6 work of the A update
-  const bool phi_on = MD > 1;
-  // ---- delta ----
-  if ((mask & U_DELTA) && phi_on) {
-    if (tid < K * M) {
-      const int k = tid / M, i = tid - k * M;
-      const double param1 = (i == 0) ? c.Aa[k] + ((P * M) / 2.0) : c.Aa[k + (size_t)K] + ((P * (M - i)) / 2.0);
-      gD[tid] = rgamma(key, UPD_DELTA, (uint32_t)(k * M + i), param1, 1.0);
-    } else if (tid >= 64 && tid < 64 + K * M) {
-      const int q = tid - 64, k = q / M, m = q - k * M;
-      double acc = 0.0;
-      for (int p = 0; p < P; ++p) {
-        const double ph = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
-        acc += c.gamma[k + (size_t)K * (p + (size_t)P * m)] * (ph * ph);
-      }
-      Skm[q] = acc;
-    }
-    __syncthreads();
-    if (tid < K) {
-      const int k = tid;
-      for (int i = 0; i < M; ++i) {
-        double param2 = 1.0;
-        if (i == 0) {
-          param2 += 0.5 * Skm[k * M + 0];
-          for (int m = 1; m < M; ++m) {
-            double tt = 1.0;
-            for (int nn = 1; nn <= m; ++nn) tt *= c.delta[k + (size_t)K * nn];
-            param2 += 0.5 * tt * Skm[k * M + m];
-          }
-        } else {
-          for (int m = i; m < M; ++m) {
-            double tt = 1.0;
-            for (int nn = 0; nn <= m; ++nn)
-              if (nn != i) tt *= c.delta[k + (size_t)K * nn];
-            param2 += 0.5 * tt * Skm[k * M + m];
-          }
-        }
-        c.delta[k + (size_t)K * i] = gD[k * M + i] * (1.0 / param2);
-      }
-    }
-    __syncthreads();
-  }
-  // ---- A : six lanes per cell (j, i): proposal, then lpdf(cur), lpdf(new), the two proposal densities ----
-  if ((mask & U_A) && phi_on) {
-    const int ncell = K * 2;
-    if (tid < ncell) {
-      const int j = tid / 2, i = tid - 2 * j;
-      const double sd = (i == 0) ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
-      aw[tid * 6 + 0] = rtruncnorm_lo(key, UPD_A_PROP, (uint32_t)(j * 2 + i), c.Aa[j + (size_t)K * i], sd, 0.0);
-    }
-    __syncthreads();
-    if (tid < ncell * 4) {
-      const int cell = tid >> 2, job = tid & 3;
-      const int j = cell / 2, i = cell - 2 * j;
-      const bool first = (i == 0);
-      const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
-      const double cur = c.Aa[j + (size_t)K * i], na = aw[cell * 6 + 0];
-      double v;
-      if (job < 2) {
-        const double a = (job == 0) ? cur : na;
-        if (first) {
-          v = -logGamma_ref(a) + (a - 1) * log(c.delta[j]) + (c.h.alpha1l - 1) * log(a) - (a * c.h.beta1l);   // UpdateA.h:17-24
-        } else {
-          const double x = M - 1;                                                                             // UpdateA.h:33-44
-          v = -x * logGamma_ref(a) + (c.h.alpha2l - 1) * log(a) - (a * c.h.beta2l);
-          for (int q = 1; q < M; ++q) v = v + (a - 1) * log(c.delta[j + (size_t)K * q]);
-        }
-      } else if (job == 2) v = dtruncnorm_lo_log(cur, na, sd, 0.0);
-      else v = dtruncnorm_lo_log(na, cur, sd, 0.0);
-      aw[cell * 6 + 1 + job] = v;
-    }
-    __syncthreads();
-    if (tid < ncell) {
-      const int j = tid / 2, i = tid - 2 * j;
-      const double* w = aw + tid * 6;
-      const double acc = (w[2] + w[3]) - w[1] - w[4];
-      const double u = runif(key, UPD_A_ACC, (uint32_t)(j * 2 + i));
-      if (log(u) < acc) c.Aa[j + (size_t)K * i] = w[0];
-    }
-    __syncthreads();
-  }
-  // ---- gamma ----
-  if ((mask & U_GAMMA) && phi_on) {
-    for (int e = tid; e < K * P * M; e += 256) {
-      // e = (i*P + l)*M + j  (reference loop order i, l, j)
-      const int jj = e % M, il = e / M, l = il % P, i = il / P;
-      double ph = 1.0;
-      for (int j2 = 0; j2 <= jj; ++j2) ph *= c.delta[i + (size_t)K * j2];
-      const double phi = c.theta[(size_t)(i * (M + 1) + jj + 1) * P + l];
-      c.gamma[i + (size_t)K * (l + (size_t)P * jj)] =
-          rgamma(key, UPD_GAMMA, (uint32_t)e, (c.h.nu_1 + 1) / 2, 1.0) * (2 / (c.h.nu_1 + ph * (phi * phi)));
-    }
-  }
-  // ---- tau ----
-  if (mask & U_TAU) {
-    if (tid < K) gT[tid] = rgamma(key, UPD_TAU, (uint32_t)tid, c.h.alpha_nu + (P / 2), 1.0);   // integer division, UpdateTau.h:29
-    for (int k = 0; k < K; ++k) {
-      double acc = 0.0;
-      if (tid < P) {
-        const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
-        const double vp = nu[tid];
-        double s = 0.0;
-        if (d.mv) s = vp;
-        else
-          for (int q = 0; q < P; ++q) s += c.Pmat[tid + (size_t)P * q] * nu[q];
-        acc = vp * s;
-      }
-      const double qf = block_sum256(acc, red);
-      if (tid == 0) {
-        const double b = c.h.beta_nu + (0.5 * qf);
-        const double gg = gT[k] * (1.0 / b);
-        dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- chain slots ----
-  double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
-  for (int e = tid; e < K * P * M; e += 256) s_gam[e] = c.gamma[e];
-  if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
-  if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
-  if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -857,11 +599,11 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 }
 
 // ---- host launchers -------------------------------------------------------------------------
-void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st) {
-  (void)NTG;
+void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int ncol = std::max(16, c.d.CTS * 16);
   const size_t lds = (size_t)KS * (c.d.K + c.d.MD + ncol) * sizeof(double);
-  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 1, NKS), dim3(256), lds, st, c, KS);
+  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(256), lds, st, c, KS, do_pg);
+  if (!do_pg) return;
   const int nthreads = c.d.NT * 256;
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, c, NKS);
 }
@@ -869,8 +611,10 @@ void launch_pair_gram(const Ctx& c, int NTG, int NKS, int KS, hipStream_t st) {
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP + (size_t)c.d.A * c.d.LG) * sizeof(double);
-  if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(c.d.A), dim3(256), lds, st, c);
-  else hipLaunchKernelGGL(k_factor<64>, dim3(c.d.A), dim3(256), lds, st, c);
+  const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K;
+  const int grid = c.d.A + (n_draw + 255) / 256;
+  if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(grid), dim3(256), lds, st, c);
+  else hipLaunchKernelGGL(k_factor<64>, dim3(grid), dim3(256), lds, st, c);
 }
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
@@ -884,13 +628,6 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   return 0;
 }
 
-void launch_pi_alpha(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_pi_alpha, dim3(1), dim3(256), 0, st, c); }
-
-void launch_hyper(const Ctx& c, hipStream_t st) {
-  const size_t lds = ((size_t)2 * c.d.K * c.d.M + KMAX + (size_t)c.d.K * 2 * 6 + 8) * sizeof(double);
-  hipLaunchKernelGGL(k_hyper, dim3(1), dim3(256), lds, st, c);
-}
-
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
   hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, st, c, use_rss_part, r_stored);
 }
@@ -900,7 +637,6 @@ void prepare_sweep_kernels() {
   set_max_lds((const void*)k_pair_gram);
   set_max_lds((const void*)k_factor<32>);
   set_max_lds((const void*)k_factor<64>);
-  set_max_lds((const void*)k_hyper);
 }
 
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {

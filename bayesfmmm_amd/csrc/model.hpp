@@ -100,6 +100,7 @@ struct Ctx {
   double* rvec;                 // A x P            r_a = t_a - sum_b H_ab theta_b at the start of the sweep
   double* hq;                   // A x P            H_aa theta_a
   double* Lz;                   // A x P            chol_lower(C_a) z_a, z_a the direction's N(0,I) draw
+  double* gstd;                 // state-independent variates of job_hyper (scalar_jobs.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty

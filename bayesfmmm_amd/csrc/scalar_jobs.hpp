@@ -1,0 +1,319 @@
+// Scalar ("small") updates of the sweep, written as single-workgroup device jobs (256 threads)
+// that ride as ONE EXTRA WORKGROUP of a wide kernel instead of being kernels of their own:
+//   job_pi_alpha : pi (updatePi_PM, UpdatePi.h:84-116) and alpha_3 (updateAlpha3, UpdateAlpha3.h:36-63)
+//                  -> extra workgroup of k_pair_gram (only the next Z update reads pi / alpha_3)
+//   job_hyper    : delta (UpdateDelta.h:17-64), A (UpdateA.h:58-123), gamma (UpdateGamma.h:17-37),
+//                  tau (UpdateTau.h:18-36; MV :47-63) in the reference's order
+//                  -> extra workgroup of k_curve_chi (only the next factorisation reads them)
+// so they cost neither a launch nor a cross-stream dependency, and run while the other 255 CUs do
+// the per-curve / contraction work.  On a GPU a single lane runs ~3e8 dependent instructions/s, so
+// the jobs are organised to spread their transcendental work (lgamma, log, gamma rejection
+// loops) over lanes: every gamma variate is  scale * Gamma(shape, 1)  with a shape known up
+// front, so all standard variates are drawn in one parallel phase and only O(M) scale
+// recursions stay sequential.
+#pragma once
+#include "model.hpp"
+#include "rng.hpp"
+
+namespace bfmmm {
+
+// deterministic tree reduction over blockDim.x == 256 values held in LDS scratch
+__device__ inline double block_sum256(double v, double* scratch) {
+  __syncthreads();
+  scratch[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) scratch[threadIdx.x] += scratch[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
+
+// ------------------------------------------------------------------------------------------------
+__device__ inline void job_pi_alpha(const Ctx& c) {
+  __shared__ double red[KMAX][256];
+  __shared__ double S[KMAX], g[KMAX], lg[6 * KMAX + 8], ph_s[1];
+  const Dims& d = c.d;
+  const int K = d.K, n = d.n, tid = threadIdx.x;
+  Dyn* dyn = c.dyn;
+  const uint32_t mask = c.mask;
+  if (!(mask & (U_PI | U_ALPHA3))) {
+    if (tid == 0) {
+      c.c_alpha3[dyn->slot] = dyn->alpha3;
+      for (int k = 0; k < K; ++k) c.c_pi[(size_t)dyn->slot * K + k] = dyn->pi[k];
+    }
+    return;
+  }
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  // S_k = sum_i log Z_ik from the block partials of k_curve_z: one fixed-order tree for all k at once
+  {
+    double acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+    const int per = (c.nblk_curve + 255) / 256;
+    for (int b = tid * per; b < min(c.nblk_curve, (tid + 1) * per); ++b)
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc[k] += c.logz_part[(size_t)b * K + k];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) red[k][tid] += red[k][tid + o];
+      __syncthreads();
+    }
+    if (tid < K) S[tid] = red[tid][0];
+  }
+  // proposals: lane k < K draws the pi gamma, lane K the alpha_3 truncated normal
+  double alpha3 = dyn->alpha3;
+  const double sd = c.h.var_alpha3;
+  if (tid < K) {
+    const double a_old = c.h.a_pi_PM * dyn->pi[tid];
+    g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
+  } else if (tid == K) {
+    ph_s[0] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
+  }
+  __syncthreads();
+  double pi_old[KMAX], pi_new[KMAX];
+  double gsum = 0.0;
+  for (int k = 0; k < K; ++k) gsum += g[k];
+  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
+  const double a3_ph = ph_s[0];
+  // lgamma table, one lane each.  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
+  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5
+  if (tid < 6 * K) {
+    const int row = tid / K, k = tid - row * K;
+    const double pk = (row & 1) ? pi_new[k] : pi_old[k];
+    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
+    lg[tid] = lgamma(sc * pk);
+  } else if (tid < 6 * K + 6) {
+    const int row = tid - 6 * K;
+    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += sc * ((row & 1) ? pi_new[k] : pi_old[k]);
+    lg[tid] = lgamma(acc);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto lB = [&](int row) {   // calc_lB of (scale_row * pi_row), Distributions.h:51-60
+      double s = 0.0;
+      for (int k = 0; k < K; ++k) s += lg[row * K + k];
+      return s - lg[6 * K + row];
+    };
+    double pi[KMAX];
+    for (int k = 0; k < K; ++k) pi[k] = pi_old[k];
+    int pi_is_new = 0;
+    if (mask & U_PI) {
+      double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double lo = log(pi_old[k]), ln = log(pi_new[k]);
+        lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
+        lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
+        pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
+        po += (c.h.a_pi_PM * pi_new[k] - 1) * lo;
+      }
+      lpdf_new -= n * lB(3);
+      lpdf_old -= n * lB(2);
+      const double lpn = pn - lB(0);
+      const double lpo = po - lB(1);
+      const double acc = lpdf_new - lpdf_old + lpo - lpn;
+      const double u = runif(key, UPD_PI_ACC, 0);
+      if (log(u) < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
+      for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
+    }
+    if (mask & U_ALPHA3) {
+      double l_old = (-c.h.b) * alpha3, l_new = (-c.h.b) * a3_ph;
+      for (int k = 0; k < K; ++k) {
+        l_old += ((alpha3 * pi[k]) - 1) * S[k];
+        l_new += ((a3_ph * pi[k]) - 1) * S[k];
+      }
+      l_old -= n * lB(2 + pi_is_new);
+      l_new -= n * lB(4 + pi_is_new);
+      // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
+      l_old += dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0);
+      l_new += dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
+      const double u = runif(key, UPD_A3_ACC, 0);
+      if (log(u) < l_new - l_old) alpha3 = a3_ph;
+      dyn->alpha3 = alpha3;
+    }
+    c.c_alpha3[dyn->slot] = dyn->alpha3;
+    for (int k = 0; k < K; ++k) c.c_pi[(size_t)dyn->slot * K + k] = dyn->pi[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// State-independent variates of job_hyper, drawn by spare workgroups of k_factor (same iteration):
+//   gstd = [ gamma(k,p,m): K*P*M standard gammas | delta: K*M | tau: K | A proposals: 2K | A accept uniforms: 2K ]
+// (the delta shapes and the A proposals depend on A, which the previous iteration's job_hyper
+// finished updating before this iteration's k_factor started).
+__device__ inline int hyper_gstd_count(const Dims& d) { return d.K * d.P * d.M + d.K * d.M + d.K + 4 * d.K; }
+
+__device__ inline void job_hyper_draws(const Ctx& c, int first) {
+  const Dims& d = c.d;
+  const int P = d.P, K = d.K, M = d.M;
+  const Dyn* dyn = c.dyn;
+  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  const int nG = K * P * M;
+  const int e = first + threadIdx.x;
+  if (e >= hyper_gstd_count(d)) return;
+  double v;
+  if (e < nG) {
+    v = rgamma(key, UPD_GAMMA, (uint32_t)e, (c.h.nu_1 + 1) / 2, 1.0);                       // UpdateGamma.h:29
+  } else if (e < nG + K * M) {
+    const int q = e - nG, k = q / M, i = q - k * M;
+    const double param1 = (i == 0) ? c.Aa[k] + ((P * M) / 2.0) : c.Aa[k + (size_t)K] + ((P * (M - i)) / 2.0);
+    v = rgamma(key, UPD_DELTA, (uint32_t)(k * M + i), param1, 1.0);                         // UpdateDelta.h:28,42 / :45,57
+  } else if (e < nG + K * M + K) {
+    const int k = e - nG - K * M;
+    v = rgamma(key, UPD_TAU, (uint32_t)k, c.h.alpha_nu + (P / 2), 1.0);                     // integer division, UpdateTau.h:29
+  } else if (e < nG + K * M + K + 2 * K) {
+    const int cell = e - nG - K * M - K, j = cell / 2, i = cell - 2 * j;
+    const double sd = (i == 0) ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
+    v = rtruncnorm_lo(key, UPD_A_PROP, (uint32_t)(j * 2 + i), c.Aa[j + (size_t)K * i], sd, 0.0);   // UpdateA.h:79,98
+  } else {
+    const int cell = e - nG - K * M - K - 2 * K;
+    v = runif(key, UPD_A_ACC, (uint32_t)cell);                                              // UpdateA.h:90,109
+  }
+  c.gstd[e] = v;
+}
+
+__device__ inline void job_hyper(const Ctx& c) {
+  __shared__ double Skm[KMAX * 16], aw[KMAX * 2 * 6], qrow[KMAX * PMAX], dl[KMAX * 16], slog[KMAX];
+  const Dims& d = c.d;
+  const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
+  Dyn* dyn = c.dyn;
+  const uint32_t mask = c.mask, slot = dyn->slot;
+  const bool phi_on = MD > 1;
+  const bool do_delta = (mask & U_DELTA) && phi_on, do_A = (mask & U_A) && phi_on, do_gamma = (mask & U_GAMMA) && phi_on;
+  const bool do_tau = (mask & U_TAU) != 0;
+  const int nG = K * P * M;
+  const double* gGam = c.gstd;
+  const double* gD = c.gstd + nG;
+  const double* gT = gD + K * M;
+  const double* aProp = gT + K;
+  const double* aUnif = aProp + 2 * K;
+#define HSTAMP(i) do { if (tid == 0) dyn->stamps[i] = wall_clock64(); } while (0)
+  HSTAMP(0);
+  // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 ; row products of nu_k' P nu_k ----
+  if (do_delta && tid < K * M) {
+    const int k = tid / M, m = tid - k * M;
+    double acc = 0.0;
+    for (int p = 0; p < P; ++p) {
+      const double ph = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
+      acc += c.gamma[k + (size_t)K * (p + (size_t)P * m)] * (ph * ph);
+    }
+    Skm[tid] = acc;
+  }
+  if (do_tau && tid >= 64 && tid < 64 + K * P && tid < 256) {
+    const int e = tid - 64, k = e / P, p = e - k * P;
+    const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
+    double s = 0.0;
+    if (d.mv) s = nu[p];
+    else
+      for (int q = 0; q < P; ++q) s += c.Pmat[p + (size_t)P * q] * nu[q];
+    qrow[e] = nu[p] * s;
+  }
+  if (tid < K)
+    for (int m = 0; m < M; ++m) dl[tid * 16 + m] = c.delta[tid + (size_t)K * m];
+  __syncthreads();
+  HSTAMP(1);
+  // ---- phase 2: tau (K lanes), delta recursion (K lanes) ----
+  if (do_tau && tid >= 32 && tid < 32 + K) {
+    const int k = tid - 32;
+    double qf = 0.0;
+    if (K * P <= 192) { for (int p = 0; p < P; ++p) qf += qrow[k * P + p]; }
+    else {
+      const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
+      for (int p = 0; p < P; ++p) {
+        double s = 0.0;
+        if (d.mv) s = nu[p];
+        else for (int q = 0; q < P; ++q) s += c.Pmat[p + (size_t)P * q] * nu[q];
+        qf += nu[p] * s;
+      }
+    }
+    const double b = c.h.beta_nu + (0.5 * qf);
+    const double gg = gT[k] * (1.0 / b);
+    dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
+  }
+  if (tid < K) {
+    const int k = tid;
+    double* dk = dl + k * 16;
+    if (do_delta) {
+      for (int i = 0; i < M; ++i) {
+        double param2 = 1.0;
+        if (i == 0) {
+          param2 += 0.5 * Skm[k * M + 0];
+          double tt = 1.0;
+          for (int m = 1; m < M; ++m) { tt *= dk[m]; param2 += 0.5 * tt * Skm[k * M + m]; }
+        } else {
+          for (int m = i; m < M; ++m) {
+            double tt = 1.0;
+            for (int nn = 0; nn <= m; ++nn)
+              if (nn != i) tt *= dk[nn];
+            param2 += 0.5 * tt * Skm[k * M + m];
+          }
+        }
+        dk[i] = gD[k * M + i] * (1.0 / param2);
+      }
+      for (int m = 0; m < M; ++m) c.delta[k + (size_t)K * m] = dk[m];
+    }
+    double sl = 0.0;                                   // sum_{q >= 1} log delta(k, q), used by lpdf_a2
+    for (int q = 1; q < M; ++q) sl += log(dk[q]);
+    slog[k] = sl;
+  }
+  __syncthreads();
+  HSTAMP(2);
+  // ---- phase 3: A terms (4 lanes per cell), gamma scaling ----
+  if (do_A && tid < K * 2 * 4) {
+    const int cell = tid >> 2, job = tid & 3;
+    const int j = cell / 2, i = cell - 2 * j;
+    const bool first = (i == 0);
+    const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
+    const double cur = c.Aa[j + (size_t)K * i], na = aProp[cell];
+    double v;
+    if (job < 2) {
+      const double a = (job == 0) ? cur : na;
+      if (first) {
+        v = -logGamma_ref(a) + (a - 1) * log(dl[j * 16]) + (c.h.alpha1l - 1) * log(a) - (a * c.h.beta1l);   // UpdateA.h:17-24
+      } else {
+        const double x = M - 1;                                                                             // UpdateA.h:33-44
+        v = -x * logGamma_ref(a) + (c.h.alpha2l - 1) * log(a) - (a * c.h.beta2l) + (a - 1) * slog[j];
+      }
+    } else if (job == 2) v = dtruncnorm_lo_log(cur, na, sd, 0.0);
+    else v = dtruncnorm_lo_log(na, cur, sd, 0.0);
+    aw[cell * 6 + 1 + job] = v;
+  }
+  if (do_gamma) {
+    for (int e = tid; e < nG; e += 256) {            // e = (i*P + l)*M + j  (reference loop order i, l, j)
+      const int jj = e % M, il = e / M, l = il % P, i = il / P;
+      double ph = 1.0;
+      for (int j2 = 0; j2 <= jj; ++j2) ph *= dl[i * 16 + j2];
+      const double phi = c.theta[(size_t)(i * (M + 1) + jj + 1) * P + l];
+      c.gamma[i + (size_t)K * (l + (size_t)P * jj)] = gGam[e] * (2 / (c.h.nu_1 + ph * (phi * phi)));
+    }
+  }
+  __syncthreads();
+  HSTAMP(3);
+  // ---- phase 4: A accept; chain slots ----
+  if (do_A && tid < K * 2) {
+    const double* w = aw + tid * 6;
+    const double acc = (w[2] + w[3]) - w[1] - w[4];
+    if (log(aUnif[tid]) < acc) c.Aa[(tid >> 1) + (size_t)K * (tid & 1)] = aProp[tid];
+  }
+  __syncthreads();
+  double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
+  for (int e = tid; e < nG; e += 256) s_gam[e] = c.gamma[e];
+  if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
+  if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
+  if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
+  HSTAMP(4);
+}
+
+}  // namespace bfmmm

@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent-chains", type=int, default=8,
+                    help="extra (untimed-region) measurement: this many independent chains at once on GPU 0")
+    ap.add_argument("--concurrent-steps", type=int, default=400)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +150,34 @@ def main():
             fams[nm] = dict(ms_per_launch=ms / max(cnt, 1), launches=cnt)
         smp.set_profile(False)
 
+    # extra: aggregate throughput of C independent chains sharing GPU 0 (multi-try chains are independent;
+    # the single-chain sweep is latency-bound and leaves most CUs idle)
+    multi = None
+    if rank == 0 and args.concurrent_chains > 1:
+        import threading
+        C_ = args.concurrent_chains
+        cfg2 = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"],
+                                 tot_mcmc_iters=args.concurrent_steps + 10)
+        smps = [bf.Sampler(cfg2, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
+                for _ in range(C_)]
+        for q, s_ in enumerate(smps):
+            s_.set_state(**w["state"])
+            s_.run(bf.SWEEP_WARM, 10, first_iter=0, seed=1, chain=100 + q)
+
+        def work(q):
+            smps[q].run(bf.SWEEP_WARM, args.concurrent_steps, first_iter=10, seed=1, chain=100 + q)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=work, args=(q,)) for q in range(C_)]
+        [t_.start() for t_ in ths]
+        [t_.join() for t_ in ths]
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        multi = dict(chains=C_, steps_per_chain=args.concurrent_steps, value=C_ * args.concurrent_steps / dt2,
+                     unit="Gibbs iterations/sec (all chains)")
+        for s_ in smps:
+            s_.close()
+
     if rank == 0:
         n, P, M, K = w["n"], w["P"], w["M"], w["K"]
         value = world * args.steps / dt
@@ -156,7 +187,7 @@ def main():
         blocks = {"curve_z": 1, "pair_gram": 2, "sweep": 1, "curve_chi": 1, "factor": 0, "loglik": 0}
         roofline = None
         if fams:
-            dom = max(fams, key=lambda k: fams[k]["ms_per_launch"])
+            dom = max((k for k in fams if blocks[k] > 0), key=lambda k: fams[k]["ms_per_launch"])
             ms = fams[dom]["ms_per_launch"]
             bytes_dom = blocks[dom] * n * 8 * (P * P + P + 1)
             ach = bytes_dom / (ms * 1e-3) / 1e9
@@ -174,6 +205,7 @@ def main():
                                    f"fp64, one independent chain per GPU", "chains": world,
                        "device_ms_per_step": dev_ms / args.steps},
             "roofline": roofline,
+            "multi_chain": multi,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)

@@ -7,7 +7,7 @@ smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"])
 smp.set_state(**w["state"])
 smp.run(bf.SWEEP_WARM, 50)
 st = smp.get_state("stamps")
-names = ["start","prologue loads","pf step0 + rhs","step0 total","step1 phaseA","barrier","step1 phaseB (to step2)","steps 2..20","sigma","publish"]
-print("k_sweep stamps (us):")
-for i in range(1, 10): print(f"  {names[i]:28s} {(st[i]-st[i-1])*0.01:8.2f}")
-print("  total", st[9]*0.01)
+names = ["start","Skm + tau rows","tau, delta rec, slog","A terms + gamma scale","accept + slots"]
+print("job_hyper stamps (us):")
+for i in range(1, 5): print(f"  {names[i]:32s} {(st[i]-st[i-1])*0.01:8.2f}")
+print("  total", st[4]*0.01)
