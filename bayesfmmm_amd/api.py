@@ -33,7 +33,7 @@ class EntryArgs(C.Structure):
                 ("alpha_0", C.c_double), ("beta_0", C.c_double), ("thinning_num", C.c_double), ("beta_N_t", C.c_double),
                 ("N_t", C.c_int32), ("n_temp_trans", C.c_int32), ("r_stored_iters", C.c_int32),
                 ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
-                ("max_concurrent", C.c_int32)]
+                ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32)]
 
 
 ENTRY_SYMBOLS = {
@@ -48,6 +48,9 @@ ENTRY_SYMBOLS = {
     "bfmmm_BFMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_BFMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
     "bfmmm_BFMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_BMVMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_BMVMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_BMVMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bfmmm_entry_last_error": (C.c_char_p, []),
 }
 
@@ -71,6 +74,33 @@ def _check(rc):
         raise _lib.BfmmmError(_lib_entry().bfmmm_entry_last_error().decode())
 
 
+class _ArgsMV:
+    """bfmmm_entry_args of the multivariate entry points: Y is the n x P matrix."""
+
+    def __init__(self, entry, tot_mcmc_iters, K, Y, n_eigen, X, kw):
+        if X is not None:
+            raise NotImplementedError("covariate-adjusted models (X) are not implemented in this round")
+        lib = _lib_entry()
+        self.a = EntryArgs()
+        lib.bfmmm_entry_defaults(C.byref(self.a), entry)
+        self.Y = np.asfortranarray(Y, dtype=np.float64)
+        n, P = self.Y.shape
+        a = self.a
+        a.n_funct, a.P, a.tot_mcmc_iters, a.K, a.n_eigen = n, P, tot_mcmc_iters, K, n_eigen
+        a.y = self.Y.ctypes.data_as(c_double_p)
+        self.P, self.offsets = P, None
+        c = kw.pop("c", None)
+        if c is not None:
+            self.c = np.ascontiguousarray(c, dtype=np.float64)
+            if self.c.size != K:
+                raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
+            a.c = self.c.ctypes.data_as(c_double_p)
+        for k, v in kw.items():
+            if not hasattr(a, k):
+                raise TypeError(f"unexpected argument '{k}'")
+            setattr(a, k, v)
+
+
 def _result_to_dict(lib, res, offsets, P):
     out = {}
     for i in range(lib.bfmmm_result_count(res)):
@@ -80,7 +110,7 @@ def _result_to_dict(lib, res, offsets, P):
         shape = tuple(dims[k] for k in range(nd.value))
         arr = np.ctypeslib.as_array(data, shape=(cnt.value,)).copy()
         key = name.decode()
-        if key in ("B", "B_obs"):
+        if key in ("B", "B_obs") and offsets is not None:
             rows = arr.reshape(-1, P)
             out[key] = [rows[offsets[j]:offsets[j + 1]].copy() for j in range(len(offsets) - 1)]
         elif key in ("best_chain", "best_score"):
@@ -191,3 +221,38 @@ def BFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen,
     mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
     te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
     return _call1(lib.bfmmm_BFMMM_warm_start, args, mt, te)
+
+
+def BMVMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, n_eigen, X=None, group=None, **kw):
+    """src/UserFunctions.cpp:4579 (multivariate model: Y is an n x P matrix, no basis)."""
+    lib = _lib_entry()
+    args = _ArgsMV(3, tot_mcmc_iters, K, Y, n_eigen, X, kw)
+    args.a.n_try = n_try
+    if group is not None:
+        from . import parallel
+        return parallel.multi_try(lambda: _call1(lib.bfmmm_BMVMMM_Nu_Z_multiple_try, args), args, group)
+    return _call1(lib.bfmmm_BMVMMM_Nu_Z_multiple_try, args)
+
+
+def BMVMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, n_eigen, multiple_try, X=None, burnin_prop=0.8, group=None, **kw):
+    """src/UserFunctions.cpp:4995."""
+    lib = _lib_entry()
+    args = _ArgsMV(4, tot_mcmc_iters, K, Y, n_eigen, X, kw)
+    args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
+    mt = {k: multiple_try[k] for k in ("Z", "nu")}
+    if group is not None:
+        from . import parallel
+        return parallel.multi_try(lambda: _call1(lib.bfmmm_BMVMMM_Theta_est, args, mt), args, group)
+    return _call1(lib.bfmmm_BMVMMM_Theta_est, args, mt)
+
+
+def BMVMMM_warm_start(tot_mcmc_iters, K, Y, n_eigen, multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
+    """src/UserFunctions.cpp:5540."""
+    if dir is not None:
+        raise NotImplementedError("on-disk chain batches ('dir') are not implemented in this round")
+    lib = _lib_entry()
+    args = _ArgsMV(5, tot_mcmc_iters, K, Y, n_eigen, X, kw)
+    args.a.burnin_prop = burnin_prop
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
+    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
+    return _call1(lib.bfmmm_BMVMMM_warm_start, args, mt, te)

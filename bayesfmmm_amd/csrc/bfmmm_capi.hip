@@ -160,7 +160,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
     BW = std::min(cfg->basis_degree, P - 1);
   }
   if (P > PMAX) return fail("P larger than 64 is not supported by this build");
-  if (M > 16 || (long)K * P * M > 1024) return fail("n_eigen larger than 16 or K*P*n_eigen larger than 1024 is not supported by this build");
+  if (M > 16) return fail("n_eigen larger than 16 is not supported by this build");
 
   HIPCHK(hipSetDevice(device));
   prepare_curve_kernels();

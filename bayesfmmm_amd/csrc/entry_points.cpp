@@ -75,8 +75,11 @@ extern "C" void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry) {
   a->n_try = 1;
   a->burnin_prop = 0.8;
   a->b = 10; a->nu_1 = 3;
-  if (entry == 0) { a->alpha1l = 1; a->alpha2l = 2; a->beta1l = 1; a->beta2l = 1; }   // UserFunctions.cpp:179-182
-  else { a->alpha1l = 2; a->alpha2l = 3; a->beta1l = 2; a->beta2l = 2; }               // :699-702, :1363-1366
+  if (entry == 0) { a->alpha1l = 1; a->alpha2l = 2; a->beta1l = 1; a->beta2l = 1; }        // UserFunctions.cpp:179-182
+  else if (entry == 1 || entry == 2) { a->alpha1l = 2; a->alpha2l = 3; a->beta1l = 2; a->beta2l = 2; }   // :699-702, :1363-1366
+  else if (entry == 3) { a->alpha1l = 2; a->alpha2l = 3; a->beta1l = 1; a->beta2l = 1; }   // :4586-4589
+  else { a->alpha1l = 1; a->alpha2l = 2; a->beta1l = 1; a->beta2l = 1; }                    // :5006-5009, :5556-5559
+  a->model = (entry >= 3) ? BFMMM_MODEL_MULTIVARIATE : BFMMM_MODEL_FUNCTIONAL;
   a->a_Z_PM = 10000; a->a_pi_PM = 1000; a->var_alpha3 = 0.05; a->var_epsilon1 = 1; a->var_epsilon2 = 1;
   a->alpha_nu = 10; a->beta_nu = 1; a->alpha_eta = 10; a->beta_eta = 1; a->alpha_0 = 1; a->beta_0 = 1;
   a->thinning_num = 1; a->beta_N_t = 1; a->N_t = 1; a->n_temp_trans = 0; a->r_stored_iters = 0;
@@ -85,7 +88,10 @@ extern "C" void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry) {
 
 // argument checks in the reference's order and wording (UserFunctions.cpp:198-286, 727-818, 1394-1498)
 static int validate(const bfmmm_entry_args* a, int entry) {
-  if (!a || !a->y || !a->t || !a->offsets || !a->boundary_knots) return efail("null argument");
+  if (!a || !a->y) return efail("null argument");
+  const bool mv = a->model == BFMMM_MODEL_MULTIVARIATE;
+  if (!mv && (!a->t || !a->offsets || !a->boundary_knots)) return efail("null argument");
+  if (mv && a->P < 1) return efail("'Y' must have at least one column");
   if (a->tot_mcmc_iters < 100) return efail("'tot_mcmc_iters' must be an integer greater than or equal to 100");
   if (entry != 2 && a->n_try < 1) return efail("'n_try' must be an integer greater than or equal to 1");
   if (entry != 0) {
@@ -94,9 +100,9 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   }
   if (a->K < 2) return efail("'K' must be an integer greater than or equal to 2");
   if (a->n_funct < 1) return efail("'n_funct' must be an integer greater than or equal to 1");
-  if (a->basis_degree < 1) return efail("'basis_degree' must be an integer greater than or equal to 1");
+  if (!mv && a->basis_degree < 1) return efail("'basis_degree' must be an integer greater than or equal to 1");
   if (a->n_eigen < 1) return efail("'n_eigen' must be an integer greater than or equal to 1");
-  for (int i = 0; i < a->n_internal_knots; ++i) {
+  for (int i = 0; !mv && i < a->n_internal_knots; ++i) {
     if (a->boundary_knots[0] >= a->internal_knots[i])
       return efail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
     if (a->boundary_knots[1] <= a->internal_knots[i])
@@ -127,7 +133,8 @@ static int validate(const bfmmm_entry_args* a, int entry) {
 
 static void make_cfg(const bfmmm_entry_args* a, int T, bfmmm_config* cfg) {
   bfmmm_config_defaults(cfg);
-  cfg->model = BFMMM_MODEL_FUNCTIONAL;
+  cfg->model = a->model;
+  cfg->P = a->P;
   cfg->n_funct = a->n_funct; cfg->K = a->K; cfg->n_eigen = a->n_eigen;
   cfg->basis_degree = a->basis_degree; cfg->n_internal_knots = a->n_internal_knots;
   cfg->tot_mcmc_iters = T;
@@ -245,8 +252,13 @@ static int fetch_tau(bfmmm_handle* h, bfmmm_result* r, int T, int K, int extra_s
   return 0;
 }
 
+static int dimP(const bfmmm_entry_args* a) {
+  return (a->model == BFMMM_MODEL_MULTIVARIATE) ? a->P : a->n_internal_knots + a->basis_degree + 1;
+}
+
 static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a, const char* name) {
-  const int P = a->n_internal_knots + a->basis_degree + 1;
+  if (a->model == BFMMM_MODEL_MULTIVARIATE) return 0;      // no basis in the multivariate model
+  const int P = dimP(a);
   const int64_t n_obs = a->offsets[a->n_funct];
   std::vector<double> B((size_t)n_obs * P);
   if (bfmmm_get_basis(h, B.data(), (int64_t)B.size())) return efail_lib();
@@ -264,7 +276,7 @@ extern "C" int bfmmm_BFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_re
   if (!out) return efail("null argument");
   if (validate(a, 0)) return 1;
   const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
-  const int P = a->n_internal_knots + a->basis_degree + 1;
+  const int P = dimP(a);
   bfmmm_config cfg;
   make_cfg(a, T, &cfg);
   ChainRun best;
@@ -306,7 +318,7 @@ static int median_Z_nu(const bfmmm_entry_args* a, const bfmmm_result* mt, std::v
   const int64_t* dz; const int64_t* dn;
   int ndz, ndn;
   if (bfmmm_result_get(mt, "Z", &Zs, &cz, &dz, &ndz) || bfmmm_result_get(mt, "nu", &nus, &cn, &dn, &ndn)) return 1;
-  const int n = a->n_funct, K = a->K, P = a->n_internal_knots + a->basis_degree + 1;
+  const int n = a->n_funct, K = a->K, P = dimP(a);
   if (cz % ((int64_t)n * K) != 0 || cn % ((int64_t)K * P) != 0) return efail("'multiple_try' arrays have the wrong shape");
   const int64_t n_nu = cn / ((int64_t)K * P);
   if (cz / ((int64_t)n * K) != n_nu) return efail("'multiple_try' arrays have the wrong shape");
@@ -329,7 +341,7 @@ extern "C" int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_resu
   if (!out || !multiple_try) return efail("null argument");
   if (validate(a, 1)) return 1;
   const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
-  const int P = a->n_internal_knots + a->basis_degree + 1;
+  const int P = dimP(a);
   ThetaCtx tc;
   tc.a = a;
   if (median_Z_nu(a, multiple_try, tc.Z_est, tc.nu_est, nullptr)) return 1;
@@ -366,7 +378,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
     return efail("batched on-disk chains (r_stored_iters > 0 with 'dir') are not implemented in this build");
   if (a->thinning_num != 1) return efail("thinning_num != 1 only applies to on-disk batches, which are not implemented in this build");
   const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
-  const int P = a->n_internal_knots + a->basis_degree + 1;
+  const int P = dimP(a);
   // ---- posterior medians of every block (UserFunctions.cpp:1557-1647) ----
   std::vector<double> Z_est, nu_est, buf;
   int64_t n_nu = 0;
@@ -437,4 +449,20 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   if (rc) { bfmmm_result_free(r); return 1; }
   *out = r;
   return 0;
+}
+
+// ---- multivariate aliases (BMVMMM_*): the same drivers on G_i = I records ------------------------
+static int need_mv(const bfmmm_entry_args* a) {
+  if (!a || a->model != BFMMM_MODEL_MULTIVARIATE) return efail("bfmmm_BMVMMM_*: args.model must be BFMMM_MODEL_MULTIVARIATE");
+  return 0;
+}
+extern "C" int bfmmm_BMVMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out) {
+  return need_mv(a) || bfmmm_BFMMM_Nu_Z_multiple_try(a, out);
+}
+extern "C" int bfmmm_BMVMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* mt, bfmmm_result** out) {
+  return need_mv(a) || bfmmm_BFMMM_Theta_est(a, mt, out);
+}
+extern "C" int bfmmm_BMVMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* mt, const bfmmm_result* te,
+                                       bfmmm_result** out) {
+  return need_mv(a) || bfmmm_BFMMM_warm_start(a, mt, te, out);
 }

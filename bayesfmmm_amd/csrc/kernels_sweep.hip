@@ -582,7 +582,11 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_s
   }
   if (tid == 0) {
     const double s2 = dyn->sigma2;
-    const double ll = -(double)c.d.n_obs_total * (0.91893853320467274178 + log(sqrt(s2))) - rss / (2.0 * s2);
+    double ll;
+    if (c.d.mv)   // calcLikelihoodMV: (y_obs.n_cols / 2) is an integer division, CalculateLikelihood.h:155
+      ll = -(double)c.d.n * ((c.d.P / 2) * log(2 * 3.14159265358979323846 * s2)) - (1 / (s2 * 2)) * rss;
+    else
+      ll = -(double)c.d.n_obs_total * (0.91893853320467274178 + log(sqrt(s2))) - rss / (2.0 * s2);
     dyn->rss = rss;
     dyn->loglik = ll;
     if (c.mask & U_LOGLIK) c.c_loglik[dyn->slot] = ll;

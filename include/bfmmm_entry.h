@@ -65,11 +65,17 @@ typedef struct {
   int32_t device;
   int32_t chain_offset, chain_stride;
   int32_t max_concurrent;          /* chains run concurrently on the device (>= 1) */
+  /* multivariate model (BMVMMM_*): model = 1, y = the n_funct x P column-major matrix `Y`
+   * (UserFunctions.cpp:4582); t, offsets and the knot arguments are ignored */
+  int32_t model;
+  int32_t P;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:
  *   0: BFMMM_Nu_Z_multiple_try (alpha1l = 1, alpha2l = 2, beta1l = beta2l = 1; UserFunctions.cpp:178-193)
- *   1: BFMMM_Theta_est, 2: BFMMM_warm_start (alpha1l = 2, alpha2l = 3, beta1l = beta2l = 2; :695-715, :1353-1378) */
+ *   1: BFMMM_Theta_est, 2: BFMMM_warm_start (alpha1l = 2, alpha2l = 3, beta1l = beta2l = 2; :695-715, :1353-1378)
+ *   3: BMVMMM_Nu_Z_multiple_try (alpha1l = 2, alpha2l = 3, beta1l = beta2l = 1; :4586-4589)
+ *   4: BMVMMM_Theta_est, 5: BMVMMM_warm_start (alpha1l = 1, alpha2l = 2, beta1l = beta2l = 1; :5006-5009, :5556-5559) */
 void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry);
 
 /* result names: "B" (all basis rows, row-major, see bfmmm_get_basis), "nu" K x P x T, "pi" K x T, "alpha_3" T,
@@ -82,6 +88,14 @@ int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multipl
  * every array has tot_mcmc_iters + 1 slots when r_stored_iters == 0 (UserFunctions.cpp:1510-1541, BFMMM.h:1414-1434) */
 int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, const bfmmm_result* theta_est,
                            bfmmm_result** out);
+
+/* Multivariate model: BMVMMM_Nu_Z_multiple_try (src/UserFunctions.cpp:4579, .Call symbol at src/RcppExports.cpp:680),
+ * BMVMMM_Theta_est (:4995 / RcppExports.cpp:713), BMVMMM_warm_start (:5540 / RcppExports.cpp:750).  Same results as
+ * the functional entry points minus "B" / "B_obs". */
+int bfmmm_BMVMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out);
+int bfmmm_BMVMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, bfmmm_result** out);
+int bfmmm_BMVMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, const bfmmm_result* theta_est,
+                            bfmmm_result** out);
 
 /* message of the last failing bfmmm_result_* / bfmmm_BFMMM_* call on this thread */
 const char* bfmmm_entry_last_error(void);

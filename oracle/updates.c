@@ -621,7 +621,8 @@ void orc_updateChi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
   if (iter < (T - 1)) memcpy(SL_CHI(c, iter + 1), chi_t, sizeof(double) * (size_t)n * M);
 }
 
-/* calcLikelihood, CalculateLikelihood.h:19-44 (R::dnorm(y, mean, sqrt(sigma), log)) */
+/* calcLikelihood, CalculateLikelihood.h:19-44 (R::dnorm(y, mean, sqrt(sigma), log));
+ * calcLikelihoodMV :137-160 uses (y_obs.n_cols / 2) * log(2 pi sigma) with INTEGER division (:155) */
 double orc_calcLikelihood(const orc_data* d, int iter, const orc_chain* c) {
   DIMS;
   const double sigma = c->sigma[iter];
@@ -629,6 +630,15 @@ double orc_calcLikelihood(const orc_data* d, int iter, const orc_chain* c) {
   double log_lik = 0;
   for (int i = 0; i < n; ++i) {
     const int ni = NI(i);
+    if (d->mv) {
+      double ss = 0.0;
+      for (int l = 0; l < ni; ++l) {
+        double rr = YOBS(i, l) - fitted_skipzero(d, c, iter, i, BROW(i, l));
+        ss += rr * rr;
+      }
+      log_lik = log_lik - ((P / 2) * log(2 * 3.14159265358979323846 * sigma)) - ((1 / (sigma * 2)) * ss);
+      continue;
+    }
     for (int l = 0; l < ni; ++l) {
       double mean = fitted_skipzero(d, c, iter, i, BROW(i, l));
       double z = (YOBS(i, l) - mean) / sd;

@@ -1,0 +1,110 @@
+"""Multivariate model (BMVMMM_*): the HIP path (band width 0 records, G_i = I) against the CPU
+oracle's MV variants (UpdateNu.h:160, UpdatePhi.h:190, UpdateChi.h:138, UpdateSigma.h:127,
+UpdateTau.h:47, CalculateLikelihood.h:137), and the package's multivariate example pipeline
+(man/BMVMMM_warm_start.Rd: MVSim_data.RDS, K=2, n_eigen=2, 150 iterations)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_parity import ORC_FIELD, push_state, rel_err
+from rds_reader import read_rds
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def simulate_mv(n, P, K, M, sigma_sq, seed):
+    # src/test-Nu.cpp:213-254 style: Y = Z (nu + sum_m chi_m Phi_m) + N(0, sigma_sq)
+    rng = np.random.default_rng(seed)
+    nu = rng.standard_normal((K, P)) * 2
+    Phi = np.stack([(M - m) * 0.3 * rng.standard_normal((K, P)) for m in range(M)], axis=2)
+    chi = rng.standard_normal((n, M))
+    Z = rng.dirichlet(np.full(K, 2.0), size=n)
+    Y = Z @ nu + np.einsum("ik,im,kpm->ip", Z, chi, Phi) + np.sqrt(sigma_sq) * rng.standard_normal((n, P))
+    return dict(Y=Y, nu=nu, Phi=Phi, chi=chi, Z=Z, n=n, P=P, K=K, M=M, sigma_sq=sigma_sq)
+
+
+def setup(seed, n=45, P=11, K=3, M=2, T=6):
+    import bayesfmmm_amd as bf
+    sim = simulate_mv(n, P, K, M, 0.05, seed)
+    model = O.Model([sim["Y"][i] for i in range(n)], [np.eye(P)] * n, K, M, mv=True)
+    ch = O.Chain(model, T)
+    rng = np.random.default_rng(seed + 1)
+    ch.nu[:, :, 0] = sim["nu"] + 0.2 * rng.standard_normal((K, P))
+    ch.Phi[..., 0] = sim["Phi"] + 0.1 * rng.standard_normal((K, P, M))
+    ch.chi[:, :, 0] = sim["chi"] + 0.2 * rng.standard_normal((n, M))
+    ch.Z[:, :, 0] = rng.dirichlet(np.full(K, 2.0), size=n)
+    ch.pi[:, 0] = rng.dirichlet(np.full(K, 5.0))
+    ch.alpha3[0] = 4.0
+    ch.delta[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, M))
+    ch.A[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, 2))
+    ch.gamma[..., 0] = rng.gamma(2.0, 0.7, size=(K, P, M))
+    ch.tau[0, :] = rng.gamma(3.0, 0.5, size=K)
+    ch.sigma[0] = 0.07
+    cfg = bf.default_config(model=bf.MODEL_MULTIVARIATE, K=K, n_eigen=M, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, sim["Y"])
+    push_state(smp, ch)
+    return sim, model, ch, smp
+
+
+@pytest.mark.parametrize("sweep", ["nu_z", "theta", "warm"])
+def test_mv_trajectory_matches_oracle(sweep):
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    T = 6
+    sim, model, ch, smp = setup(seed=21, T=T)
+    h = O.make_hyper(sim["K"])
+    if sweep == "nu_z":
+        ch.chi[:] = 0.0
+        ch.Phi[:] = 0.0
+        push_state(smp, ch)
+        O.run_sweeps(model, h, ch, O.SWEEP_NU_Z, seed=5)
+        smp.run(S.SWEEP_NU_Z, T, seed=5, phi_chi_zero=True)
+        names = ["nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik"]
+    elif sweep == "theta":
+        O.run_sweeps(model, h, ch, O.SWEEP_THETA, seed=5)
+        smp.run(S.SWEEP_THETA, T, seed=5)
+        names = ["Phi", "chi", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]
+    else:
+        O.run_sweeps(model, h, ch, O.SWEEP_WARM, seed=5)
+        smp.run(S.SWEEP_WARM, T, seed=5)
+        names = ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]
+    for nm in names:
+        got = smp.get_chain(nm)
+        ref = getattr(ch, ORC_FIELD.get(nm, nm))
+        assert rel_err(got, ref) < 1e-6, (sweep, nm, rel_err(got, ref))
+
+
+def test_mv_quirks_integer_divisions():
+    # odd P: loglik uses floor(P/2) log(2 pi sigma^2) per row (CalculateLikelihood.h:155) and sigma's shape uses
+    # floor(n*P/2) (UpdateSigma.h:150); tau is stored inverted (UpdateTau.h:58)
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    sim, model, ch, smp = setup(seed=33, n=7, P=5, T=3)
+    smp.run(S.U_LOGLIK, 1, seed=1)
+    ll = smp.get_chain("loglik", 1)[0]
+    Y = sim["Y"]
+    coef = ch.Z[:, :, 0] @ ch.nu[:, :, 0] + np.einsum("ik,im,kpm->ip", ch.Z[:, :, 0], ch.chi[:, :, 0], ch.Phi[..., 0])
+    rss = ((Y - coef) ** 2).sum()
+    s2 = ch.sigma[0]
+    expect = -7 * (5 // 2) * np.log(2 * np.pi * s2) - rss / (2 * s2)
+    assert abs(ll - expect) < 1e-9 * abs(expect)
+    assert abs(O.calcLikelihood(model, ch, 0) - expect) < 1e-9 * abs(expect)
+
+
+def test_mv_example_pipeline():
+    from bayesfmmm_amd import api
+    Y = np.asarray(read_rds(os.path.join(GOLD, "MVSim_data.RDS")))
+    T, K, M = 150, 2, 2
+    n, P = Y.shape
+    est1 = api.BMVMMM_Nu_Z_multiple_try(T, 1, K, Y, M, seed=2)
+    assert "B" not in est1 and est1["nu"].shape == (K, P, T) and est1["Z"].shape == (n, K, T)
+    est2 = api.BMVMMM_Theta_est(T, 1, K, Y, M, est1, seed=3)
+    assert est2["Phi"].shape == (K, P, M, T)
+    mcmc = api.BMVMMM_warm_start(T, K, Y, M, est1, est2, seed=4)
+    assert mcmc["chi"].shape == (n, M, T + 1) and np.isfinite(mcmc["loglik"][:T]).all()
+    assert np.allclose(mcmc["Z"][:, :, :T].sum(axis=1), 1.0)
+    with pytest.raises(Exception, match="'K' must be an integer greater than or equal to 2"):
+        api.BMVMMM_Nu_Z_multiple_try(T, 1, 1, Y, M)
