@@ -120,11 +120,16 @@ static void set_md(Dims& d, int MD) {
 }
 
 static void pg_geometry(const Dims& d, int& NTG, int& NKS, int& KS) {
+  // k-slices of the pair-Gram contraction: about 32 of them, but never more curves per slice than fit a
+  // 96 KB LDS staging area (Z, chi and 16..CTS*16 record columns per curve)
+  const int ncol = std::max(16, d.CTS * 16);
+  const int ks_cap = std::max(4, (int)((96 * 1024) / (sizeof(double) * (size_t)(d.K + d.MD + ncol))) / 4 * 4);
   NKS = std::max(1, std::min(32, d.n / 16));
   KS = (d.n + NKS - 1) / NKS;
   KS = (KS + 3) / 4 * 4;
+  KS = std::min(KS, ks_cap);
   NKS = (d.n + KS - 1) / KS;
-  NTG = std::max(1, std::min(d.NT, 256 / NKS));
+  NTG = 1;
 }
 
 extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
