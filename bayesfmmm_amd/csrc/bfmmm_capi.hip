@@ -29,6 +29,8 @@ void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
+void launch_cov_block(const Ctx& c, hipStream_t st);
+void prepare_cov_kernels();
 }  // namespace bfmmm
 
 using namespace bfmmm;
@@ -170,6 +172,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   HIPCHK(hipSetDevice(device));
   prepare_curve_kernels();
   prepare_sweep_kernels();
+  prepare_cov_kernels();
   { hipError_t e0 = hipGetLastError(); if (e0 != hipSuccess) fprintf(stderr, "[bfmmm] note: kernel attribute setup reported %s\n", hipGetErrorString(e0)); }
   bfmmm_handle* h = new bfmmm_handle();
   h->cfg = *cfg;
@@ -284,6 +287,42 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   return 0;
 }
 
+extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int covariance_adj) {
+  if (!h || !X) return fail("bfmmm_set_covariates: null argument");
+  if (D < 1 || D > 8) return fail("bfmmm_set_covariates: the number of covariates must be between 1 and 8 in this build");
+  if (h->c.d.D != 0) return fail("bfmmm_set_covariates: covariates are already set");
+  HIPCHK(hipSetDevice(h->device));
+  Ctx& c = h->c;
+  Dims& d = c.d;
+  const size_t n = d.n, K = d.K, P = d.P, M = d.M, T = (size_t)h->T;
+  d.D = D;
+  c.covariance_adj = covariance_adj ? 1 : 0;
+  c.A2 = (int)(K * D + (covariance_adj ? K * M * D : 0));
+  c.NB2 = 16;
+  c.NBS = c.nblk_curve;
+  double* Xd;
+  if (dalloc(h, &Xd, n * D)) return 1;
+  HIPCHK(copy_sync(h, Xd, X, sizeof(double) * n * D, hipMemcpyHostToDevice));
+  c.X = Xd;
+  if (dalloc(h, &c.thetaX, K * (M + 1) * D * P) || dalloc(h, &c.tau_eta, K * D) || dalloc(h, &c.gamma_xi, K * P * D * M) ||
+      dalloc(h, &c.delta_xi, K * M * D) || dalloc(h, &c.A_xi, K * 2 * D) || dalloc(h, &c.stil, n * P) ||
+      dalloc(h, &c.yyp_part, (size_t)c.nblk_curve) || dalloc(h, &c.cfull, n * P) || dalloc(h, &c.gfull, n * P) ||
+      dalloc(h, &c.w2_part, (size_t)c.A2 * c.NB2 * d.LG) || dalloc(h, &c.H2aa, (size_t)c.A2 * d.LG) ||
+      dalloc(h, &c.C2, (size_t)c.A2 * P * P) || dalloc(h, &c.Lz2, (size_t)c.A2 * P) ||
+      dalloc(h, &c.step_part, (size_t)c.nblk_curve * P) || dalloc(h, &c.delta_cur, P + 2) ||
+      dalloc(h, &c.c_eta, T * P * D * K) || dalloc(h, &c.c_xi, T * K * P * D * M) || dalloc(h, &c.c_tau_eta, T * K * D) ||
+      dalloc(h, &c.c_gamma_xi, T * K * P * D * M) || dalloc(h, &c.c_delta_xi, T * K * M * D) || dalloc(h, &c.c_A_xi, T * K * 2 * D))
+    return 1;
+  // neutral state: eta = xi = 0, tau_eta = gamma_xi = delta_xi = A_xi = 1 (BFMMM.h:3705-3722, 3896-3915)
+  std::vector<double> ones(std::max({K * D, K * P * D * M, K * M * D, K * 2 * D}), 1.0);
+  HIPCHK(copy_sync(h, c.tau_eta, ones.data(), sizeof(double) * K * D, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, c.gamma_xi, ones.data(), sizeof(double) * K * P * D * M, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, c.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
+  HIPCHK(copy_sync(h, c.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
+  if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  return 0;
+}
+
 extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
@@ -357,11 +396,33 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
     HIPCHK(copy_sync(h, h->c.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
     return 0;
   }
+  const int D = d.D;
+  if ((s == "eta" || s == "xi") && D > 0) {
+    std::vector<double> tx((size_t)K * (M + 1) * D * P);
+    HIPCHK(copy_sync(h, tx.data(), h->c.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
+    if (s == "eta") {        // P x D x K
+      if (need((int64_t)P * D * K)) return 1;
+      for (int k = 0; k < K; ++k)
+        for (int dd = 0; dd < D; ++dd)
+          for (int p = 0; p < P; ++p) tx[((size_t)(k * (M + 1)) * D + dd) * P + p] = v[p + (size_t)P * (dd + (size_t)D * k)];
+    } else {                 // K arrays P x D x M
+      if (need((int64_t)K * P * D * M)) return 1;
+      for (int k = 0; k < K; ++k)
+        for (int m = 0; m < M; ++m)
+          for (int dd = 0; dd < D; ++dd)
+            for (int p = 0; p < P; ++p)
+              tx[((size_t)(k * (M + 1) + m + 1) * D + dd) * P + p] = v[(size_t)k * P * D * M + p + (size_t)P * (dd + (size_t)D * m)];
+    }
+    HIPCHK(copy_sync(h, h->c.thetaX, tx.data(), sizeof(double) * tx.size(), hipMemcpyHostToDevice));
+    return 0;
+  }
   struct Arr { const char* nm; double* p; int64_t len; };
   const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
-                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M}};
+                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M},
+                      {"tau_eta", h->c.tau_eta, (int64_t)K * D}, {"gamma_xi", h->c.gamma_xi, (int64_t)K * P * D * M},
+                      {"delta_xi", h->c.delta_xi, (int64_t)K * M * D}, {"A_xi", h->c.A_xi, (int64_t)K * 2 * D}};
   for (const Arr& a : arrs)
-    if (s == a.nm) {
+    if (s == a.nm && a.p) {
       if (need(a.len)) return 1;
       HIPCHK(copy_sync(h, a.p, v, sizeof(double) * (size_t)a.len, hipMemcpyHostToDevice));
       return 0;
@@ -399,11 +460,32 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
     }
     return 0;
   }
+  const int D = d.D;
+  if ((s == "eta" || s == "xi") && D > 0) {
+    std::vector<double> tx((size_t)K * (M + 1) * D * P);
+    HIPCHK(copy_sync(h, tx.data(), h->c.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
+    if (s == "eta") {
+      if (need((int64_t)P * D * K)) return 1;
+      for (int k = 0; k < K; ++k)
+        for (int dd = 0; dd < D; ++dd)
+          for (int p = 0; p < P; ++p) out[p + (size_t)P * (dd + (size_t)D * k)] = tx[((size_t)(k * (M + 1)) * D + dd) * P + p];
+    } else {
+      if (need((int64_t)K * P * D * M)) return 1;
+      for (int k = 0; k < K; ++k)
+        for (int m = 0; m < M; ++m)
+          for (int dd = 0; dd < D; ++dd)
+            for (int p = 0; p < P; ++p)
+              out[(size_t)k * P * D * M + p + (size_t)P * (dd + (size_t)D * m)] = tx[((size_t)(k * (M + 1) + m + 1) * D + dd) * P + p];
+    }
+    return 0;
+  }
   struct Arr { const char* nm; double* p; int64_t len; };
   const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
-                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M}};
+                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M},
+                      {"tau_eta", h->c.tau_eta, (int64_t)K * D}, {"gamma_xi", h->c.gamma_xi, (int64_t)K * P * D * M},
+                      {"delta_xi", h->c.delta_xi, (int64_t)K * M * D}, {"A_xi", h->c.A_xi, (int64_t)K * 2 * D}};
   for (const Arr& a : arrs)
-    if (s == a.nm) {
+    if (s == a.nm && a.p) {
       if (need(a.len)) return 1;
       HIPCHK(copy_sync(h, out, a.p, sizeof(double) * (size_t)a.len, hipMemcpyDeviceToHost));
       return 0;
@@ -472,7 +554,7 @@ struct Plan {
 
 static Plan make_plan(uint32_t mask, int MD) {
   Plan p;
-  p.z = (mask & (U_Z | U_PI | U_ALPHA3)) != 0;
+  p.z = (mask & (U_Z | U_PI | U_ALPHA3)) != 0;   // (forced on by the caller for covariate-adjusted models: s~_i)
   p.z_update = (mask & U_Z) ? 1 : 0;
   p.pg = (mask & (U_PHI | U_NU | U_SIGMA)) != 0;
   p.factor = true;   // k_factor prepares r = t - H theta for the sweep and draws job_hyper's variates
@@ -502,6 +584,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
   launch_curve(c, 1, p.chi ? (p.chi_update ? 2 : 1) : 0, st);
+  if (c.d.D > 0) launch_cov_block(c, st);      // eta, tau_eta, Xi, delta_xi, A_xi, gamma_xi (+ residual sums)
   mark();
   launch_loglik(c, p.use_rss_part, 0, st);
   mark();
@@ -519,11 +602,13 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   int NTG, NKS, KS;
   pg_geometry(c.d, NTG, NKS, KS);
   if ((size_t)NKS * c.d.NT * 256 > h->pg_part_doubles) return fail("bfmmm_run: internal workspace too small");
-  const Plan plan = make_plan(mask, MD);
+  Plan plan = make_plan(mask, MD);
+  if (c.d.D > 0) { plan.z = true; plan.chi = true; plan.use_rss_part = 1; }
   h->last_md = MD;
   Dyn dyn;
   if (dyn_get(h, dyn)) return 1;
   dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = 0; dyn.beta = beta; dyn.status = 0;
+  dyn.pend_dir = -1;
   if (dyn_put(h, dyn)) return 1;
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
   HIPCHK(hipEventRecord(h->ev0, h->st));
@@ -586,10 +671,13 @@ extern "C" int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, d
   const Arr arrs[] = {{"nu", c.c_nu, K * P}, {"chi", c.c_chi, n * M}, {"Z", c.c_Z, n * K}, {"pi", c.c_pi, K},
                       {"alpha_3", c.c_alpha3, 1}, {"delta", c.c_delta, K * M}, {"A", c.c_A, K * 2},
                       {"sigma_sq", c.c_sigma, 1}, {"gamma", c.c_gamma, K * P * M}, {"Phi", c.c_Phi, K * P * M},
-                      {"loglik", c.c_loglik, 1}};
+                      {"loglik", c.c_loglik, 1},
+                      {"eta", c.c_eta, P * d.D * K}, {"xi", c.c_xi, K * P * d.D * M}, {"tau_eta", c.c_tau_eta, K * d.D},
+                      {"gamma_xi", c.c_gamma_xi, K * P * d.D * M}, {"delta_xi", c.c_delta_xi, K * M * d.D},
+                      {"A_xi", c.c_A_xi, K * 2 * d.D}};
   HIPCHK(hipStreamSynchronize(h->st));
   for (const Arr& a : arrs)
-    if (s == a.nm) {
+    if (s == a.nm && a.p) {
       const int64_t want = a.len * n_slots;
       if (capacity < want) return fail("bfmmm_get_chain(" + s + "): buffer too small");
       HIPCHK(copy_sync(h, out, a.p, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost));

@@ -84,17 +84,22 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
   const Dims& d = c.d;
-  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
+  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD, D = d.D;
   const int nth = K * (M + 1) * P;
+  const int NR = K * (M + 1);                        // rows of the effective-parameter tile (D > 0)
   double* sTh = smem;
-  double* sLog = sTh + nth;                          // GPB*KMAX
+  double* sThX = sTh + nth;                          // D > 0: thetaX, K*(M+1)*D*P
+  double* sLog = sThX + (size_t)nth * D;             // GPB*KMAX
+  double* sYp = sLog + GPB * KMAX;                   // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int per_group = (2 * K + 1) * T::STR + MMAX + 32;
-  double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
-  T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};
-  double* sChi = gbase + (2 * K + 1) * T::STR;
+  const int per_group = (2 * K + 3) * T::STR + MMAX + 32 + (D > 0 ? NR * T::STR : 0);
+  double* gbase = sYp + GPB + (size_t)grp * per_group;
+  T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
+  double* sChi = gbase + (2 * K + 3) * T::STR;
   double* sRes = sChi + MMAX;
+  T tE{sRes + 32};                                   // D > 0: effective nu / phi of this curve
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
+  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
@@ -103,25 +108,55 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
   Curve<BW, LPC> cv;
   if (valid) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
-    tU.zero_pads(2 * K + 1, lp);
+    tU.zero_pads(2 * K + 3, lp);
+    if (D > 0) tE.zero_pads(NR, lp);
     if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
     tS.row(0)[lp] = cv.s;
   }
   __syncthreads();
+  // parameter rows seen by this curve: theta itself, or theta + sum_d x_id thetaX (covariate adjustment)
+  const double* thb = sTh + lp;
+  int ths = P;
+  if (valid && D > 0) {
+    double xv[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) xv[dd] = (dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
+    for (int r = 0; r < NR; ++r) {
+      double v = 0.0;
+      if (act) {
+        v = sTh[r * P + lp];
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd)
+          if (dd < D) v += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
+      }
+      tE.row(r)[lp] = v;
+    }
+    thb = tE.row(0) + lp;
+    ths = T::STR;
+  }
   double logz_mine = 0.0;
   if (valid) {
     double Zold[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
-    for (int k = 0; k < K; ++k) {
-      double v = 0.0;
-      if (act) {
-        const double* th = sTh + (size_t)k * (M + 1) * P;
-        v = th[lp];
+    double ucov[KMAX];                 // covariate part of u_k (D > 0)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      double v = 0.0, vb = 0.0;
+      if (k < K && act) {
+        const double* th = thb + (size_t)k * (M + 1) * ths;
+        v = th[0];
         if (MD > 1)
-          for (int m = 0; m < M; ++m) v += sChi[m] * th[(m + 1) * P + lp];
+          for (int m = 0; m < M; ++m) v += sChi[m] * th[(m + 1) * ths];
+        if (D > 0) {
+          const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
+          vb = tb[0];
+          if (MD > 1)
+            for (int m = 0; m < M; ++m) vb += sChi[m] * tb[(m + 1) * P];
+        }
       }
-      tU.row(k)[lp] = v;
+      if (k < K) tU.row(k)[lp] = v;
+      ucov[k] = v - vb;
     }
     __builtin_amdgcn_wave_barrier();
     for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
@@ -229,6 +264,22 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
       if (k < K && lp == k) logz_mine = log(Zfin[k]);
+    if (D > 0) {
+      // offset seen by the Phi / nu block: o = sum_k Z_k ucov_k;  s~ = s - G o;  yy~ = yy - 2 o's + o'G o
+      double o = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) o += Zfin[k] * ucov[k];
+      tS.row(1)[lp] = o;
+      __builtin_amdgcn_wave_barrier();
+      const double Go = cv.matvec(tS.row(1), lp);
+      tS.row(2)[lp] = Go;
+      if (act) c.stil[(size_t)i * P + lp] = cv.s - Go;
+      __builtin_amdgcn_wave_barrier();
+      if (lp == 0) sYp[grp] = cv.yy - 2.0 * dotP(tS.row(1), tS.row(0), P) + dotP(tS.row(1), tS.row(2), P);
+    }
+  } else if (lp == 0) {
+    sYp[grp] = 0.0;
   }
   // block partial of sum_i log Z_ik, fixed order over the groups of this block
   if (lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
@@ -237,6 +288,11 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
     double acc = 0.0;
     for (int g = 0; g < GPB; ++g) acc += sLog[g * KMAX + threadIdx.x];
     c.logz_part[(size_t)blockIdx.x * K + threadIdx.x] = acc;
+  }
+  if (D > 0 && threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int g = 0; g < GPB; ++g) acc += sYp[g];
+    c.yyp_part[blockIdx.x] = acc;
   }
 }
 
@@ -258,20 +314,24 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
   const Dims& d = c.d;
-  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
+  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD, D = d.D;
   const int nth = K * (M + 1) * P;
+  const int NR = K * (M + 1);
   const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
   const int ntask = Mu * (Mu + 1) / 2 + Mu + 2;
   double* sTh = smem;
-  double* sRss = sTh + nth;                         // GPB
+  double* sThX = sTh + nth;
+  double* sRss = sThX + (size_t)nth * D;            // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int per_group = (2 * M + 3) * T::STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2);
+  const int per_group = (2 * M + 3) * T::STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2) + (D > 0 ? NR * T::STR : 0);
   double* gbase = sRss + GPB + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + M * T::STR}, tX{gbase + 2 * M * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
   double* sChi = gbase + (2 * M + 3) * T::STR;
   double* sZn = sChi + MMAX;
   double* sRes = sZn + MMAX;
+  T tE{sRes + (MMAX * (MMAX + 1) / 2 + MMAX + 2)};
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
+  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blk * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
@@ -281,10 +341,30 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   if (valid) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
     tU.zero_pads(2 * M + 3, lp);
+    if (D > 0) tE.zero_pads(NR, lp);
     if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
     tX.row(2)[lp] = cv.s;
   }
   __syncthreads();
+  const double* thb = sTh + lp;
+  int ths = P;
+  if (valid && D > 0) {
+    double xv[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) xv[dd] = (dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
+    for (int r = 0; r < NR; ++r) {
+      double v = 0.0;
+      if (act) {
+        v = sTh[r * P + lp];
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd)
+          if (dd < D) v += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
+      }
+      tE.row(r)[lp] = v;
+    }
+    thb = tE.row(0) + lp;
+    ths = T::STR;
+  }
   double rss = 0.0;
   if (valid) {
     double Zi[KMAX];
@@ -295,7 +375,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     if (act) {
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
-        if (k < K) cf += Zi[k] * sTh[(size_t)k * (M + 1) * P + lp];
+        if (k < K) cf += Zi[k] * thb[(size_t)k * (M + 1) * ths];
     }
     if (MD > 1) {
       for (int m = 0; m < M; ++m) {
@@ -303,7 +383,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
         if (act) {
 #pragma unroll
           for (int k = 0; k < KMAX; ++k)
-            if (k < K) um += Zi[k] * sTh[((size_t)k * (M + 1) + m + 1) * P + lp];
+            if (k < K) um += Zi[k] * thb[((size_t)k * (M + 1) + m + 1) * ths];
         }
         if (m < Mu) tU.row(m)[lp] = um;
         cf += sChi[m] * um;
@@ -370,6 +450,17 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
           for (int m2 = 0; m2 < MMAX; ++m2)
             if (m2 < M) rss += dl[m] * dl[m2] * sRes[tri_index(M, min(m, m2), max(m, m2))];
         }
+      if (D > 0 && act) {      // the eta / Xi steps start from the updated coefficient c_i and g_i = G_i c_i
+        double cfin = tX.row(0)[lp], gfin = cv.s - tX.row(1)[lp];
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m)
+          if (m < M) { cfin += dl[m] * tU.row(m)[lp]; gfin += dl[m] * tG.row(m)[lp]; }
+        c.cfull[(size_t)i * P + lp] = cfin;
+        c.gfull[(size_t)i * P + lp] = gfin;
+      }
+    } else if (D > 0 && act) {
+      c.cfull[(size_t)i * P + lp] = tX.row(0)[lp];
+      c.gfull[(size_t)i * P + lp] = cv.s - tX.row(1)[lp];
     }
   }
   if (lp == 0) sRss[grp] = rss;
@@ -389,10 +480,12 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int nblk = (c.d.n + GPB - 1) / GPB;
   const int K = c.d.K, M = c.d.M;
   const int STR = LPC + 2 * BW;
+  const int D = c.d.D;
   const size_t nth = (size_t)K * (M + 1) * c.d.P;
+  const size_t tileE = (D > 0) ? (size_t)K * (M + 1) * STR : 0;
   size_t lds;
-  if (which == 0) lds = nth + GPB * KMAX + (size_t)GPB * ((2 * K + 1) * STR + MMAX + 32);
-  else lds = nth + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2));
+  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
+  else lds = nth * (1 + D) + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2) + tileE);
   lds = (lds + 8) * sizeof(double);
   if (LPC == 32) {
     if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);

@@ -21,6 +21,7 @@
 #include "model.hpp"
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
+#include "factor_core.hpp"
 
 #include <algorithm>
 
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
       for (int u = 0; u < UN; ++u) {
         const int q = min(base + tid + 256 * u, nB - 1);
         const int il = q / ncol, cc = q - il * ncol, i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
-        v[u] = c.rec[(size_t)i * d.LREC + col];
+        // covariate-adjusted models contract against s~_i = s_i - G_i o_i (k_curve_z) instead of s_i
+        v[u] = (single && d.D > 0) ? c.stil[(size_t)i * d.P + min(cc, d.P - 1)] : c.rec[(size_t)i * d.LREC + col];
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -322,61 +324,8 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
   }
   __syncthreads();
-  const int bw = d.BWP;
-  bool bad = false;
-  if (tid < 64) {
-    // reverse Cholesky Prec = U U', one wave, LDS traffic is wave-ordered
-    for (int k = P - 1; k >= 0; --k) {
-      const int jhi = min(k + bw, P - 1);
-      double dkk = S[k + PP * k];
-      for (int jj = k + 1; jj <= jhi; ++jj) { const double u = S[k + PP * jj]; dkk -= u * u; }
-      if (!(dkk > 0.0)) bad = true;
-      const double ukk = sqrt(dkk);
-      const int i = k - 1 - tid;
-      double uik = 0.0;
-      if (tid < bw && i >= 0) {
-        double acc = S[i + PP * k];
-        const int j2 = min(i + bw, P - 1);
-        for (int jj = k + 1; jj <= j2; ++jj) acc -= S[i + PP * jj] * S[k + PP * jj];
-        uik = acc / ukk;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (tid == 0) S[k + PP * k] = ukk;
-      if (tid < bw && i >= 0) S[i + PP * k] = uik;
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-  if (tid < P) {
-    // column c of X = U^-1 by back substitution (banded U)
-    const int cc = tid;
-    X[cc * PP + cc] = 1.0 / S[cc + PP * cc];
-    for (int i = cc - 1; i >= 0; --i) {
-      double acc = 0.0;
-      const int j2 = min(i + bw, cc);
-      for (int jj = i + 1; jj <= j2; ++jj) acc += S[i + PP * jj] * X[jj * PP + cc];
-      X[i * PP + cc] = -acc / S[i + PP * i];
-    }
-  }
-  __syncthreads();
-  // L = X' (lower), C = L L', L z
-  double* Cg = c.Cmat + (size_t)a * P * P;
-  double* Lg = c.Lmat + (size_t)a * P * P;
-  for (int e = tid; e < PP * PP; e += 256) {
-    const int p = e & (PP - 1), q = e / PP;
-    if (p < P && q < P) {
-      const int kmax = min(p, q);
-      double acc = 0.0;
-      for (int k = 0; k <= kmax; ++k) acc += X[k * PP + p] * X[k * PP + q];
-      Cg[p + (size_t)P * q] = acc;
-      Lg[p + (size_t)P * q] = (q <= p) ? X[q * PP + p] : 0.0;
-    }
-  }
-  if (tid < P) {
-    double acc = 0.0;
-    for (int q = 0; q <= tid; ++q) acc += X[q * PP + tid] * zv[q];
-    c.Lz[a * P + tid] = acc;
-  }
+  const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
+                                   c.Lz + (size_t)a * P, tid);
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 
@@ -524,11 +473,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
   if (mask & U_SIGMA) {
     // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
+    // (covariate-adjusted: YY is replaced by sum_i yy_i - 2 o_i's_i + o_i'G_i o_i, block partials of k_curve_z)
     double acc = 0.0;
     for (int e = tid; e < AP; e += SW_THREADS) {
       const int b = e / P, p = e - b * P;
       acc += th[b * PS + BW + p] * (tv[e] + r[e]);
     }
+    if (d.D > 0)
+      for (int e = tid; e < c.nblk_curve; e += SW_THREADS) acc -= c.yyp_part[e];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
@@ -536,7 +488,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     if (tid == SW_THREADS - 1) {
       double q = 0.0;
       for (int w = 0; w < SW_THREADS / 64; ++w) q += red[w];
-      const double rss = c.YY - q;
+      const double rss = (d.D > 0) ? -q : (c.YY - q);
       const bool tempered = (dyn->tt_step != 0);
       const double b = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
       const double s2 = 1.0 / (sig_g * (1.0 / b));

@@ -44,6 +44,8 @@ struct Dyn {
   uint32_t status;      // sticky error bits (1: precision matrix not positive definite)
   uint32_t iter_hyper;  // snapshot of iter / slot taken by k_sweep for the off-critical-path k_hyper,
   uint32_t slot_hyper;  //   which may still be running when k_loglik advances the counters
+  int32_t pend_dir;     // eta / Xi direction whose delta_cur has not been applied to c_i, g_i yet (-1: none)
+  uint32_t pad0_;
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
   double alpha3;
@@ -104,6 +106,29 @@ struct Ctx {
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty
+  // ---- covariate adjustment (D > 0): eta_j[:,d] is direction (j, 0, d), xi_jm[:,d] is (j, m+1, d), weight
+  //      w = Z_ij * chit_{i,mt} * X_id.  The Phi / nu block sees them as a per-curve offset o_i; they are
+  //      sampled by the sequential "direct" steps of kernels_cov.hip.
+  const double* X;              // n x D col-major covariates
+  double* thetaX;               // [K*(M+1)*D][P], row ax = (j*(M+1) + mt)*D + d
+  double* tau_eta;              // K x D
+  double* gamma_xi;             // K cubes P x D x M (reference layout of gamma_xi(iter, k))
+  double* delta_xi;             // K x M x D
+  double* A_xi;                 // K x 2 x D
+  double* stil;                 // n x P   s_i - G_i o_i  (o_i = covariate part of the fitted coefficient)
+  double* yyp_part;             // nblk_curve  partial sums of yy_i - 2 o_i's_i + o_i'G_i o_i
+  double* cfull;                // n x P   c_i (full fitted coefficient), maintained during the eta / Xi steps
+  double* gfull;                // n x P   G_i c_i
+  double* w2_part;              // A2 x NB2 x LG   partial sums of w^2 G_i
+  double* H2aa;                 // A2 x LG         sum_i w^2 G_i
+  double* C2;                   // A2 x P x P
+  double* Lz2;                  // A2 x P
+  double* step_part;            // NBS x P         partial sums of w (s_i - g_i) of the current step
+  double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
+  int covariance_adj;           // Xi block on (BFMMM.h:4602 vs :4067)
+  int A2;                       // eta / xi directions: K*D (+ K*M*D)
+  int NB2, NBS;
+  double *c_eta, *c_xi, *c_tau_eta, *c_gamma_xi, *c_delta_xi, *c_A_xi;
   double YY;                    // sum_i yy_i
   // chain storage (slot-major, each slot laid out exactly as the reference returns it)
   double *c_nu, *c_chi, *c_Z, *c_pi, *c_alpha3, *c_delta, *c_A, *c_sigma, *c_tau, *c_gamma, *c_Phi, *c_loglik;

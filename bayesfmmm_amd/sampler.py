@@ -10,7 +10,10 @@ import numpy as np
 from . import _lib
 
 U_Z, U_PI, U_ALPHA3, U_PHI, U_DELTA, U_A, U_GAMMA, U_NU, U_TAU, U_SIGMA, U_CHI = (1 << i for i in range(11))
+U_ETA, U_TAU_ETA, U_XI, U_DELTA_XI, U_A_XI, U_GAMMA_XI = (1 << i for i in range(11, 17))
 U_LOGLIK = 1 << 17
+COV_MEAN = U_ETA | U_TAU_ETA
+COV_XI = U_XI | U_DELTA_XI | U_A_XI | U_GAMMA_XI
 SWEEP_NU_Z = U_Z | U_PI | U_ALPHA3 | U_NU | U_TAU | U_SIGMA | U_LOGLIK
 SWEEP_THETA = U_PHI | U_DELTA | U_A | U_GAMMA | U_TAU | U_SIGMA | U_CHI | U_LOGLIK
 SWEEP_WARM = SWEEP_NU_Z | SWEEP_THETA
@@ -61,6 +64,14 @@ class Sampler:
             self.offsets = None
             _lib.check(self.lib.bfmmm_create(C.byref(cfg), device, _dp(Ym), None, None, None, None, C.byref(self.h)))
         self.n, self.K, self.M, self.T = cfg.n_funct, cfg.K, cfg.n_eigen, cfg.tot_mcmc_iters
+        self.D = 0
+
+    def set_covariates(self, X, covariance_adj=False):
+        """X: (n, D) covariate matrix (the `X` argument of the reference's entry points)."""
+        Xm = np.asfortranarray(X, dtype=np.float64)
+        assert Xm.shape[0] == self.n
+        _lib.check(self.lib.bfmmm_set_covariates(self.h, _dp(Xm), Xm.shape[1], int(covariance_adj)))
+        self.D = Xm.shape[1]
 
     def close(self):
         if self.h:
@@ -78,7 +89,9 @@ class Sampler:
         n, K, P, M = self.n, self.K, self.P, self.M
         return {"nu": (K, P), "Phi": (K, P, M), "chi": (n, M), "Z": (n, K), "pi": (K,), "alpha_3": (1,),
                 "delta": (K, M), "A": (K, 2), "gamma": (K, P, M), "tau": (K,), "sigma_sq": (1,),
-                "loglik": (1,), "status": (1,), "stamps": (16,)}[name]
+                "loglik": (1,), "status": (1,), "stamps": (16,),
+                "eta": (P, self.D, K), "xi": (P, self.D, M, K), "gamma_xi": (P, self.D, M, K),
+                "tau_eta": (K, self.D), "delta_xi": (K, M, self.D), "A_xi": (K, 2, self.D)}[name]
 
     def set_state(self, **kw):
         for name, v in kw.items():
@@ -101,7 +114,9 @@ class Sampler:
         shp = {"nu": (self.K, self.P, T), "chi": (self.n, self.M, T), "Z": (self.n, self.K, T), "pi": (self.K, T),
                "alpha_3": (T,), "delta": (self.K, self.M, T), "A": (self.K, 2, T), "sigma_sq": (T,),
                "tau": (T, self.K), "gamma": (self.K, self.P, self.M, T), "Phi": (self.K, self.P, self.M, T),
-               "loglik": (T,)}[name]
+               "loglik": (T,), "eta": (self.P, self.D, self.K, T), "xi": (self.P, self.D, self.M, self.K, T),
+               "gamma_xi": (self.P, self.D, self.M, self.K, T), "tau_eta": (self.K, self.D, T),
+               "delta_xi": (self.K, self.M, self.D, T), "A_xi": (self.K, 2, self.D, T)}[name]
         out = np.zeros(shp, order="F")
         _lib.check(self.lib.bfmmm_get_chain(self.h, name.encode(), T, _dp(out), out.size))
         return out

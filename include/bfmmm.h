@@ -39,12 +39,17 @@ enum { BFMMM_MODEL_FUNCTIONAL = 0, BFMMM_MODEL_MULTIVARIATE = 1 };
 enum {
   BFMMM_U_Z = 1 << 0, BFMMM_U_PI = 1 << 1, BFMMM_U_ALPHA3 = 1 << 2, BFMMM_U_PHI = 1 << 3,
   BFMMM_U_DELTA = 1 << 4, BFMMM_U_A = 1 << 5, BFMMM_U_GAMMA = 1 << 6, BFMMM_U_NU = 1 << 7,
-  BFMMM_U_TAU = 1 << 8, BFMMM_U_SIGMA = 1 << 9, BFMMM_U_CHI = 1 << 10, BFMMM_U_LOGLIK = 1 << 17
+  BFMMM_U_TAU = 1 << 8, BFMMM_U_SIGMA = 1 << 9, BFMMM_U_CHI = 1 << 10,
+  BFMMM_U_ETA = 1 << 11, BFMMM_U_TAU_ETA = 1 << 12, BFMMM_U_XI = 1 << 13, BFMMM_U_DELTA_XI = 1 << 14,
+  BFMMM_U_A_XI = 1 << 15, BFMMM_U_GAMMA_XI = 1 << 16, BFMMM_U_LOGLIK = 1 << 17
 };
 /* sweeps of the three stages */
 #define BFMMM_SWEEP_NU_Z  (BFMMM_U_Z | BFMMM_U_PI | BFMMM_U_ALPHA3 | BFMMM_U_NU | BFMMM_U_TAU | BFMMM_U_SIGMA | BFMMM_U_LOGLIK)
 #define BFMMM_SWEEP_THETA (BFMMM_U_PHI | BFMMM_U_DELTA | BFMMM_U_A | BFMMM_U_GAMMA | BFMMM_U_TAU | BFMMM_U_SIGMA | BFMMM_U_CHI | BFMMM_U_LOGLIK)
 #define BFMMM_SWEEP_WARM  (BFMMM_SWEEP_NU_Z | BFMMM_SWEEP_THETA)
+/* covariate-adjusted drivers (BFMMM.h:3741-3780, 3944-4010, 4248-4312 / 4809-4894): the eta / Xi blocks run after chi */
+#define BFMMM_COV_MEAN (BFMMM_U_ETA | BFMMM_U_TAU_ETA)
+#define BFMMM_COV_XI   (BFMMM_U_XI | BFMMM_U_DELTA_XI | BFMMM_U_A_XI | BFMMM_U_GAMMA_XI)
 
 /* Hyper-parameters and sizes; field names follow the reference's argument names
  * (UserFunctions.cpp:166-193, 684-715, 1341-1378).  bfmmm_config_defaults() fills in the
@@ -79,6 +84,12 @@ void bfmmm_config_defaults(bfmmm_config* cfg);
 int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
                  const double* internal_knots, const double* boundary_knots, bfmmm_handle** out);
 void bfmmm_destroy(bfmmm_handle* h);
+
+/* Covariate adjustment (the `X` argument of the reference's entry points, UserFunctions.cpp:176): X is the
+ * n_funct x D column-major covariate matrix; covariance_adj != 0 enables the Xi block (BFMMM.h:4602 vs :4067).
+ * Call once, right after bfmmm_create.  Adds the state / chain names "eta" (P x D x K), "xi" and "gamma_xi"
+ * (K arrays P x D x M), "tau_eta" (K x D), "delta_xi" (K x M x D), "A_xi" (K x 2 x D). */
+int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int covariance_adj);
 
 /* Basis matrices "B" returned by the reference's entry points (UserFunctions.cpp:327): the rows of
  * all curves concatenated, each row P doubles (row-major: out[(offsets[i]+l)*P + p] = B_i(l,p)). */
