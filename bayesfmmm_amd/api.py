@@ -33,7 +33,8 @@ class EntryArgs(C.Structure):
                 ("alpha_0", C.c_double), ("beta_0", C.c_double), ("thinning_num", C.c_double), ("beta_N_t", C.c_double),
                 ("N_t", C.c_int32), ("n_temp_trans", C.c_int32), ("r_stored_iters", C.c_int32),
                 ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
-                ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32)]
+                ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32),
+                ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32)]
 
 
 ENTRY_SYMBOLS = {
@@ -137,8 +138,6 @@ class _Args:
 
     def __init__(self, entry, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
                  internal_knots, X, kw):
-        if X is not None:
-            raise NotImplementedError("covariate-adjusted models (X) are not implemented in this round")
         if len(Y) != n_funct or len(time) != n_funct:
             raise ValueError("'Y' and 'time' must have 'n_funct' elements")
         lib = _lib_entry()
@@ -157,6 +156,14 @@ class _Args:
         a.offsets = self.offsets.ctypes.data_as(c_int64_p)
         a.boundary_knots, a.internal_knots = self.bk.ctypes.data_as(c_double_p), self.ik.ctypes.data_as(c_double_p)
         self.P = len(self.ik) + basis_degree + 1
+        if X is not None:
+            self.X = np.asfortranarray(X, dtype=np.float64)
+            if self.X.shape[0] != n_funct:
+                raise _lib.BfmmmError("'X' must be have 'n_funct' number of rows")
+            a.X, a.D = self.X.ctypes.data_as(c_double_p), self.X.shape[1]
+            a.covariance_adj = int(bool(kw.pop("covariance_adj", False)))
+        else:
+            kw.pop("covariance_adj", None)
         c = kw.pop("c", None)
         if c is not None:
             self.c = np.ascontiguousarray(c, dtype=np.float64)
@@ -203,7 +210,7 @@ def BFMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_
     lib = _lib_entry()
     args = _Args(1, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
-    mt = {k: multiple_try[k] for k in ("Z", "nu")}
+    mt = {k: multiple_try[k] for k in ("Z", "nu") + (("eta",) if X is not None else ())}
     if group is not None:
         from . import parallel
         return parallel.multi_try(lambda: _call1(lib.bfmmm_BFMMM_Theta_est, args, mt), args, group)
@@ -218,8 +225,11 @@ def BFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen,
     lib = _lib_entry()
     args = _Args(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.burnin_prop = burnin_prop
-    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
-    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau") + (("eta", "tau_eta") if X is not None else ())}
+    te_names = ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")
+    if X is not None and args.a.covariance_adj:
+        te_names += ("xi", "gamma_xi", "delta_xi", "A_xi")
+    te = {k: theta_est[k] for k in te_names}
     return _call1(lib.bfmmm_BFMMM_warm_start, args, mt, te)
 
 

@@ -126,6 +126,9 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   if (a->c)
     for (int i = 0; i < a->K; ++i)
       if (a->c[i] <= 0) return efail("all elements of 'c' must be positive");
+  if (a->X && (a->D < 1 || a->D > 8)) return efail("the number of covariates (columns of 'X') must be between 1 and 8 in this build");
+  if (a->X && a->alpha_eta <= 0) return efail("'alpha_eta' must be positive");
+  if (a->X && a->beta_eta <= 0) return efail("'beta_eta' must be positive");
   if (a->K > 6) return efail("K larger than 6 is not supported by this build");
   if (a->chain_stride < 1 || a->chain_offset < 0) return efail("invalid chain_offset / chain_stride");
   return 0;
@@ -266,9 +269,30 @@ static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args*
   return 0;
 }
 
+static int attach_cov(bfmmm_handle* h, const bfmmm_entry_args* a) {
+  if (!a->X) return 0;
+  return bfmmm_set_covariates(h, a->X, a->D, a->covariance_adj);
+}
+
+// chain arrays of the covariate blocks, in the reference's shapes
+static int fetch_cov(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a, int T, bool with_xi, int extra_slot = 0) {
+  if (!a->X) return 0;
+  const int64_t K = a->K, M = a->n_eigen, D = a->D, P = dimP(a);
+  const int TT = T + extra_slot;
+  if (fetch(h, r, "eta", "eta", T, P * D * K, {P, D, K, TT}, extra_slot) ||
+      fetch(h, r, "tau_eta", "tau_eta", T, K * D, {K, D, TT}, extra_slot))
+    return 1;
+  if (!with_xi) return 0;
+  return fetch(h, r, "xi", "xi", T, K * P * D * M, {P, D, M, K, TT}, extra_slot) ||
+         fetch(h, r, "gamma_xi", "gamma_xi", T, K * P * D * M, {P, D, M, K, TT}, extra_slot) ||
+         fetch(h, r, "delta_xi", "delta_xi", T, K * M * D, {K, M, D, TT}, extra_slot) ||
+         fetch(h, r, "A_xi", "A_xi", T, K * 2 * D, {K, 2, D, TT}, extra_slot);
+}
+
 // ------------------------------------------------------------------------------------------------
 static int setup_nu_z(bfmmm_handle* h, int chain, const void* ctx) {
   const bfmmm_entry_args* a = (const bfmmm_entry_args*)ctx;
+  if (attach_cov(h, a)) return 1;                                // eta = 0, tau_eta = 1 (BFMMM.h:3705-3722)
   return bfmmm_init_state(h, 0, a->seed, (uint32_t)chain);      // BFMMM.h:1039-1071
 }
 
@@ -280,14 +304,16 @@ extern "C" int bfmmm_BFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_re
   bfmmm_config cfg;
   make_cfg(a, T, &cfg);
   ChainRun best;
-  if (run_multi_try(a, cfg, BFMMM_SWEEP_NU_Z, 1, setup_nu_z, a, &best)) return 1;
+  const uint32_t mask_nz = BFMMM_SWEEP_NU_Z | (a->X ? BFMMM_COV_MEAN : 0);      // BFMMM.h:3741-3780
+  if (run_multi_try(a, cfg, mask_nz, 1, setup_nu_z, a, &best)) return 1;
   bfmmm_result* r = bfmmm_result_create();
   int rc = fetch_basis(best.h, r, a, "B") || fetch(best.h, r, "nu", "nu", T, (int64_t)K * P, {K, P, T}) ||
            fetch(best.h, r, "pi", "pi", T, K, {K, T}) || fetch(best.h, r, "alpha_3", "alpha_3", T, 1, {T}) ||
            fetch(best.h, r, "A", "A", T, (int64_t)K * 2, {K, 2, T}) ||
            fetch(best.h, r, "delta", "delta", T, (int64_t)K * M, {K, M, T}) ||
            fetch(best.h, r, "sigma_sq", "sigma_sq", T, 1, {T}) || fetch_tau(best.h, r, T, K) ||
-           fetch(best.h, r, "Z", "Z", T, (int64_t)n * K, {n, K, T}) || fetch(best.h, r, "loglik", "loglik", T, 1, {T});
+           fetch(best.h, r, "Z", "Z", T, (int64_t)n * K, {n, K, T}) || fetch(best.h, r, "loglik", "loglik", T, 1, {T}) ||
+           fetch_cov(best.h, r, a, T, false);
   bfmmm_destroy(best.h);
   if (rc) { bfmmm_result_free(r); return 1; }
   put(r, "best_chain", {(double)best.chain}, {1});
@@ -299,12 +325,14 @@ extern "C" int bfmmm_BFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_re
 // ------------------------------------------------------------------------------------------------
 struct ThetaCtx {
   const bfmmm_entry_args* a;
-  std::vector<double> Z_est, nu_est;
+  std::vector<double> Z_est, nu_est, eta_est;
 };
 
 static int setup_theta(bfmmm_handle* h, int chain, const void* ctx) {
   const ThetaCtx* t = (const ThetaCtx*)ctx;
+  if (attach_cov(h, t->a)) return 1;
   if (bfmmm_init_state(h, 1, t->a->seed, (uint32_t)chain)) return 1;             // BFMMM.h:1210-1235
+  if (t->a->X && bfmmm_set_state(h, "eta", t->eta_est.data(), (int64_t)t->eta_est.size())) return 1;   // BFMMM.h:3936-3942
   if (bfmmm_set_state(h, "Z", t->Z_est.data(), (int64_t)t->Z_est.size())) return 1;   // BFMMM.h:1244-1250
   return bfmmm_set_state(h, "nu", t->nu_est.data(), (int64_t)t->nu_est.size());
 }
@@ -344,11 +372,23 @@ extern "C" int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_resu
   const int P = dimP(a);
   ThetaCtx tc;
   tc.a = a;
-  if (median_Z_nu(a, multiple_try, tc.Z_est, tc.nu_est, nullptr)) return 1;
+  int64_t n_nu = 0;
+  if (median_Z_nu(a, multiple_try, tc.Z_est, tc.nu_est, &n_nu)) return 1;
+  if (a->X) {   // eta_est: median over the same trailing slices (UserFunctions.cpp:1049-1054)
+    const double* es; int64_t ce;
+    if (bfmmm_result_get(multiple_try, "eta", &es, &ce, nullptr, nullptr)) return 1;
+    const int64_t len = (int64_t)P * a->D * K;
+    if (ce != len * n_nu) return efail("'multiple_try$eta' has the wrong shape");
+    const int64_t burn = (int64_t)std::round(n_nu * a->burnin_prop);
+    std::vector<double> buf;
+    tc.eta_est.resize((size_t)len);
+    for (int64_t e = 0; e < len; ++e) tc.eta_est[e] = tail_median(es, len, e, burn, n_nu, buf);
+  }
   bfmmm_config cfg;
   make_cfg(a, T, &cfg);
   ChainRun best;
-  if (run_multi_try(a, cfg, BFMMM_SWEEP_THETA, 0, setup_theta, &tc, &best)) return 1;
+  const uint32_t mask_th = BFMMM_SWEEP_THETA | (a->X ? (BFMMM_U_TAU_ETA | (a->covariance_adj ? BFMMM_COV_XI : 0)) : 0);   // BFMMM.h:3944-4010
+  if (run_multi_try(a, cfg, mask_th, 0, setup_theta, &tc, &best)) return 1;
   bfmmm_result* r = bfmmm_result_create();
   int rc = fetch_basis(best.h, r, a, "B") || fetch(best.h, r, "Z", "Z", T, (int64_t)n * K, {n, K, T}) ||
            fetch(best.h, r, "nu", "nu", T, (int64_t)K * P, {K, P, T}) ||
@@ -358,7 +398,7 @@ extern "C" int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_resu
            fetch(best.h, r, "sigma_sq", "sigma_sq", T, 1, {T}) || fetch_tau(best.h, r, T, K) ||
            fetch(best.h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, T}) ||
            fetch(best.h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, T}) ||
-           fetch(best.h, r, "loglik", "loglik", T, 1, {T});
+           fetch(best.h, r, "loglik", "loglik", T, 1, {T}) || fetch_cov(best.h, r, a, T, true);
   bfmmm_destroy(best.h);
   if (rc) { bfmmm_result_free(r); return 1; }
   put(r, "best_chain", {(double)best.chain}, {1});
@@ -422,18 +462,55 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   std::vector<double> delta_est = med_block(deltas, (int64_t)K * M), gamma_est = med_block(gammas, (int64_t)K * P * M),
                       Phi_est = med_block(Phis, (int64_t)K * P * M), A_est = med_block(As, (int64_t)K * 2),
                       chi_est = med_block(chis, (int64_t)n * M);
+  // covariate blocks: eta, tau_eta from stage 1; xi, gamma_xi, delta_xi, A_xi from stage 2 (UserFunctions.cpp:1893-1899, 1951-1960)
+  std::vector<double> eta_est, tau_eta_est, xi_est, gamma_xi_est, delta_xi_est, A_xi_est;
+  if (a->X) {
+    const int64_t D = a->D;
+    const double *es, *tes;
+    int64_t s_e, s_te;
+    if (get(mt, "eta", &es, (int64_t)P * D * K, &s_e) || get(mt, "tau_eta", &tes, (int64_t)K * D, &s_te)) return 1;
+    if (s_e != n_nu || s_te != n_nu) return efail("'multiple_try' arrays have inconsistent lengths");
+    auto med_nu = [&](const double* chain, int64_t len) {
+      std::vector<double> v((size_t)len);
+      for (int64_t e = 0; e < len; ++e) v[e] = tail_median(chain, len, e, burn_nu, n_nu, buf);
+      return v;
+    };
+    eta_est = med_nu(es, (int64_t)P * D * K);
+    tau_eta_est = med_nu(tes, (int64_t)K * D);
+    if (a->covariance_adj) {
+      const double *xs, *gxs, *dxs, *axs;
+      int64_t s1, s2, s3, s4;
+      if (get(te, "xi", &xs, (int64_t)K * P * D * M, &s1) || get(te, "gamma_xi", &gxs, (int64_t)K * P * D * M, &s2) ||
+          get(te, "delta_xi", &dxs, (int64_t)K * M * D, &s3) || get(te, "A_xi", &axs, (int64_t)K * 2 * D, &s4))
+        return 1;
+      if (s1 != n_Phi || s2 != n_Phi || s3 != n_Phi || s4 != n_Phi) return efail("'theta_est' arrays have inconsistent lengths");
+      xi_est = med_block(xs, (int64_t)K * P * D * M);
+      gamma_xi_est = med_block(gxs, (int64_t)K * P * D * M);
+      delta_xi_est = med_block(dxs, (int64_t)K * M * D);
+      A_xi_est = med_block(axs, (int64_t)K * 2 * D);
+    }
+  }
   // ---- one chain of the full sweep from the medians (BFMMM.h:1486-1498, 1500-1554) ----
   bfmmm_config cfg;
   make_cfg(a, T, &cfg);
   bfmmm_handle* h = nullptr;
   if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &h)) return efail_lib();
-  int rc = bfmmm_set_state(h, "Z", Z_est.data(), (int64_t)Z_est.size()) || bfmmm_set_state(h, "pi", pi_est.data(), K) ||
+  const uint32_t mask_ws = BFMMM_SWEEP_WARM | (a->X ? (BFMMM_COV_MEAN | (a->covariance_adj ? BFMMM_COV_XI : 0)) : 0);   // BFMMM.h:4248-4312 / 4809-4894
+  int rc = attach_cov(h, a) ||
+           (a->X && (bfmmm_set_state(h, "eta", eta_est.data(), (int64_t)eta_est.size()) ||
+                     bfmmm_set_state(h, "tau_eta", tau_eta_est.data(), (int64_t)tau_eta_est.size()))) ||
+           (a->X && a->covariance_adj &&
+            (bfmmm_set_state(h, "xi", xi_est.data(), (int64_t)xi_est.size()) ||
+             bfmmm_set_state(h, "gamma_xi", gamma_xi_est.data(), (int64_t)gamma_xi_est.size()) ||
+             bfmmm_set_state(h, "delta_xi", delta_xi_est.data(), (int64_t)delta_xi_est.size()) ||
+             bfmmm_set_state(h, "A_xi", A_xi_est.data(), (int64_t)A_xi_est.size()))) ||
+           bfmmm_set_state(h, "Z", Z_est.data(), (int64_t)Z_est.size()) || bfmmm_set_state(h, "pi", pi_est.data(), K) ||
            bfmmm_set_state(h, "alpha_3", &alpha_3_est, 1) || bfmmm_set_state(h, "delta", delta_est.data(), (int64_t)K * M) ||
            bfmmm_set_state(h, "gamma", gamma_est.data(), (int64_t)K * P * M) ||
            bfmmm_set_state(h, "Phi", Phi_est.data(), (int64_t)K * P * M) || bfmmm_set_state(h, "A", A_est.data(), (int64_t)K * 2) ||
            bfmmm_set_state(h, "nu", nu_est.data(), (int64_t)K * P) || bfmmm_set_state(h, "tau", tau_est.data(), K) ||
            bfmmm_set_state(h, "sigma_sq", &sigma_est, 1) || bfmmm_set_state(h, "chi", chi_est.data(), (int64_t)n * M) ||
-           bfmmm_run(h, BFMMM_SWEEP_WARM, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+           bfmmm_run(h, mask_ws, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
   if (rc) { efail_lib(); bfmmm_destroy(h); return 1; }
   // r_stored_iters defaults to tot_mcmc_iters + 1 slots (UserFunctions.cpp:1510-1541): slot T repeats slot T-1
   const int TT = T + 1;
@@ -444,7 +521,8 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
        fetch(h, r, "A", "A", T, (int64_t)K * 2, {K, 2, TT}, 1) || fetch(h, r, "delta", "delta", T, (int64_t)K * M, {K, M, TT}, 1) ||
        fetch(h, r, "sigma_sq", "sigma_sq", T, 1, {TT}, 1) || fetch_tau(h, r, T, K, 1) ||
        fetch(h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, TT}, 1) ||
-       fetch(h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, TT}, 1) || fetch(h, r, "loglik", "loglik", T, 1, {TT}, 1);
+       fetch(h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, TT}, 1) || fetch(h, r, "loglik", "loglik", T, 1, {TT}, 1) ||
+       fetch_cov(h, r, a, T, a->covariance_adj != 0, 1);
   bfmmm_destroy(h);
   if (rc) { bfmmm_result_free(r); return 1; }
   *out = r;

@@ -69,6 +69,13 @@ typedef struct {
    * (UserFunctions.cpp:4582); t, offsets and the knot arguments are ignored */
   int32_t model;
   int32_t P;
+  /* covariate adjustment: the `X` (n_funct x D, column-major) and `covariance_adj` arguments of the reference
+   * (UserFunctions.cpp:176, :715); NULL = no covariates.  Results then also carry "eta" (P x D x K x T),
+   * "tau_eta" (K x D x T) and, from Theta_est / warm_start, "xi" / "gamma_xi" (P x D x M x K x T), "delta_xi"
+   * (K x M x D x T), "A_xi" (K x 2 x D x T). */
+  const double* X;
+  int32_t D;
+  int32_t covariance_adj;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:

@@ -89,3 +89,26 @@ def test_multi_try_keeps_best_chain(example):
     assert multi["best_chain"] == int(np.argmax(scores))
     assert multi["best_score"] == max(scores)
     assert abs(multi["best_score"] - multi["loglik"][T - 99:].mean()) < 1e-9 * abs(multi["best_score"])
+
+
+@pytest.mark.parametrize("covariance_adj", [False, True])
+def test_three_stage_pipeline_covariate_adjusted(example, covariance_adj):
+    # second half of the reference's examples (man/BFMMM_warm_start.Rd "Covariate Adj"): X = matrix(rnorm(40), 40, 1)
+    from bayesfmmm_amd import api
+    e = example
+    T, n, K, P, M, D = 150, 40, 2, 7, 3, 1
+    X = np.random.default_rng(1).standard_normal((n, D))
+    common = (e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    est1 = api.BFMMM_Nu_Z_multiple_try(T, 1, K, *common, X=X, seed=3)
+    assert est1["eta"].shape == (P, D, K, T) and est1["tau_eta"].shape == (K, D, T)
+    assert np.abs(est1["eta"][..., -1]).max() > 0
+    est2 = api.BFMMM_Theta_est(T, 1, K, *common, est1, X=X, covariance_adj=covariance_adj, seed=4)
+    assert est2["xi"].shape == (P, D, M, K, T) and est2["delta_xi"].shape == (K, M, D, T)
+    assert (np.abs(est2["xi"]).max() > 0) == covariance_adj          # xi stays 0 under mean-only adjustment
+    burn = int(round(T * 0.8))
+    np.testing.assert_allclose(est2["eta"][..., 0], np.median(est1["eta"][..., burn:], axis=3), rtol=1e-13)
+    mcmc = api.BFMMM_warm_start(T, K, *common, est1, est2, X=X, covariance_adj=covariance_adj, seed=5)
+    assert mcmc["eta"].shape == (P, D, K, T + 1) and np.isfinite(mcmc["loglik"][:T]).all()
+    assert ("xi" in mcmc) == covariance_adj
+    with pytest.raises(Exception, match="'X' must be have 'n_funct' number of rows"):
+        api.BFMMM_Nu_Z_multiple_try(T, 1, K, *common, X=X[:10])
