@@ -78,3 +78,53 @@ def test_config4_multivariate_properties():
     ref = -n * (P // 2) * np.log(2 * np.pi * s2[t]) - rss / (2 * s2[t])
     assert abs(ll[t] - ref) < 1e-8 * abs(ref)
     assert 0.0005 < s2[t] < 0.002
+
+
+def test_config3_covariate_adjusted_properties():
+    # BASELINE.json configs[2]: config 2 + D = 5 covariates, mean and covariance adjustment (19-update sweep)
+    import time
+    import bayesfmmm_amd as bf
+    from bench import make_config2
+    S = bf.sampler
+    w = make_config2()
+    rng = np.random.default_rng(8)
+    n, K, P, M, D = w["n"], w["K"], w["P"], w["M"], 5
+    X = rng.standard_normal((n, D))
+    eta = 0.3 * rng.standard_normal((P, D, K))
+    xi = np.stack([0.1 * (M - m) / M * rng.standard_normal((P, D, K)) for m in range(M)], axis=2)   # P x D x M x K
+    B = w["B"][0]
+    st = w["state"]
+    coef = np.zeros((n, P))
+    for k in range(K):
+        u = st["nu"][k][None, :] + X @ eta[:, :, k].T
+        for m in range(M):
+            u = u + st["chi"][:, m:m + 1] * (st["Phi"][k, :, m][None, :] + X @ xi[:, :, m, k].T)
+        coef += st["Z"][:, k:k + 1] * u
+    Y = coef @ B.T + 0.1 * rng.standard_normal((n, B.shape[0]))
+    T = 6
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=3, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, [Y[i] for i in range(n)], w["t"], w["internal_knots"], w["boundary_knots"])
+    smp.set_covariates(X, True)
+    smp.set_state(**st)
+    smp.set_state(eta=eta, xi=xi)
+    mask = S.SWEEP_WARM | S.COV_MEAN | S.COV_XI
+    smp.run(mask, 2, seed=2)
+    t0 = time.perf_counter()
+    smp.run(mask, T - 2, first_iter=2, seed=2)
+    dt = (time.perf_counter() - t0) / (T - 2)
+    print(f"config 3: {dt * 1e3:.2f} ms per 19-update sweep")
+    t = T - 1
+    Z = smp.get_chain("Z")[:, :, t]; nu = smp.get_chain("nu")[:, :, t]; Phi = smp.get_chain("Phi")[..., t]
+    chi = smp.get_chain("chi")[:, :, t]; e_t = smp.get_chain("eta")[..., t]; x_t = smp.get_chain("xi")[..., t]
+    s2 = smp.get_chain("sigma_sq")[t]
+    coef = np.zeros((n, P))
+    for k in range(K):
+        u = nu[k][None, :] + X @ e_t[:, :, k].T
+        for m in range(M):
+            u = u + chi[:, m:m + 1] * (Phi[k, :, m][None, :] + X @ x_t[:, :, m, k].T)
+        coef += Z[:, k:k + 1] * u
+    rss = ((Y - coef @ B.T) ** 2).sum()
+    ref = -Y.size * (0.9189385332046727 + 0.5 * np.log(s2)) - rss / (2 * s2)
+    ll = smp.get_chain("loglik")[t]
+    assert abs(ll - ref) < 1e-8 * abs(ref)
+    assert 0.005 < s2 < 0.02
