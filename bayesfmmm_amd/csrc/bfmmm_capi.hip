@@ -31,11 +31,15 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 void launch_cov_block(const Ctx& c, hipStream_t st);
 void prepare_cov_kernels();
+#ifdef BFMMM_TIMELINE
+void fetch_wgtrace(unsigned long long* out);
+#endif
 }  // namespace bfmmm
 
 using namespace bfmmm;
 
 static thread_local std::string g_err;
+static constexpr int GRAPH_UNROLL = 10;
 static std::mutex g_capture_mutex;   // one stream capture at a time (samplers may run on several host threads)
 static int fail(const std::string& msg) { g_err = msg; return 1; }
 
@@ -65,7 +69,8 @@ struct bfmmm_handle {
   std::vector<void*> allocs;
   size_t pg_part_doubles = 0;
   // graph cache for the last (mask, md, seed, chain)
-  hipGraphExec_t gexec = nullptr;
+  hipGraphExec_t gexec = nullptr;      // one iteration
+  hipGraphExec_t gexecN = nullptr;     // GRAPH_UNROLL iterations (amortises the fixed cost of a graph launch)
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
@@ -122,11 +127,14 @@ static void set_md(Dims& d, int MD) {
 }
 
 static void pg_geometry(const Dims& d, int& NTG, int& NKS, int& KS) {
-  // k-slices of the pair-Gram contraction: about 32 of them, but never more curves per slice than fit a
-  // 96 KB LDS staging area (Z, chi and 16..CTS*16 record columns per curve)
-  const int ncol = std::max(16, d.CTS * 16);
-  const int ks_cap = std::max(4, (int)((96 * 1024) / (sizeof(double) * (size_t)(d.K + d.MD + ncol))) / 4 * 4);
-  NKS = std::max(1, std::min(32, d.n / 16));
+  // k-slices of the pair-Gram contraction.  LDS doubles per curve: the raw weight row, the record columns and,
+  // for the G workgroups, the pair-weight row (k_pair_gram); a workgroup never stages more than 96 KB.
+  const int row_g = (d.K + d.MD + 1) + 16 + (d.NZZ + d.NCC + 1);
+  const int row_s = (d.K + d.MD + 1) + d.CTS * 16;
+  const int ks_cap = std::max(4, (int)((96 * 1024) / (sizeof(double) * (size_t)std::max(row_g, row_s))) / 4 * 4);
+  // one workgroup per CU: (CTG + 2) column groups x NKS k-slices <= 256 whenever the LDS cap allows, so that
+  // every workgroup is resident at once (a 257th would wait a whole workgroup lifetime for a free CU)
+  NKS = std::max(1, std::min(256 / (d.CTG + 2), d.n / 16));
   KS = (d.n + NKS - 1) / NKS;
   KS = (KS + 3) / 4 * 4;
   KS = std::min(KS, ks_cap);
@@ -320,6 +328,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   HIPCHK(copy_sync(h, c.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
   HIPCHK(copy_sync(h, c.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
   if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
   return 0;
 }
 
@@ -328,6 +337,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+  if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -498,7 +508,10 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   else if (s == "sigma_sq") { if (need(1)) return 1; out[0] = dyn.sigma2; }
   else if (s == "loglik") { if (need(1)) return 1; out[0] = dyn.loglik; }
   else if (s == "status") { if (need(1)) return 1; out[0] = (double)dyn.status; }
-  else if (s == "stamps") { if (need(16)) return 1; for (int q = 0; q < 16; ++q) out[q] = (double)(dyn.stamps[q] - dyn.stamps[0]); }
+  else if (s == "stamps") { if (need(32)) return 1; for (int q = 0; q < 32; ++q) out[q] = (double)(dyn.stamps[q] % 100000000000ULL); }
+#ifdef BFMMM_TIMELINE
+  else if (s == "wgtrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_wgtrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
+#endif
   else return fail("bfmmm_get_state: unknown name '" + s + "'");
   return 0;
 }
@@ -630,16 +643,24 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
     const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
     if (!reuse) {
       if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-      hipGraph_t graph = nullptr;
+      if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
       std::lock_guard<std::mutex> lock(g_capture_mutex);
-      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
-      launch_iteration(h, c, plan, NKS, KS, h->st, nullptr);
-      HIPCHK(hipStreamEndCapture(h->st, &graph));
-      HIPCHK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int reps = pass == 0 ? 1 : GRAPH_UNROLL;
+        if (pass == 1 && n_iters < 2 * GRAPH_UNROLL) break;
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
+        for (int r = 0; r < reps; ++r) launch_iteration(h, c, plan, NKS, KS, h->st, nullptr);
+        HIPCHK(hipStreamEndCapture(h->st, &graph));
+        HIPCHK(hipGraphInstantiate(pass == 0 ? &h->gexec : &h->gexecN, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+      }
       h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
     }
-    for (int it = 0; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+    int it = 0;
+    if (h->gexecN)
+      for (; it + GRAPH_UNROLL <= n_iters; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
+    for (; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
   }
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);

@@ -78,13 +78,15 @@ __device__ inline double dotP(const double* a, const double* b, int P) {
 // sampled with Z held fixed).
 // LDS per group: U[K], GU[K], S (1 row), chi (MMAX), res (32)
 // ------------------------------------------------------------------------------------------------
-template <int BW, int LPC>
+template <int BW, int LPC, bool COV>
 __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
+  TIMELINE(c, 0);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
   const Dims& d = c.d;
-  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD, D = d.D;
+  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
+  const int D = COV ? d.D : 0;   // the covariate code is compiled only into the COV instantiation
   const int nth = K * (M + 1) * P;
   const int NR = K * (M + 1);                        // rows of the effective-parameter tile (D > 0)
   double* sTh = smem;
@@ -221,6 +223,17 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       for (int k = 0; k < KMAX; ++k) if (k < K) lB_new += __shfl(lgv, k, LPC);
       lB_old -= __shfl(lgv, K, LPC);
       lB_new -= __shfl(lgv, K + 1, LPC);
+      // log Z_old,k on lane k and log Z_new,k on lane KMAX + k: one log sequence for all 2K values
+      double lgz = 0.0;
+      {
+        double arg = 1.0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K && lp == k) arg = Zold[k];
+          if (k < K && lp == KMAX + k) arg = Znew[k];
+        }
+        lgz = log(arg);
+      }
       // quadratic form of the residual sum of squares in Z
       double q_old = cv.yy, q_new = cv.yy, pr_old = 0.0, pr_new = 0.0, dn = 0.0, dold = 0.0;
 #pragma unroll
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
               q_new += Znew[k] * Znew[k2] * qq;
             }
           }
-          const double lo = log(Zold[k]), ln = log(Znew[k]);
+          const double lo = __shfl(lgz, k, LPC), ln = __shfl(lgz, KMAX + k, LPC);
           pr_old += (alpha3 * dyn->pi[k] - 1.0) * lo;
           pr_new += (alpha3 * dyn->pi[k] - 1.0) * ln;
           dn += (a_old[k] - 1.0) * ln;       // density of proposing new from old
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-      if (k < K && lp == k) logz_mine = log(Zfin[k]);
+      if (k < K && lp == k) logz_mine = log(Zfin[k]);     // (one log sequence: every lane k evaluates its own)
     if (D > 0) {
       // offset seen by the Phi / nu block: o = sum_k Z_k ucov_k;  s~ = s - G o;  yy~ = yy - 2 o's + o'G o
       double o = 0.0;
@@ -298,10 +311,12 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
 
 // ------------------------------------------------------------------------------------------------
 // chi update + per-curve residual sum of squares.  do_update == 0 computes only the residuals.
-// LDS per group: U[M], GU[M], C0 (1), D = s - G c0 (1), chi (MMAX), z (MMAX), res (MMAX(MMAX+1)/2 + MMAX + 2)
+// LDS per group: U[M], GU[M], C0 (1), D = s - G c0 (1), chi (M), z (M), res (M(M+1)/2 + M + 2).  Sized by the
+// actual M so that three workgroups fit a CU and the extra scalar-job workgroup never waits for a free slot.
 // ------------------------------------------------------------------------------------------------
-template <int BW, int LPC>
+template <int BW, int LPC, bool COV>
 __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
+  TIMELINE(c, 5);
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
   if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
     job_hyper(c);
@@ -314,7 +329,8 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
   const Dims& d = c.d;
-  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD, D = d.D;
+  const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
+  const int D = COV ? d.D : 0;
   const int nth = K * (M + 1) * P;
   const int NR = K * (M + 1);
   const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
@@ -323,13 +339,14 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   double* sThX = sTh + nth;
   double* sRss = sThX + (size_t)nth * D;            // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int per_group = (2 * M + 3) * T::STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2) + (D > 0 ? NR * T::STR : 0);
+  const int nres = M * (M + 1) / 2 + M + 2;
+  const int per_group = (2 * M + 3) * T::STR + 2 * M + nres + (D > 0 ? NR * T::STR : 0);
   double* gbase = sRss + GPB + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + M * T::STR}, tX{gbase + 2 * M * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
   double* sChi = gbase + (2 * M + 3) * T::STR;
-  double* sZn = sChi + MMAX;
-  double* sRes = sZn + MMAX;
-  T tE{sRes + (MMAX * (MMAX + 1) / 2 + MMAX + 2)};
+  double* sZn = sChi + M;
+  double* sRes = sZn + M;
+  T tE{sRes + nres};
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blk * GPB + grp;
@@ -485,23 +502,29 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const size_t tileE = (D > 0) ? (size_t)K * (M + 1) * STR : 0;
   size_t lds;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
-  else lds = nth * (1 + D) + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * MMAX + (MMAX * (MMAX + 1) / 2 + MMAX + 2) + tileE);
+  else lds = nth * (1 + D) + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * M + (M * (M + 1) / 2 + M + 2) + tileE);
   lds = (lds + 8) * sizeof(double);
-  if (LPC == 32) {
-    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 32>), dim3(nblk), dim3(256), lds, st, c, do_update);
-    else hipLaunchKernelGGL((k_curve_chi<BW, 32>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);
-  } else {
-    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, 64>), dim3(nblk), dim3(256), lds, st, c, do_update);
-    else hipLaunchKernelGGL((k_curve_chi<BW, 64>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);
-  }
+  const bool cov = D > 0;
+#define LAUNCH_CURVE(L, CV)                                                                                   \
+  do {                                                                                                        \
+    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, L, CV>), dim3(nblk), dim3(256), lds, st, c, do_update);  \
+    else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);      \
+  } while (0)
+  if (LPC == 32) { if (cov) LAUNCH_CURVE(32, true); else LAUNCH_CURVE(32, false); }
+  else { if (cov) LAUNCH_CURVE(64, true); else LAUNCH_CURVE(64, false); }
+#undef LAUNCH_CURVE
 }
 
 template <int BW>
 static void prepare_bw() {
-  set_max_lds((const void*)k_curve_z<BW, 32>);
-  set_max_lds((const void*)k_curve_z<BW, 64>);
-  set_max_lds((const void*)k_curve_chi<BW, 32>);
-  set_max_lds((const void*)k_curve_chi<BW, 64>);
+  set_max_lds((const void*)k_curve_z<BW, 32, false>);
+  set_max_lds((const void*)k_curve_z<BW, 64, false>);
+  set_max_lds((const void*)k_curve_z<BW, 32, true>);
+  set_max_lds((const void*)k_curve_z<BW, 64, true>);
+  set_max_lds((const void*)k_curve_chi<BW, 32, false>);
+  set_max_lds((const void*)k_curve_chi<BW, 64, false>);
+  set_max_lds((const void*)k_curve_chi<BW, 32, true>);
+  set_max_lds((const void*)k_curve_chi<BW, 64, true>);
 }
 
 void prepare_curve_kernels() {

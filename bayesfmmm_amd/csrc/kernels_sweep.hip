@@ -37,19 +37,41 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // ---------------------------------------------------------------------------------------------
 // pair-Gram
 // ---------------------------------------------------------------------------------------------
-// grid = (CTG + 1, NKS); block = 256 (4 waves).  Workgroup (ct, ks) owns the 16 record columns
+// grid = (CTG + 2, NKS); block = 256 (4 waves).  Workgroup (ct, ks) owns the 16 record columns
 // [16 ct, 16 ct + 16) of the G part for the KS curves of k-slice ks: it stages them once in LDS
 // (coalesced 128-byte segments) and its four waves walk the RT row tiles of pair weights, each
 // wave issuing one v_mfma_f64_16x16x4_f64 per 4 curves and row tile; the weights w_ai w_bi are
 // rebuilt on the fly from Z and chi (also staged in LDS).  Workgroup (CTG, ks) does the same for the
 // single-weight rows against the s part of the records (t_a = sum_i w_ai s_i).
+//
+// LDS per curve i:  raw row  sW = [ Z_i1 .. Z_iK | 1, chi_i1 .. chi_iM | 0 ]  and, for the G workgroups,
+// the pair row  sP = [ Z_ij Z_ij' (j <= j') | chit_im chit_im' (m <= m') | 0 ].  Every MFMA weight is then the
+// branch-free product of two LDS entries (padding rows point at the 0 slot), so the inner loop has
+// no divergence and the TPW accumulators of a wave stay in flight together.
+#ifdef BFMMM_TIMELINE
+__device__ unsigned long long g_wgtrace[3 * 1024];
+void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtrace), sizeof(unsigned long long) * 3 * 1024); }
+#endif
+
 __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
+  TIMELINE(c, 1);
+#ifdef BFMMM_TIMELINE
+  const int wgid = blockIdx.x + gridDim.x * blockIdx.y;
+  if (threadIdx.x == 0 && wgid < 1024) {
+    unsigned id, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_wgtrace[3 * wgid] = wall_clock64();
+    g_wgtrace[3 * wgid + 1] = ((unsigned long long)(id & 0xf) << 32) | hw;
+  }
+  struct EndTrace { int w; __device__ ~EndTrace() { if (threadIdx.x == 0 && w < 1024) g_wgtrace[3 * w + 2] = wall_clock64(); } } et_{wgid};
+#endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
   if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
-    if (ks == 0) job_pi_alpha(c);
+    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 29); }
     return;
   }
   if (!do_pg) return;
@@ -58,112 +80,142 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int col0 = single ? d.LG : ct * 16;
   const int colend = single ? d.LG + d.P : d.LG;
   const int i0 = ks * KS;
-  double* sZ = smem;                         // KS x K
-  double* sC = sZ + (size_t)KS * K;          // KS x MD   (chit: 1, chi_1..chi_M)
-  double* sB = sC + (size_t)KS * MD;         // KS x ncol
-  // staging with batched loads: all of a thread's global loads are issued before its first LDS store
+  const int RS = K + MD + 1, ONE = K;
+  const int RP = d.NZZ + d.NCC + 1;
+  double* sW = smem;                         // KS x RS
+  double* sB = sW + (size_t)KS * RS;         // KS x ncol
+  double* sP = sB + (size_t)KS * ncol;       // KS x RP   (G workgroups only)
+  const int tid = threadIdx.x;
+  // staging: a thread issues all its global loads (one curve's Z / chi entries, UB record entries)
+  // before its first LDS store, so the workgroup pays about one memory round trip
   {
-    constexpr int UN = 4;
-    const int tid = threadIdx.x;
-    const int nZ = KS * K, nC = KS * MD, nB = KS * ncol;
-    for (int base = 0; base < nZ; base += 256 * UN) {
-      double v[UN];
+    constexpr int UW = 12, UB = 12;
+    const int ncw = K + MD - 1;              // source columns: Z_1..Z_K, chi_1..chi_M
+    const int nB = KS * ncol;
+    auto loadW = [&](int il0, int cb, double (&v)[UW]) {
+      const int i = min(i0 + il0 + tid, n - 1);
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int q = min(base + tid + 256 * u, nZ - 1);
-        const int k = q / KS, il = q - k * KS, i = min(i0 + il, n - 1);       // k-major: coalesced over curves
-        v[u] = c.Z[i + (size_t)n * k];
+      for (int u = 0; u < UW; ++u) {
+        const int col = min(cb + u, ncw - 1);
+        v[u] = (col < K) ? c.Z[i + (size_t)n * col] : c.chi[i + (size_t)n * (col - K)];
       }
+    };
+    auto storeW = [&](int il0, int cb, const double (&v)[UW]) {
+      const int il = il0 + tid;
+      if (il >= KS) return;
+      const bool live = i0 + il < n;
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int q = base + tid + 256 * u;
-        if (q < nZ) { const int k = q / KS, il = q - k * KS; sZ[il * K + k] = (i0 + il < n) ? v[u] : 0.0; }
+      for (int u = 0; u < UW; ++u) {
+        const int col = cb + u;
+        if (col < ncw) sW[il * RS + ((col < K) ? col : col + 1)] = live ? v[u] : 0.0;
       }
-    }
-    for (int base = 0; base < nC; base += 256 * UN) {
-      double v[UN];
+      if (cb == 0) { sW[il * RS + ONE] = 1.0; sW[il * RS + K + MD] = 0.0; }
+    };
+    auto loadB = [&](int base, double (&v)[UB]) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int q = min(base + tid + 256 * u, nC - 1);
-        const int mt = q / KS, il = q - mt * KS, i = min(i0 + il, n - 1);
-        v[u] = c.chi[i + (size_t)n * max(mt - 1, 0)];
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int q = base + tid + 256 * u;
-        if (q < nC) { const int mt = q / KS, il = q - mt * KS; sC[il * MD + mt] = (i0 + il < n) ? ((mt == 0) ? 1.0 : v[u]) : 0.0; }
-      }
-    }
-    for (int base = 0; base < nB; base += 256 * UN) {
-      double v[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const int q = min(base + tid + 256 * u, nB - 1);
-        const int il = q / ncol, cc = q - il * ncol, i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
+        const int il = single ? q / ncol : q >> 4, cc = q - il * ncol;
+        const int i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
         // covariate-adjusted models contract against s~_i = s_i - G_i o_i (k_curve_z) instead of s_i
         v[u] = (single && d.D > 0) ? c.stil[(size_t)i * d.P + min(cc, d.P - 1)] : c.rec[(size_t)i * d.LREC + col];
       }
+    };
+    auto storeB = [&](int base, const double (&v)[UB]) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const int q = base + tid + 256 * u;
-        if (q < nB) { const int il = q / ncol, cc = q - il * ncol; sB[q] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0; }
+        if (q < nB) {
+          const int il = single ? q / ncol : q >> 4, cc = q - il * ncol;
+          sB[q] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
+        }
       }
-    }
+    };
+    TSTAMP(c, 24);
+    double vw[UW], vb[UB];
+    loadW(0, 0, vw);
+    loadB(0, vb);
+    storeW(0, 0, vw);
+    storeB(0, vb);
+    for (int il0 = 0; il0 < KS; il0 += 256)
+      for (int cb = 0; cb < ncw; cb += UW) {
+        if (il0 == 0 && cb == 0) continue;
+        loadW(il0, cb, vw);
+        storeW(il0, cb, vw);
+      }
+    for (int base = 256 * UB; base < nB; base += 256 * UB) { loadB(base, vb); storeB(base, vb); }
+    TSTAMP(c, 25);
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TSTAMP(c, 26);
+  if (!single) {                             // pair rows, one thread per curve
+    for (int il = tid; il < KS; il += 256) {
+      const double* w = sW + il * RS;
+      double* p = sP + il * RP;
+      int e = 0;
+      for (int a = 0; a < K; ++a) { const double za = w[a]; for (int b = a; b < K; ++b) p[e++] = za * w[b]; }
+      for (int a = 0; a < MD; ++a) { const double ca = w[K + a]; for (int b = a; b < MD; ++b) p[e++] = ca * w[K + b]; }
+      p[e] = 0.0;
+    }
+    __syncthreads();
+  }
+  TSTAMP(c, 27);
+  const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const int ntile = single ? d.AT * d.CTS : d.RT;
-  for (int tt = wave; tt < ntile; tt += 4) {
-    int row, t, bcol;
-    bool rvalid;
-    int j1 = 0, j2 = 0, m1 = 0, m2 = 0;
-    if (!single) {
-      row = tt * 16 + lr;
-      t = tt * d.CTG + ct;
-      bcol = lr;
-      rvalid = row < d.R;
-      if (rvalid) {
-        const int zz = row / d.NCC, cc = row - zz * d.NCC;
-        int a = 0, rem = zz;                       // invert the packed-upper-triangle indices
-        while (rem >= K - a) { rem -= K - a; ++a; }
-        j1 = a; j2 = a + rem;
-        a = 0; rem = cc;
-        while (rem >= MD - a) { rem -= MD - a; ++a; }
-        m1 = a; m2 = a + rem;
-      }
-    } else {
-      const int at = tt / d.CTS, cs = tt - at * d.CTS;
-      row = at * 16 + lr;
-      t = d.RT * d.CTG + tt;
-      bcol = cs * 16 + lr;
-      rvalid = row < d.A;
-      if (rvalid) { j1 = row / MD; m1 = row - j1 * MD; }
-    }
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    if (single) {
-#pragma unroll 4
-      for (int kk = 0; kk < KS; kk += 4) {
-        const int il = kk + kq;
-        const double a = rvalid ? sZ[il * K + j1] * sC[il * MD + m1] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[il * ncol + bcol], acc, 0, 0, 0);
-      }
-    } else {
-#pragma unroll 4
-      for (int kk = 0; kk < KS; kk += 4) {
-        const int il = kk + kq;
-        const double a = rvalid ? (sZ[il * K + j1] * sZ[il * K + j2]) * (sC[il * MD + m1] * sC[il * MD + m2]) : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[il * 16 + bcol], acc, 0, 0, 0);
+  const double* wsrc = single ? sW : sP;
+  const int wstride = single ? RS : RP, ZERO = wstride - 1;
+  // each wave walks its tiles TPW at a time with independent accumulators: the LDS latency of one
+  // tile's operands hides behind the other tiles' MFMAs
+  constexpr int TPW = 3;
+  for (int t0 = wave; t0 < ntile; t0 += 4 * TPW) {
+    int tix[TPW], bcol[TPW], o1[TPW], o2[TPW];
+    bool tv[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int tt = t0 + 4 * q;
+      tv[q] = tt < ntile;
+      o1[q] = o2[q] = ZERO; bcol[q] = lr; tix[q] = 0;
+      if (tv[q]) {
+        if (!single) {
+          const int row = tt * 16 + lr;
+          tix[q] = tt * d.CTG + ct;
+          if (row < d.R) { const int zz = row / d.NCC; o1[q] = zz; o2[q] = d.NZZ + (row - zz * d.NCC); }
+        } else {
+          const int at = tt / d.CTS, cs = tt - at * d.CTS;
+          const int row = at * 16 + lr;
+          tix[q] = d.RT * d.CTG + tt;
+          bcol[q] = cs * 16 + lr;
+          if (row < d.A) { const int j = row / MD; o1[q] = j; o2[q] = K + (row - j * MD); }
+        }
       }
     }
-    double* out = c.pg_part + ((size_t)ks * d.NT + t) * 256 + lane;
-    out[0] = acc[0]; out[64] = acc[1]; out[128] = acc[2]; out[192] = acc[3];
+    double4_t acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < KS; kk += 4) {
+      const double* wrow = wsrc + (kk + kq) * wstride;
+      const double* brow = sB + (kk + kq) * ncol;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const double a = wrow[o1[q]] * wrow[o2[q]];
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[bcol[q]], acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+      if (tv[q]) {
+        double* out = c.pg_part + ((size_t)ks * d.NT + tix[q]) * 256 + lane;
+        out[0] = acc[q][0]; out[64] = acc[q][1]; out[128] = acc[q][2]; out[192] = acc[q][3];
+      }
+    TSTAMP(c, 28);
   }
 }
 
 // one thread per element of every output tile; fixed summation order over the k-slices
 // (four interleaved partial sums, combined in a fixed order)
 __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c, int NKS) {
+  TIMELINE(c, 2);
   const Dims& d = c.d;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= d.NT * 256) return;
@@ -236,6 +288,7 @@ __device__ inline double band_mv(const double* __restrict__ Hb, const double* v,
 // ---------------------------------------------------------------------------------------------
 template <int PP>
 __global__ __launch_bounds__(256) void k_factor(Ctx c) {
+  TIMELINE(c, 3);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
@@ -352,6 +405,7 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi) {
 }
 
 __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
+  TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD, BW = d.BW, LG = d.LG;
@@ -380,7 +434,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
   const int n_nu = (mask & U_NU) ? K : 0;
   const int n_steps = n_phi + n_nu;
-#define STAMP(i) do { if (tid == 0) dyn->stamps[i] = wall_clock64(); } while (0)
 
   // standard gamma variate of the sigma^2 draw: its shape does not depend on the sweep
   double sig_shape = 0.0, sig_g = 0.0;
@@ -522,6 +575,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
 // bookkeeping (advance the iteration counter / slot for graph replay).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_stored) {
+  TIMELINE(c, 6);
   __shared__ double red[256];
   Dyn* dyn = c.dyn;
   const int tid = threadIdx.x;
@@ -556,8 +610,8 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
-  const int ncol = std::max(16, c.d.CTS * 16);
-  const size_t lds = (size_t)KS * (c.d.K + c.d.MD + ncol) * sizeof(double);
+  const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
+  const size_t lds = (size_t)KS * std::max(row_g, row_s) * sizeof(double);
   hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(256), lds, st, c, KS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;

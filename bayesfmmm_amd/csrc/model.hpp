@@ -53,7 +53,7 @@ struct Dyn {
   double loglik;
   double pi[KMAX];
   double tau[KMAX];
-  unsigned long long stamps[16];   // diagnostic phase stamps of k_sweep (100 MHz wall clock)
+  unsigned long long stamps[32];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
 };
 
 struct Dims {
@@ -138,6 +138,24 @@ struct Ctx {
 __host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
   return a * n - (a * (a - 1)) / 2 + (b - a);
 }
+
+// Diagnostic timeline (compiled in only with -DBFMMM_TIMELINE): stamps[2k] = start of the first workgroup of
+// kernel k, stamps[2k+1] = latest end over all its workgroups, on the 100 MHz wall clock.
+#ifdef BFMMM_TIMELINE
+struct Timeline {
+  unsigned long long* s; int k;
+  __device__ Timeline(const Ctx& c, int k_) : s(c.dyn->stamps), k(k_) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) s[2 * k] = wall_clock64();
+    if (threadIdx.x == 0) atomicMax(&s[16 + k], (unsigned long long)wall_clock64());   // latest workgroup start
+  }
+  __device__ ~Timeline() { if (threadIdx.x == 0) atomicMax(&s[2 * k + 1], (unsigned long long)wall_clock64()); }
+};
+#define TIMELINE(c, k) Timeline tl_((c), (k))
+#define TSTAMP(c, i) do { if (threadIdx.x == 0) atomicMax(&(c).dyn->stamps[i], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define TIMELINE(c, k) do { } while (0)
+#define TSTAMP(c, i) do { } while (0)
+#endif
 
 // Batched global -> LDS copy: every thread issues UN independent loads before the first store, so
 // the copy costs one memory latency per UN*nthreads elements instead of one per nthreads.

@@ -143,7 +143,11 @@ __host__ __device__ inline double rgamma(const RngKey& r, uint32_t upd, uint32_t
     if (v <= 0.0) continue;
     v = v * v * v;
     g = d * v;
-    if (log(u1) < 0.5 * x * x + d - d * v + d * log(v)) break;
+    // Marsaglia-Tsang squeeze: a sufficient condition for the log test below, so the accept / reject
+    // decisions (and therefore the variates) are unchanged; it only skips the two logarithms
+    const double x2 = x * x;
+    if (u1 < 1.0 - 0.0331 * (x2 * x2)) break;
+    if (log(u1) < 0.5 * x2 + d - d * v + d * log(v)) break;
   }
   return g * boost * scale;
 }

@@ -199,8 +199,6 @@ __device__ inline void job_hyper(const Ctx& c) {
   const double* gT = gD + K * M;
   const double* aProp = gT + K;
   const double* aUnif = aProp + 2 * K;
-#define HSTAMP(i) do { if (tid == 0) dyn->stamps[i] = wall_clock64(); } while (0)
-  HSTAMP(0);
   // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 ; row products of nu_k' P nu_k ----
   if (do_delta && tid < K * M) {
     const int k = tid / M, m = tid - k * M;
@@ -223,7 +221,6 @@ __device__ inline void job_hyper(const Ctx& c) {
   if (tid < K)
     for (int m = 0; m < M; ++m) dl[tid * 16 + m] = c.delta[tid + (size_t)K * m];
   __syncthreads();
-  HSTAMP(1);
   // ---- phase 2: tau (K lanes), delta recursion (K lanes) ----
   if (do_tau && tid >= 32 && tid < 32 + K) {
     const int k = tid - 32;
@@ -269,7 +266,6 @@ __device__ inline void job_hyper(const Ctx& c) {
     slog[k] = sl;
   }
   __syncthreads();
-  HSTAMP(2);
   // ---- phase 3: A terms (4 lanes per cell), gamma scaling ----
   if (do_A && tid < K * 2 * 4) {
     const int cell = tid >> 2, job = tid & 3;
@@ -300,7 +296,6 @@ __device__ inline void job_hyper(const Ctx& c) {
     }
   }
   __syncthreads();
-  HSTAMP(3);
   // ---- phase 4: A accept; chain slots ----
   if (do_A && tid < K * 2) {
     const double* w = aw + tid * 6;
@@ -313,7 +308,6 @@ __device__ inline void job_hyper(const Ctx& c) {
   if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
   if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
   if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
-  HSTAMP(4);
 }
 
 }  // namespace bfmmm

@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'.')
+"""Diagnostic (not a test): kernel timeline of one warm-start iteration at config 2.
+Build the library with `make -C bayesfmmm_amd/csrc clean && make -C bayesfmmm_amd/csrc EXTRA=-DBFMMM_TIMELINE` first."""
+import sys; sys.path.insert(0, '.')
 import numpy as np, bayesfmmm_amd as bf
 from bench import make_config2
 w = make_config2()
@@ -6,8 +8,44 @@ cfg = bf.default_config(model=0, K=3, n_eigen=6, basis_degree=3, tot_mcmc_iters=
 smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"])
 smp.set_state(**w["state"])
 smp.run(bf.SWEEP_WARM, 50)
-st = smp.get_state("stamps")
-names = ["start","Skm + tau rows","tau, delta rec, slog","A terms + gamma scale","accept + slots"]
-print("job_hyper stamps (us):")
-for i in range(1, 5): print(f"  {names[i]:32s} {(st[i]-st[i-1])*0.01:8.2f}")
-print("  total", st[4]*0.01)
+st = np.array(smp.get_state("stamps")) * 0.01
+names = ["curve_z", "pair_gram", "pg_reduce", "factor", "sweep", "curve_chi", "loglik"]
+t0 = st[0]
+prev_end = None
+for k, nm in enumerate(names):
+    b, e = st[2 * k] - t0, st[2 * k + 1] - t0
+    gap = "" if prev_end is None else " (gap after previous end %.2f us)" % (b - prev_end)
+    print("%-10s start %8.2f end %8.2f  busy %6.2f us, last WG starts at +%.2f%s" % (nm, b, e, e - b, st[16 + k] - st[2 * k], gap))
+    prev_end = e
+
+
+
+
+print("pair_gram (max over WGs, rel. kernel start): begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[24:30]-st[2]))
+try:
+    tr = np.array(smp.get_state("wgtrace")).reshape(-1, 3)
+    nwg = 250
+    t0 = tr[:nwg, 0].min()
+    order = np.argsort(tr[:nwg, 0])
+    print("pair_gram per-WG trace (latest 12 starters): wg (ct,ks) start end xcc se/cu-bits")
+    for w in order[-12:]:
+        meta = int(tr[w, 1]); xcc = meta >> 32; hw = meta & 0xffffffff
+        print("  wg %3d (ct %d, ks %2d) start +%6.2f end +%6.2f xcc %d hw_id 0x%08x cu %d sh %d se %d" % (w, w % 10, w // 10, (tr[w, 0] - t0) * 0.01, (tr[w, 2] - t0) * 0.01, xcc, hw, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7))
+    for x in range(8):
+        sel = [w for w in range(nwg) if (int(tr[w, 1]) >> 32) == x and w % 10 != 9]
+        if sel:
+            print("  xcc %d: %2d real WGs, start min +%.2f max +%.2f, end min +%.2f max +%.2f, dur min %.2f max %.2f" % (x, len(sel), (tr[sel, 0].min() - t0) * 0.01, (tr[sel, 0].max() - t0) * 0.01,
+                  (tr[sel, 2].min() - t0) * 0.01, (tr[sel, 2].max() - t0) * 0.01, ((tr[sel, 2] - tr[sel, 0]).min()) * 0.01, ((tr[sel, 2] - tr[sel, 0]).max()) * 0.01))
+    import collections
+    cnt = collections.Counter((int(tr[w, 1]) >> 32, (int(tr[w, 1]) >> 8) & 0xff) for w in range(nwg) if w % 10 != 9)
+    print("max real WGs sharing one (xcc, se/sh/cu):", max(cnt.values()), " distinct CUs used:", len(cnt))
+except Exception as ex:
+    print("no wgtrace:", ex)
+print("abs: stamps pair_gram start %.2f  latest-start %.2f  end %.2f | trace min start %.2f max start(all) %.2f max end(all) %.2f" % (st[2], st[17], st[3], t0 * 0.01, tr[:nwg, 0].max() * 0.01, tr[:nwg, 2].max() * 0.01))
+w = int(np.argmax(tr[:nwg, 0])); print("latest starter overall: wg", w, "ct", w % 10, "ks", w // 10, "xcc", int(tr[w, 1]) >> 32)
+w = int(np.argmax(tr[:nwg, 2])); print("latest finisher overall: wg", w, "ct", w % 10, "ks", w // 10, "xcc", int(tr[w, 1]) >> 32, "start +%.2f" % ((tr[w, 0] - t0) * 0.01))
+tr_all = np.array(smp.get_state("wgtrace")).reshape(-1, 3)
+nz = np.nonzero(tr_all[:, 0])[0]
+print("trace entries written:", len(nz), "max wg id", nz.max())
+late = [w for w in nz if tr_all[w, 0] > t0 + 500]
+print("entries starting > 5 us after t0:", late[:20], [(round((tr_all[w,0]-t0)*0.01,2), round((tr_all[w,2]-t0)*0.01,2)) for w in late[:20]])
