@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
   if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
-    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 29); }
+    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 31); }
     return;
   }
   if (!do_pg) return;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
         }
       }
     };
-    TSTAMP(c, 24);
+    TSTAMP(c, 20);
     double vw[UW], vb[UB];
     loadW(0, 0, vw);
     loadB(0, vb);
@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
         storeW(il0, cb, vw);
       }
     for (int base = 256 * UB; base < nB; base += 256 * UB) { loadB(base, vb); storeB(base, vb); }
-    TSTAMP(c, 25);
+    TSTAMP(c, 21);
   }
   __syncthreads();
-  TSTAMP(c, 26);
+  TSTAMP(c, 22);
   if (!single) {                             // pair rows, one thread per curve
     for (int il = tid; il < KS; il += 256) {
       const double* w = sW + il * RS;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     }
     __syncthreads();
   }
-  TSTAMP(c, 27);
+  TSTAMP(c, 23);
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const int ntile = single ? d.AT * d.CTS : d.RT;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
         double* out = c.pg_part + ((size_t)ks * d.NT + tix[q]) * 256 + lane;
         out[0] = acc[q][0]; out[64] = acc[q][1]; out[128] = acc[q][2]; out[192] = acc[q][3];
       }
-    TSTAMP(c, 28);
+    TSTAMP(c, 30);
   }
 }
 
@@ -238,7 +238,14 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c, int NKS) {
   if (t < n_pair_tiles) {
     const int rt = t / d.CTG, ct = t - rt * d.CTG;
     const int row = rt * 16 + rit, col = ct * 16 + cit;
-    if (row < d.R && col < d.LG) c.H[(size_t)row * d.LG + col] = s;
+    if (row < d.R && col < d.LG) {
+      c.H[(size_t)row * d.LG + col] = s;
+      // row-major copy for the sweep: entry k of row p is G(p, p + k - BW)
+      const int dd = col / d.P, p0 = col - dd * d.P, W = 2 * d.BW + 2;
+      double* h2 = c.H2 + (size_t)row * d.P * W;
+      h2[p0 * W + d.BW + dd] = s;
+      if (dd > 0 && p0 + dd < d.P) h2[(p0 + dd) * W + d.BW - dd] = s;
+    }
   } else {
     const int t2 = t - n_pair_tiles;
     const int at = t2 / d.CTS, cs = t2 - at * d.CTS;
@@ -435,15 +442,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   const int n_nu = (mask & U_NU) ? K : 0;
   const int n_steps = n_phi + n_nu;
 
-  // standard gamma variate of the sigma^2 draw: its shape does not depend on the sweep
-  double sig_shape = 0.0, sig_g = 0.0;
-  if ((mask & U_SIGMA) && tid == SW_THREADS - 1) {
-    const bool tempered = (dyn->tt_step != 0);
-    sig_shape = tempered ? (beta * (double)d.n_obs_total) / 2
-                         : (d.mv ? (double)(d.n_obs_total / 2) : (double)d.half_sum);   // UpdateSigma.h:49 / :150
-    sig_shape += c.h.alpha_0;
-    sig_g = rgamma(key, UPD_SIGMA, 0, sig_shape, 1.0);
-  }
+  // the standard gamma variate of the sigma^2 draw was produced by a spare k_factor workgroup (job_hyper_draws)
+  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
   for (int e = tid; e < A * PS; e += SW_THREADS) {
     const int b = e / PS, pp = e - b * PS - BW;
     th[e] = (pp >= 0 && pp < P) ? c.theta[(size_t)full_dir(d, b) * P + pp] : 0.0;
@@ -492,7 +492,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     const int an = more ? step_dir(d, st + 1, n_phi) : -1;
     const double* buf = (st & 1) ? pbuf1 : pbuf0;
     const double* Cg = buf + (size_t)A * LG;
+#ifndef BFMMM_EXP_NOPF
     if (more) pf_load(an);
+#endif
     // phase A: new = C rhs + L z
     for (int p = tid >> 3; p < P; p += SW_THREADS / 8) {
       const int seg = tid & 7;
@@ -571,6 +573,284 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sweep_fast: the same sweep for P <= 32 and A*P <= 1024 (every configuration of BASELINE.json).
+// The kernel is a chain of K*M + K dependent steps on one CU, so what matters is the length of the
+// per-step dependency chain, not throughput:
+//   * thread (b, p) owns r_b[p] and (H_bb theta_b)[p] in registers and reads its 2 BW + 1 entries of
+//     the band block H_{b,a} straight from L2 into registers, two steps ahead (no LDS staging);
+//   * C_a rhs is one FMA pair per lane (16 lanes per row) and a 4-step DPP reduction: no loops, no
+//     LDS traffic besides rhs;
+//   * two LDS-only barriers per step; all indices are computed once.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ inline double dpp_add(double v) {   // v + dpp_permute<CTRL>(v) within a row of 16 lanes
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double row16_sum(double v) {   // every lane of a 16-lane row gets the row's sum
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  v = dpp_add<0x140>(v);    // row_mirror
+  return v;
+}
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int BW>
+struct SweepPre { v2d h[BW + 1]; double cv[4]; };
+
+__device__ inline const double* ptr_off(const double* base, uint32_t byte_off) {   // uniform base + 32-bit lane offset
+  return (const double*)((const char*)base + byte_off);
+}
+
+// Software-managed prefetch.  The loads below are inline assembly, so the compiler neither tracks them nor
+// inserts s_waitcnt for them (its own placement drained the queue every step); sweep_wait<N> is the matching
+// wait: "at most N younger loads may still be in flight" -- vmcnt retires in issue order.  The loaded registers
+// pass through the wait as read-write operands, so no use can be scheduled above it.
+template <int IMM>
+__device__ inline v2d sweep_ld16(const double* sbase, uint32_t voff) {
+  v2d r;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
+  return r;
+}
+__device__ inline double sweep_ld8(const double* sbase, uint32_t voff) {
+  double r;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase));
+  return r;
+}
+
+template <int BW>
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
+  TIMELINE(c, 4);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Dims& d = c.d;
+  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;
+  constexpr int W = 2 * BW + 2;              // doubles per row of an H2 block
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  Dyn* dyn = c.dyn;
+  const int AP = A * P;
+  double* th = smem;                         // A x P   theta of the active directions
+  double* lz = th + AP;                      // A x P   L_a z_a
+  double* rhs = lz + AP;                     // 32 (zero beyond P)
+  double* dlp = rhs + 32;                    // BW + 32 + BW + 1 (zero pads)
+  double* red = dlp + 32 + 2 * BW + 2;       // 16
+  int* htab = (int*)(red + 16);              // A x A : byte offset of block (b, a) in H2
+  int* sdir = htab + A * A;                  // directions of the steps (clamped tail)
+  const uint32_t slot = dyn->slot;
+  const uint32_t mask = c.mask;
+  const double beta = dyn->beta;
+  const double f = beta / dyn->sigma2;
+  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
+  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
+  const int n_nu = (mask & U_NU) ? K : 0;
+  const int n_steps = n_phi + n_nu;
+  // B role (all waves): element e = (b, p) of the stacked vectors.
+  // A role (waves 0-3): lane q of the 8 lanes of row pa handles columns q, q + 8, q + 16, q + 24 of C_a.
+  const bool isB = tid < AP;
+  const int e = min(tid, AP - 1);
+  const int b = e / P, p = e - b * P;
+  const bool waveA = tid < 256;              // wave-uniform
+  const bool isA = tid < 8 * P;
+  const int pa = min(tid >> 3, P - 1), q = tid & 7;
+  uint32_t coff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) coff[u] = (uint32_t)(pa + P * min(q + 8 * u, P - 1)) * 8u;
+  const uint32_t hoff = (uint32_t)p * (W * 8u);
+  const int fd = full_dir(d, b);
+  double r_e = c.rvec[e], hq_e = c.hq[e];
+  const double tv_e = c.tvec[e];
+  {
+    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[e];
+    if (isB) { th[e] = t0; lz[e] = l0; }
+  }
+  if (tid < 32) rhs[tid] = 0.0;
+  if (tid < 32 + 2 * BW + 2) dlp[tid] = 0.0;
+  for (int x = tid; x < A * A; x += nthr) htab[x] = hrow(d, x / A, x % A) * P * W * 8;
+  for (int x = tid; x < n_steps + 4; x += nthr) sdir[x] = step_dir(d, min(x, n_steps - 1), n_phi);
+  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
+  // H2 and C were written by other XCDs (k_pg_reduce, k_factor): a first touch costs a trip to HBM, far longer
+  // than a step of the chain.  Pull both into this XCD's L2 once, in one batch of wide loads, so that the
+  // per-step register prefetch only ever sees L2 hits.
+  {
+    double wsum = 0.0;
+    auto warm = [&](const double* src, int count) {
+      const double2* s2 = (const double2*)src;
+      const int n2 = count / 2;
+      constexpr int UN = 8;
+      for (int base = 0; base < n2; base += nthr * UN) {
+        double2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = s2[min(base + tid + nthr * u, n2 - 1)];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) wsum += v[u].x + v[u].y;
+      }
+    };
+    if (n_steps > 0) { warm(c.H2, d.R * P * W); warm(c.Cmat, A * P * P); }
+    if (wsum == 1.2345e300 && tid == 0) dyn->status |= 0x80000000u;     // never true: keeps the loads alive
+  }
+  __syncthreads();
+  // branch-free loads (every lane reads valid addresses).  A set is refilled right after its last use, so the
+  // loaded values land in the registers the loop carries.
+  auto issueH = [&](SweepPre<BW>& s, int a) {
+    const uint32_t off = (uint32_t)htab[b * A + a] + hoff;
+    s.h[0] = sweep_ld16<0>(c.H2, off);
+    if constexpr (BW >= 1) s.h[1] = sweep_ld16<16>(c.H2, off);
+    if constexpr (BW >= 2) s.h[2] = sweep_ld16<32>(c.H2, off);
+    if constexpr (BW >= 3) s.h[3] = sweep_ld16<48>(c.H2, off);
+    if constexpr (BW >= 4) s.h[4] = sweep_ld16<64>(c.H2, off);
+    if constexpr (BW >= 5) s.h[5] = sweep_ld16<80>(c.H2, off);
+  };
+  const uint32_t cstride = (uint32_t)(P * P) * 8u;
+  auto issueC = [&](SweepPre<BW>& s, int a) {    // waves 0-3 only
+    const uint32_t base = (uint32_t)a * cstride;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.cv[u] = sweep_ld8(c.Cmat, base + coff[u]);
+  };
+  auto waitC = [&](SweepPre<BW>& s) {            // younger: H(this set), C + H (other set)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.cv[0]), "+v"(s.cv[1]), "+v"(s.cv[2]), "+v"(s.cv[3]) : "n"(2 * (BW + 1) + 4));
+  };
+  auto waitH = [&](SweepPre<BW>& s) {
+    // younger: C + H of the other set and this set's refilled C (waves 0-3); H of the other set (other waves)
+    if (waveA) {
+      if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(BW + 9));
+      if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(BW + 9));
+      if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(BW + 9));
+      if constexpr (BW == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]) : "n"(BW + 9));
+      if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(BW + 9));
+      if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(BW + 9));
+    } else {
+      if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(BW + 1));
+      if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(BW + 1));
+      if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(BW + 1));
+      if constexpr (BW == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]) : "n"(BW + 1));
+      if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(BW + 1));
+      if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(BW + 1));
+    }
+  };
+#ifdef BFMMM_TIMELINE
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SWT(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tlast; tlast = now_; } while (0)
+  unsigned long long tlast = clock64();
+#else
+#define SWT(i) do { } while (0)
+#endif
+  auto step = [&](SweepPre<BW>& s, int a, int an, int a_refill) {
+    SWT(4);
+    // phase A (waves 0-3): theta_a <- C_a rhs + L_a z_a
+    if (waveA) {
+      const double lza = lz[a * P + pa], tha = th[a * P + pa];
+      const double x0 = rhs[q], x1 = rhs[q + 8], x2 = rhs[q + 16], x3 = rhs[q + 24];
+      waitC(s);
+      double acc = (s.cv[0] * x0 + s.cv[1] * x1) + (s.cv[2] * x2 + s.cv[3] * x3);
+      issueC(s, a_refill);
+      acc = dpp_add<0xB1>(acc);     // quad_perm [1,0,3,2]
+      acc = dpp_add<0x4E>(acc);     // quad_perm [2,3,0,1]
+      acc = dpp_add<0x141>(acc);    // row_half_mirror: the 8 lanes of a row now hold its sum
+      if (isA && q == 0) {
+        const double nw = acc + lza;
+        dlp[BW + pa] = nw - tha;
+        th[a * P + pa] = nw;
+      }
+    }
+    SWT(0);
+    lds_barrier();
+    SWT(1);
+    // phase B: r_b -= H_ba dl ; (H_aa theta_a) follows theta_a ; rhs of the next direction
+    const double* dl = dlp + p;              // dl[k] = delta[p + k - BW]
+    double dv[2 * BW + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * BW + 2; ++k) dv[k] = dl[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SWT(5);
+    waitH(s);
+    SWT(6);
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k <= BW; ++k) v += s.h[k].x * dv[2 * k] + s.h[k].y * dv[2 * k + 1];   // last .y is the zero pad
+    issueH(s, a_refill);
+    SWT(7);
+    r_e -= v;
+    if (b == a) hq_e += v;
+    if (isB && b == an) rhs[p] = f * (r_e + hq_e);
+    SWT(2);
+    lds_barrier();
+    SWT(3);
+  };
+  if (n_steps > 0) {
+    const int a0 = sdir[0];
+    if (isB && b == a0) rhs[p] = f * (r_e + hq_e);
+    SweepPre<BW> s0, s1;
+    // the hand-counted waits below start from an empty queue; naming the registers that the setup loaded makes
+    // the compiler place its own (tracked) waits for them here instead of inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_e), "+v"(hq_e) :: "memory");
+    {
+      const int a1i = sdir[1];
+      if (waveA) issueC(s0, a0);
+      issueH(s0, a0);                                    // same issue order as the steady state
+      if (waveA) issueC(s1, a1i);
+      issueH(s1, a1i);
+    }
+    lds_barrier();
+    int a = __builtin_amdgcn_readfirstlane(sdir[0]), a1 = __builtin_amdgcn_readfirstlane(sdir[1]);
+    int a2 = __builtin_amdgcn_readfirstlane(sdir[2]), a3 = __builtin_amdgcn_readfirstlane(sdir[3]);
+    for (int st = 0; st < n_steps; st += 2) {
+      const int v4 = sdir[min(st + 4, n_steps + 2)], v5 = sdir[min(st + 5, n_steps + 3)];   // consumed after the steps
+      step(s0, a, (st + 1 < n_steps) ? a1 : -1, a2);
+      if (st + 1 < n_steps) step(s1, a1, (st + 2 < n_steps) ? a2 : -1, a3);
+      a = a2; a1 = a3;
+      a2 = __builtin_amdgcn_readfirstlane(v4); a3 = __builtin_amdgcn_readfirstlane(v5);
+    }
+    // drain the prefetches of the (clamped) tail before their registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.h[0]), "+v"(s1.h[0]), "+v"(s0.cv[0]), "+v"(s1.cv[0]) :: "memory");
+  }
+#ifdef BFMMM_TIMELINE
+  if (tid == 0) for (int x = 0; x < 8; ++x) dyn->stamps[24 + x] = tk[x];
+#endif
+  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
+  const double th_e = th[e];
+  if (mask & U_SIGMA) {
+    // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
+    // (covariate-adjusted: YY is replaced by sum_i yy_i - 2 o_i's_i + o_i'G_i o_i, block partials of k_curve_z)
+    double acc = isB ? th_e * (tv_e + r_e) : 0.0;
+    if (d.D > 0)
+      for (int x = tid; x < c.nblk_curve; x += nthr) acc -= c.yyp_part[x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double qs = 0.0;
+      for (int w = 0; w < nthr / 64; ++w) qs += red[w];
+      const double rss = (d.D > 0) ? -qs : (c.YY - qs);
+      const bool tempered = (dyn->tt_step != 0);
+      const double bb = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
+      const double s2 = 1.0 / (sig_g * (1.0 / bb));
+      dyn->sigma2 = s2;
+      dyn->rss = rss;
+      c.c_sigma[slot] = s2;
+    }
+  } else if (tid == 0) {
+    c.c_sigma[slot] = dyn->sigma2;
+  }
+
+  // ---------------- publish theta and its chain slots -------------------------------------------
+  double* s_nu = c.c_nu + (size_t)slot * K * P;
+  double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
+  if (isB) {
+    const int jj = b / MD, mt = b - jj * MD;
+    c.theta[(size_t)fd * P + p] = th_e;
+    if (mt == 0) s_nu[jj + (size_t)K * p] = th_e;
+    else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = th_e;
+  }
+  if (MD == 1)
+    for (int x = tid; x < K * P * M; x += nthr) {
+      const int k = x % K, pm = x / K, pp = pm % P, m = pm / P;
+      s_phi[x] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + pp];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_loglik: calcLikelihood = sum_il dnorm(y_il; mean_il, sqrt(sigma2), log)  and end-of-iteration
 // bookkeeping (advance the iteration counter / slot for graph replay).
 // ---------------------------------------------------------------------------------------------
@@ -621,7 +901,7 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP + (size_t)c.d.A * c.d.LG) * sizeof(double);
-  const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K;
+  const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1;   // + sigma^2's gamma variate
   const int grid = c.d.A + (n_draw + 255) / 256;
   if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(grid), dim3(256), lds, st, c);
   else hipLaunchKernelGGL(k_factor<64>, dim3(grid), dim3(256), lds, st, c);
@@ -629,6 +909,19 @@ void launch_factor(const Ctx& c, hipStream_t st) {
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
+  if (d.P <= 32 && d.A * d.P <= SW_THREADS && d.BW <= 5) {      // fast path: register-resident sweep
+    const int nthr = (std::max(d.A * d.P, 256) + 63) / 64 * 64;
+    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 32 + 2 * d.BW + 2 + 16) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
+    switch (d.BW) {
+      case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1), dim3(nthr), lds, st, c); break;
+      case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1), dim3(nthr), lds, st, c); break;
+      case 2: hipLaunchKernelGGL(k_sweep_fast<2>, dim3(1), dim3(nthr), lds, st, c); break;
+      case 3: hipLaunchKernelGGL(k_sweep_fast<3>, dim3(1), dim3(nthr), lds, st, c); break;
+      case 4: hipLaunchKernelGGL(k_sweep_fast<4>, dim3(1), dim3(nthr), lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_fast<5>, dim3(1), dim3(nthr), lds, st, c); break;
+    }
+    return 0;
+  }
   const size_t pf_len = (size_t)d.A * d.LG + (size_t)d.P * d.P;
   if (pf_len > (size_t)NPF * SW_THREADS) return 1;
   const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf_len;

@@ -98,6 +98,7 @@ struct Ctx {
   double* rss_part;             // nblk_curve       partial residual sums of squares
   double* pg_part;              // NWG x NT x 256   pair-Gram partial tiles
   double* H;                    // R x LG           pair-weighted Gram blocks (band-packed)
+  double* H2;                   // R x P x (2BW+2)  the same blocks row-major by p: [G(p,p-BW) .. G(p,p+BW), 0] (k_sweep_fast)
   double* tvec;                 // A x P            sum_i w_ai s_i
   double* rvec;                 // A x P            r_a = t_a - sum_b H_ab theta_b at the start of the sweep
   double* hq;                   // A x P            H_aa theta_a

@@ -162,9 +162,15 @@ __device__ inline void job_hyper_draws(const Ctx& c, int first) {
   const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
   const int nG = K * P * M;
   const int e = first + threadIdx.x;
-  if (e >= hyper_gstd_count(d)) return;
+  if (e > hyper_gstd_count(d)) return;
   double v;
-  if (e < nG) {
+  if (e == hyper_gstd_count(d)) {
+    // standard gamma variate of the sigma^2 draw (its shape is state-independent): UpdateSigma.h:49 / :150
+    const bool tempered = (dyn->tt_step != 0);
+    double shape = tempered ? (dyn->beta * (double)d.n_obs_total) / 2 : (d.mv ? (double)(d.n_obs_total / 2) : (double)d.half_sum);
+    shape += c.h.alpha_0;
+    v = rgamma(key, UPD_SIGMA, 0, shape, 1.0);
+  } else if (e < nG) {
     v = rgamma(key, UPD_GAMMA, (uint32_t)e, (c.h.nu_1 + 1) / 2, 1.0);                       // UpdateGamma.h:29
   } else if (e < nG + K * M) {
     const int q = e - nG, k = q / M, i = q - k * M;

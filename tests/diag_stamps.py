@@ -21,7 +21,8 @@ for k, nm in enumerate(names):
 
 
 
-print("pair_gram (max over WGs, rel. kernel start): begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[24:30]-st[2]))
+print("pair_gram (max over WGs, rel. kernel start): begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[[20,21,22,23,30,31]]-st[2]))
+print("sweep wave0 clocks/step: phaseA %d  barrier1 %d | B: lds-reads %d  waitH %d  fma+issueH %d  tail %d | barrier2 %d  between %d" % tuple(np.array(smp.get_state("stamps"))[[24,25,29,30,31,26,27,28]] / 21))
 try:
     tr = np.array(smp.get_state("wgtrace")).reshape(-1, 3)
     nwg = 250
