@@ -597,8 +597,6 @@ __device__ inline double row16_sum(double v) {   // every lane of a 16-lane row 
 }
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-template <int BW>
-struct SweepPre { v2d h[BW + 1]; double cv[4]; };
 
 __device__ inline const double* ptr_off(const double* base, uint32_t byte_off) {   // uniform base + 32-bit lane offset
   return (const double*)((const char*)base + byte_off);
@@ -608,18 +606,36 @@ __device__ inline const double* ptr_off(const double* base, uint32_t byte_off) {
 // inserts s_waitcnt for them (its own placement drained the queue every step); sweep_wait<N> is the matching
 // wait: "at most N younger loads may still be in flight" -- vmcnt retires in issue order.  The loaded registers
 // pass through the wait as read-write operands, so no use can be scheduled above it.
+// The destination is a read-write operand: the register stays allocated to the variable across the load (the
+// compiler believes inline assembly completes synchronously; a write-only destination that is dead until its
+// next definition could be handed out as a temporary while the load is still in flight).
 template <int IMM>
-__device__ inline v2d sweep_ld16(const double* sbase, uint32_t voff) {
-  v2d r;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
-  return r;
+__device__ inline void sweep_ld16(v2d& r, const double* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
 }
-__device__ inline double sweep_ld8(const double* sbase, uint32_t voff) {
-  double r;
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase));
-  return r;
+__device__ inline void sweep_ld8(double& r, const double* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(r) : "v"(voff), "s"(sbase));
 }
 
+template <int BW> struct SweepH { v2d h[BW + 1]; };
+
+// s_waitcnt vmcnt(N) that the loaded registers pass through (no use can be scheduled above it)
+template <int N, int BW>
+__device__ inline void sweep_wait_h(SweepH<BW>& s) {
+  if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(N));
+  if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(N));
+  if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(N));
+  if constexpr (BW == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]) : "n"(N));
+  if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(N));
+  if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(N));
+}
+
+// Thread layout: waves 0-3 (tid < 256) run the critical chain (phase A: theta_a <- C_a rhs + L_a z_a, 8 lanes
+// per row of C_a); threads 256 + e own element e = (b, p) of the stacked residual r.  Per step st with direction a:
+//   P1  waves 0-3 : theta_a, delta_st -> LDS                       | r threads: LAGGING update r_b -= H_{b,a'} delta_{st-1}
+//   P2  r threads of the NEXT direction only: r -= H delta_st, next rhs -> LDS   (the urgent 1/A-th of the update)
+// so the bulk of the memory traffic (H blocks from L2, delta from LDS) overlaps the dependent chain instead of
+// sitting on it.  H_{b,a} rows are prefetched into registers one to two steps ahead (sweep_ld16 / sweep_wait_h).
 template <int BW>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   TIMELINE(c, 4);
@@ -627,14 +643,15 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   const Dims& d = c.d;
   const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;
   constexpr int W = 2 * BW + 2;              // doubles per row of an H2 block
+  constexpr int DLS = 32 + 2 * BW + 2;       // one delta buffer: BW zero pads | 32 | BW + 2 zero pads
   const int tid = threadIdx.x, nthr = blockDim.x;
   Dyn* dyn = c.dyn;
   const int AP = A * P;
   double* th = smem;                         // A x P   theta of the active directions
   double* lz = th + AP;                      // A x P   L_a z_a
   double* rhs = lz + AP;                     // 32 (zero beyond P)
-  double* dlp = rhs + 32;                    // BW + 32 + BW + 1 (zero pads)
-  double* red = dlp + 32 + 2 * BW + 2;       // 16
+  double* dlp = rhs + 32;                    // 2 x DLS, by step parity
+  double* red = dlp + 2 * DLS;               // 16
   int* htab = (int*)(red + 16);              // A x A : byte offset of block (b, a) in H2
   int* sdir = htab + A * A;                  // directions of the steps (clamped tail)
   const uint32_t slot = dyn->slot;
@@ -645,168 +662,151 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
   const int n_nu = (mask & U_NU) ? K : 0;
   const int n_steps = n_phi + n_nu;
-  // B role (all waves): element e = (b, p) of the stacked vectors.
-  // A role (waves 0-3): lane q of the 8 lanes of row pa handles columns q, q + 8, q + 16, q + 24 of C_a.
-  const bool isB = tid < AP;
-  const int e = min(tid, AP - 1);
-  const int b = e / P, p = e - b * P;
   const bool waveA = tid < 256;              // wave-uniform
   const bool isA = tid < 8 * P;
   const int pa = min(tid >> 3, P - 1), q = tid & 7;
+  const bool isB = tid >= 256 && tid - 256 < AP;
+  const int e = min(max(tid - 256, 0), AP - 1);
+  const int b = e / P, p = e - b * P;
   uint32_t coff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) coff[u] = (uint32_t)(pa + P * min(q + 8 * u, P - 1)) * 8u;
   const uint32_t hoff = (uint32_t)p * (W * 8u);
+  const uint32_t cstride = (uint32_t)(P * P) * 8u;
   const int fd = full_dir(d, b);
-  double r_e = c.rvec[e], hq_e = c.hq[e];
-  const double tv_e = c.tvec[e];
-  {
+  double r_e = 0.0, hq_e = 0.0, tv_e = 0.0;
+  if (!waveA) {
+    r_e = c.rvec[e]; hq_e = c.hq[e]; tv_e = c.tvec[e];
     const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[e];
     if (isB) { th[e] = t0; lz[e] = l0; }
   }
   if (tid < 32) rhs[tid] = 0.0;
-  if (tid < 32 + 2 * BW + 2) dlp[tid] = 0.0;
+  if (tid < 2 * DLS) dlp[tid] = 0.0;
   for (int x = tid; x < A * A; x += nthr) htab[x] = hrow(d, x / A, x % A) * P * W * 8;
   for (int x = tid; x < n_steps + 4; x += nthr) sdir[x] = step_dir(d, min(x, n_steps - 1), n_phi);
   const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
   // H2 and C were written by other XCDs (k_pg_reduce, k_factor): a first touch costs a trip to HBM, far longer
-  // than a step of the chain.  Pull both into this XCD's L2 once, in one batch of wide loads, so that the
-  // per-step register prefetch only ever sees L2 hits.
-  {
-    double wsum = 0.0;
-    auto warm = [&](const double* src, int count) {
-      const double2* s2 = (const double2*)src;
+  // than a step of the chain.  Touch both once with fire-and-forget wide loads so that the per-step register
+  // prefetch only ever sees L2 hits.
+  if (n_steps > 0) {
+    v2d w0 = {0, 0}, w1 = {0, 0}, w2 = {0, 0}, w3 = {0, 0};
+    auto touch = [&](const double* src, int count) {
       const int n2 = count / 2;
-      constexpr int UN = 8;
-      for (int base = 0; base < n2; base += nthr * UN) {
-        double2 v[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) v[u] = s2[min(base + tid + nthr * u, n2 - 1)];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) wsum += v[u].x + v[u].y;
+      for (int x = tid; x < n2; x += 4 * nthr) {
+        const uint32_t o = (uint32_t)x * 16u, st4 = (uint32_t)nthr * 16u, lim = (uint32_t)(n2 - 1) * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w1) : "v"(min(o + st4, lim)), "s"(src));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w2) : "v"(min(o + 2 * st4, lim)), "s"(src));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w3) : "v"(min(o + 3 * st4, lim)), "s"(src));
       }
     };
-    if (n_steps > 0) { warm(c.H2, d.R * P * W); warm(c.Cmat, A * P * P); }
-    if (wsum == 1.2345e300 && tid == 0) dyn->status |= 0x80000000u;     // never true: keeps the loads alive
+    touch(c.H2, d.R * P * W);
+    touch(c.Cmat, A * P * P);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) :: "memory");
   }
   __syncthreads();
-  // branch-free loads (every lane reads valid addresses).  A set is refilled right after its last use, so the
-  // loaded values land in the registers the loop carries.
-  auto issueH = [&](SweepPre<BW>& s, int a) {
+  // the hand-counted waits below start from an empty queue; naming the registers that the setup loaded makes
+  // the compiler place its own (tracked) waits for them here instead of inside the loop
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_e), "+v"(hq_e), "+v"(tv_e) :: "memory");
+  auto issueH = [&](SweepH<BW>& s, int a) {      // branch-free: every lane reads a valid address
     const uint32_t off = (uint32_t)htab[b * A + a] + hoff;
-    s.h[0] = sweep_ld16<0>(c.H2, off);
-    if constexpr (BW >= 1) s.h[1] = sweep_ld16<16>(c.H2, off);
-    if constexpr (BW >= 2) s.h[2] = sweep_ld16<32>(c.H2, off);
-    if constexpr (BW >= 3) s.h[3] = sweep_ld16<48>(c.H2, off);
-    if constexpr (BW >= 4) s.h[4] = sweep_ld16<64>(c.H2, off);
-    if constexpr (BW >= 5) s.h[5] = sweep_ld16<80>(c.H2, off);
+    sweep_ld16<0>(s.h[0], c.H2, off);
+    if constexpr (BW >= 1) sweep_ld16<16>(s.h[1], c.H2, off);
+    if constexpr (BW >= 2) sweep_ld16<32>(s.h[2], c.H2, off);
+    if constexpr (BW >= 3) sweep_ld16<48>(s.h[3], c.H2, off);
+    if constexpr (BW >= 4) sweep_ld16<64>(s.h[4], c.H2, off);
+    if constexpr (BW >= 5) sweep_ld16<80>(s.h[5], c.H2, off);
   };
-  const uint32_t cstride = (uint32_t)(P * P) * 8u;
-  auto issueC = [&](SweepPre<BW>& s, int a) {    // waves 0-3 only
+  auto band_dot = [&](const SweepH<BW>& s, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
+    double dv[2 * BW + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * BW + 2; ++k) dv[k] = dl[k];
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k <= BW; ++k) v += s.h[k].x * dv[2 * k] + s.h[k].y * dv[2 * k + 1];     // last .y is the zero pad
+    return v;
+  };
+  struct CSet { double v[4]; };
+  auto issueC = [&](CSet& s, int a) {
     const uint32_t base = (uint32_t)a * cstride;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s.cv[u] = sweep_ld8(c.Cmat, base + coff[u]);
+    for (int u = 0; u < 4; ++u) sweep_ld8(s.v[u], c.Cmat, base + coff[u]);
   };
-  auto waitC = [&](SweepPre<BW>& s) {            // younger: H(this set), C + H (other set)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.cv[0]), "+v"(s.cv[1]), "+v"(s.cv[2]), "+v"(s.cv[3]) : "n"(2 * (BW + 1) + 4));
-  };
-  auto waitH = [&](SweepPre<BW>& s) {
-    // younger: C + H of the other set and this set's refilled C (waves 0-3); H of the other set (other waves)
+  // one step.  PAR = parity of the step (delta buffer written), `a` its direction, an = next direction (-1: none),
+  // aprev = previous direction (-1: none), a2 = direction two steps ahead (prefetch target).
+  //   cs : C_a values (waves 0-3), refilled with C_{a2}
+  //   hl : H_{b, aprev} (lagging update), refilled with H_{b, an}... see the call sites for the rotation
+  auto step = [&](int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
+    double* dl_w = dlp + par * DLS;                  // written in P1 of this step
+    const double* dl_prev = dlp + (par ^ 1) * DLS;   // delta of the previous step
     if (waveA) {
-      if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(BW + 9));
-      if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(BW + 9));
-      if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(BW + 9));
-      if constexpr (BW == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]) : "n"(BW + 9));
-      if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(BW + 9));
-      if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(BW + 9));
-    } else {
-      if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(BW + 1));
-      if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(BW + 1));
-      if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(BW + 1));
-      if constexpr (BW == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]) : "n"(BW + 1));
-      if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(BW + 1));
-      if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(BW + 1));
-    }
-  };
-#ifdef BFMMM_TIMELINE
-  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SWT(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tlast; tlast = now_; } while (0)
-  unsigned long long tlast = clock64();
-#else
-#define SWT(i) do { } while (0)
-#endif
-  auto step = [&](SweepPre<BW>& s, int a, int an, int a_refill) {
-    SWT(4);
-    // phase A (waves 0-3): theta_a <- C_a rhs + L_a z_a
-    if (waveA) {
+      // ---- P1, critical chain: theta_a <- C_a rhs + L_a z_a
       const double lza = lz[a * P + pa], tha = th[a * P + pa];
       const double x0 = rhs[q], x1 = rhs[q + 8], x2 = rhs[q + 16], x3 = rhs[q + 24];
-      waitC(s);
-      double acc = (s.cv[0] * x0 + s.cv[1] * x1) + (s.cv[2] * x2 + s.cv[3] * x3);
-      issueC(s, a_refill);
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(cs.v[0]), "+v"(cs.v[1]), "+v"(cs.v[2]), "+v"(cs.v[3]));   // younger: the other C set
+      double acc = (cs.v[0] * x0 + cs.v[1] * x1) + (cs.v[2] * x2 + cs.v[3] * x3);
+      issueC(cs, a_refill);
       acc = dpp_add<0xB1>(acc);     // quad_perm [1,0,3,2]
       acc = dpp_add<0x4E>(acc);     // quad_perm [2,3,0,1]
       acc = dpp_add<0x141>(acc);    // row_half_mirror: the 8 lanes of a row now hold its sum
       if (isA && q == 0) {
         const double nw = acc + lza;
-        dlp[BW + pa] = nw - tha;
+        dl_w[BW + pa] = nw - tha;
         th[a * P + pa] = nw;
       }
+    } else {
+      // ---- P1, off the chain: lagging update with the previous step's delta (b == a was updated urgently)
+      sweep_wait_h<BW + 1, BW>(h_lag);               // younger: h_cur's refill of the previous step
+      if (aprev >= 0 && b != a) r_e -= band_dot(h_lag, dl_prev + p);
+      issueH(h_lag, an >= 0 ? an : a);               // becomes H_{b, a_next}: used in P2 of the next step or P1 after it
     }
-    SWT(0);
     lds_barrier();
-    SWT(1);
-    // phase B: r_b -= H_ba dl ; (H_aa theta_a) follows theta_a ; rhs of the next direction
-    const double* dl = dlp + p;              // dl[k] = delta[p + k - BW]
-    double dv[2 * BW + 2];
-#pragma unroll
-    for (int k = 0; k < 2 * BW + 2; ++k) dv[k] = dl[k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SWT(5);
-    waitH(s);
-    SWT(6);
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k <= BW; ++k) v += s.h[k].x * dv[2 * k] + s.h[k].y * dv[2 * k + 1];   // last .y is the zero pad
-    issueH(s, a_refill);
-    SWT(7);
-    r_e -= v;
-    if (b == a) hq_e += v;
-    if (isB && b == an) rhs[p] = f * (r_e + hq_e);
-    SWT(2);
+    // ---- P2: the rows of the next direction take this step's delta now and publish the next rhs
+    if (!waveA && an >= 0) {
+      sweep_wait_h<BW + 1, BW>(h_cur);               // younger: the refill just issued in P1
+      if (isB && b == an) {
+        r_e -= band_dot(h_cur, dl_w + p);
+        rhs[p] = f * (r_e + hq_e);
+      }
+    }
     lds_barrier();
-    SWT(3);
   };
   if (n_steps > 0) {
     const int a0 = sdir[0];
     if (isB && b == a0) rhs[p] = f * (r_e + hq_e);
-    SweepPre<BW> s0, s1;
-    // the hand-counted waits below start from an empty queue; naming the registers that the setup loaded makes
-    // the compiler place its own (tracked) waits for them here instead of inside the loop
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_e), "+v"(hq_e) :: "memory");
+    CSet c0 = {}, c1 = {};
+    SweepH<BW> h0 = {}, h1 = {};             // h0 = H_{b, a_st} for even st, h1 for odd st
     {
       const int a1i = sdir[1];
-      if (waveA) issueC(s0, a0);
-      issueH(s0, a0);                                    // same issue order as the steady state
-      if (waveA) issueC(s1, a1i);
-      issueH(s1, a1i);
+      if (waveA) { issueC(c0, a0); issueC(c1, a1i); }
+      else { issueH(h0, a0); issueH(h1, a1i); }     // same issue order as the steady state
     }
     lds_barrier();
     int a = __builtin_amdgcn_readfirstlane(sdir[0]), a1 = __builtin_amdgcn_readfirstlane(sdir[1]);
     int a2 = __builtin_amdgcn_readfirstlane(sdir[2]), a3 = __builtin_amdgcn_readfirstlane(sdir[3]);
+    int aprev = -1;
+    // step st (even): P1 lagging uses H_{b, a_{st-1}} = h1, then h1 <- H_{b, a_{st+1}};  P2 uses H_{b, a_st} = h0.
+    // step st+1     : P1 lagging uses h0 (H_{b, a_st}), then h0 <- H_{b, a_{st+2}};       P2 uses h1.
     for (int st = 0; st < n_steps; st += 2) {
       const int v4 = sdir[min(st + 4, n_steps + 2)], v5 = sdir[min(st + 5, n_steps + 3)];   // consumed after the steps
-      step(s0, a, (st + 1 < n_steps) ? a1 : -1, a2);
-      if (st + 1 < n_steps) step(s1, a1, (st + 2 < n_steps) ? a2 : -1, a3);
-      a = a2; a1 = a3;
+      step(0, c0, h1, h0, a, (st + 1 < n_steps) ? a1 : -1, aprev, a2);
+      if (st + 1 < n_steps) step(1, c1, h0, h1, a1, (st + 2 < n_steps) ? a2 : -1, a, a3);
+      aprev = a1; a = a2; a1 = a3;
       a2 = __builtin_amdgcn_readfirstlane(v4); a3 = __builtin_amdgcn_readfirstlane(v5);
     }
+    // the last step's delta still has to reach every row (nobody was "next")
+    if (!waveA) {
+      const int last = n_steps - 1;
+      const int al = __builtin_amdgcn_readfirstlane(sdir[last]);
+      (void)al;
+      if (last & 1) { sweep_wait_h<0, BW>(h1); r_e -= band_dot(h1, dlp + DLS + p); }
+      else { sweep_wait_h<0, BW>(h0); r_e -= band_dot(h0, dlp + p); }
+    }
     // drain the prefetches of the (clamped) tail before their registers are reused
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.h[0]), "+v"(s1.h[0]), "+v"(s0.cv[0]), "+v"(s1.cv[0]) :: "memory");
+    sweep_wait_h<0, BW>(h0);
+    sweep_wait_h<0, BW>(h1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0.v[0]), "+v"(c0.v[1]), "+v"(c0.v[2]), "+v"(c0.v[3]), "+v"(c1.v[0]), "+v"(c1.v[1]), "+v"(c1.v[2]), "+v"(c1.v[3]) :: "memory");
   }
-#ifdef BFMMM_TIMELINE
-  if (tid == 0) for (int x = 0; x < 8; ++x) dyn->stamps[24 + x] = tk[x];
-#endif
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
   const double th_e = th[e];
   if (mask & U_SIGMA) {
@@ -833,7 +833,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   } else if (tid == 0) {
     c.c_sigma[slot] = dyn->sigma2;
   }
-
   // ---------------- publish theta and its chain slots -------------------------------------------
   double* s_nu = c.c_nu + (size_t)slot * K * P;
   double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
@@ -909,9 +908,9 @@ void launch_factor(const Ctx& c, hipStream_t st) {
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
-  if (d.P <= 32 && d.A * d.P <= SW_THREADS && d.BW <= 5) {      // fast path: register-resident sweep
-    const int nthr = (std::max(d.A * d.P, 256) + 63) / 64 * 64;
-    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 32 + 2 * d.BW + 2 + 16) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
+  if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
+    const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
+    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
     switch (d.BW) {
       case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1), dim3(nthr), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1), dim3(nthr), lds, st, c); break;
