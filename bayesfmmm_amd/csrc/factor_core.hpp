@@ -6,67 +6,118 @@
 //     X    = U^-1   (row-major),   L = X' = chol_lower(Prec^-1),   C = L L' = Prec^-1,   Lz = L z
 // which are exactly the covariance and the factor the reference's  arma::mvnrnd(C b, C)  uses
 // (UpdateNu.h:67-69, UpdatePhi.h:79-82, UpdateEta.h:85-87, UpdateXi.h:80-83).
+//
+// The two triangular recursions are chains of P dependent pivots, so they run in the registers of
+// ONE wave (lane i owns band row i of U, then column i of X; the pivot row travels by v_readlane)
+// instead of through LDS; C = X'X is 16x16x4 fp64 MFMA tiles on all four waves.
 // 256 threads; returns true on the calling thread if a non-positive pivot was met.
 #pragma once
 #include "model.hpp"
 
 namespace bfmmm {
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ inline double readlane_f64(double v, int lane) {     // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// wave 0: reverse Cholesky, X = U^-1 (written to LDS), L z
+template <int PP, int BWT>
+__device__ inline bool factor_wave(const double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
+  double s[BWT + 1], u[BWT + 1];       // s[t] = Prec(i, i + t),  u[t] = U(i, i + t)
+#pragma unroll
+  for (int t = 0; t <= BWT; ++t) {
+    const int j = lane + t;
+    s[t] = (lane < P && j < P) ? S[lane + PP * j] : 0.0;
+    u[t] = 0.0;
+  }
+  double rinv = 0.0;                   // 1 / U(i, i)
+  bool bad = false;
+  for (int k = P - 1; k >= 0; --k) {
+    double dloc = s[0];
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) dloc -= u[t] * u[t];
+    const double dk = readlane_f64(dloc, k);
+    if (!(dk > 0.0)) bad = true;
+    const double ukk = sqrt(dk);
+    const double rk = 1.0 / ukk;
+    double uk[BWT + 1];
+#pragma unroll
+    for (int m = 1; m < BWT; ++m) uk[m] = readlane_f64(u[m], k);      // U(k, k + m)
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) {   // row i = k - t:  U(i, k) = (Prec(i, k) - sum_m U(i, k + m) U(k, k + m)) / U(k, k)
+      double acc = s[t];
+#pragma unroll
+      for (int m = 1; m <= BWT - t; ++m) acc -= u[t + m] * uk[m];
+      if (lane == k - t) u[t] = acc * rk;
+    }
+    if (lane == k) { u[0] = ukk; rinv = rk; }
+  }
+  // column `lane` of X = U^-1 by back substitution; xw[t] = X(i + t, lane)
+  const double zreg = (lane < P) ? zv[lane] : 0.0;
+  double xw[BWT + 1];
+#pragma unroll
+  for (int t = 0; t <= BWT; ++t) xw[t] = 0.0;
+  double lzacc = 0.0;
+  for (int i = P - 1; i >= 0; --i) {
+    const double ri = readlane_f64(rinv, i);
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) acc += readlane_f64(u[t], i) * xw[t];
+    const double xi = (lane == i) ? ri : ((lane > i) ? -(acc * ri) : 0.0);
+    if (lane < PP) X[i * PP + lane] = xi;
+    lzacc += xi * readlane_f64(zreg, i);
+#pragma unroll
+    for (int t = BWT; t >= 2; --t) xw[t] = xw[t - 1];
+    xw[1] = xi;
+  }
+  if (lane < P) Lz_out[lane] = lzacc;
+  return bad;
+}
+
 template <int PP>
 __device__ inline bool factor_core(double* S, double* X, const double* zv, int P, int bw, double* Cg, double* Lg,
                                    double* Lz_out, int tid) {
   bool bad = false;
   if (tid < 64) {
-    // reverse Cholesky Prec = U U', one wave, LDS traffic is wave-ordered
-    for (int k = P - 1; k >= 0; --k) {
-      const int jhi = min(k + bw, P - 1);
-      double dkk = S[k + PP * k];
-      for (int jj = k + 1; jj <= jhi; ++jj) { const double u = S[k + PP * jj]; dkk -= u * u; }
-      if (!(dkk > 0.0)) bad = true;
-      const double ukk = sqrt(dkk);
-      const int i = k - 1 - tid;
-      double uik = 0.0;
-      if (tid < bw && i >= 0) {
-        double acc = S[i + PP * k];
-        const int j2 = min(i + bw, P - 1);
-        for (int jj = k + 1; jj <= j2; ++jj) acc -= S[i + PP * jj] * S[k + PP * jj];
-        uik = acc / ukk;
+    switch (bw) {
+      case 0: bad = factor_wave<PP, 0>(S, X, zv, P, Lz_out, tid); break;
+      case 1: bad = factor_wave<PP, 1>(S, X, zv, P, Lz_out, tid); break;
+      case 2: bad = factor_wave<PP, 2>(S, X, zv, P, Lz_out, tid); break;
+      case 3: bad = factor_wave<PP, 3>(S, X, zv, P, Lz_out, tid); break;
+      case 4: bad = factor_wave<PP, 4>(S, X, zv, P, Lz_out, tid); break;
+      default: bad = factor_wave<PP, 5>(S, X, zv, P, Lz_out, tid); break;
+    }
+  }
+  __syncthreads();
+  // C = X' X on the matrix cores: tile (pt, qt) of 16 x 16, K = P rounded up to 4 (rows k > min(p, q) of X are zero)
+  {
+    constexpr int NTL = PP / 16;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int kend = (P + 3) & ~3;
+    for (int tt = wave; tt < NTL * NTL; tt += 4) {
+      const int pt = tt / NTL, qt = tt - pt * NTL;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      const double* xa = X + (lane >> 4) * PP + pt * 16 + (lane & 15);
+      const double* xb = X + (lane >> 4) * PP + qt * 16 + (lane & 15);
+      for (int k0 = 0; k0 < kend; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k0 * PP], xb[k0 * PP], acc, 0, 0, 0);
+      const int q = qt * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = pt * 16 + (lane >> 4) + 4 * r;
+        if (p < P && q < P) Cg[q + (size_t)P * p] = acc[r];     // C is symmetric: the transposed store is coalesced
       }
-      __builtin_amdgcn_wave_barrier();
-      if (tid == 0) S[k + PP * k] = ukk;
-      if (tid < bw && i >= 0) S[i + PP * k] = uik;
-      __builtin_amdgcn_wave_barrier();
     }
   }
-  __syncthreads();
-  if (tid < P) {
-    // column c of X = U^-1 by back substitution (banded U)
-    const int cc = tid;
-    X[cc * PP + cc] = 1.0 / S[cc + PP * cc];
-    for (int i = cc - 1; i >= 0; --i) {
-      double acc = 0.0;
-      const int j2 = min(i + bw, cc);
-      for (int jj = i + 1; jj <= j2; ++jj) acc += S[i + PP * jj] * X[jj * PP + cc];
-      X[i * PP + cc] = -acc / S[i + PP * i];
+  if (Lg)
+    for (int e = tid; e < PP * PP; e += 256) {
+      const int p = e & (PP - 1), q = e / PP;
+      if (p < P && q < P) Lg[p + (size_t)P * q] = (q <= p) ? X[q * PP + p] : 0.0;
     }
-  }
-  __syncthreads();
-  // L = X' (lower), C = L L', L z
-  for (int e = tid; e < PP * PP; e += 256) {
-    const int p = e & (PP - 1), q = e / PP;
-    if (p < P && q < P) {
-      const int kmax = min(p, q);
-      double acc = 0.0;
-      for (int k = 0; k <= kmax; ++k) acc += X[k * PP + p] * X[k * PP + q];
-      Cg[p + (size_t)P * q] = acc;
-      if (Lg) Lg[p + (size_t)P * q] = (q <= p) ? X[q * PP + p] : 0.0;
-    }
-  }
-  if (tid < P) {
-    double acc = 0.0;
-    for (int q = 0; q <= tid; ++q) acc += X[q * PP + tid] * zv[q];
-    Lz_out[tid] = acc;
-  }
   return bad;
 }
 

@@ -27,7 +27,7 @@
 
 namespace bfmmm {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
+
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // counter (vmcnt(0)), which would serialise the global prefetches the sweep keeps in flight
@@ -736,9 +736,18 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   // aprev = previous direction (-1: none), a2 = direction two steps ahead (prefetch target).
   //   cs : C_a values (waves 0-3), refilled with C_{a2}
   //   hl : H_{b, aprev} (lagging update), refilled with H_{b, an}... see the call sites for the rotation
+#ifdef BFMMM_TIMELINE
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = clock64();
+#define SWT(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tlast; tlast = now_; } while (0)
+  if (tid == 0) dyn->stamps[24] = wall_clock64();
+#else
+#define SWT(i) do { } while (0)
+#endif
   auto step = [&](int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
     double* dl_w = dlp + par * DLS;                  // written in P1 of this step
     const double* dl_prev = dlp + (par ^ 1) * DLS;   // delta of the previous step
+    SWT(0);
     if (waveA) {
       // ---- P1, critical chain: theta_a <- C_a rhs + L_a z_a
       const double lza = lz[a * P + pa], tha = th[a * P + pa];
@@ -760,7 +769,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
       if (aprev >= 0 && b != a) r_e -= band_dot(h_lag, dl_prev + p);
       issueH(h_lag, an >= 0 ? an : a);               // becomes H_{b, a_next}: used in P2 of the next step or P1 after it
     }
+    SWT(1);
     lds_barrier();
+    SWT(2);
     // ---- P2: the rows of the next direction take this step's delta now and publish the next rhs
     if (!waveA && an >= 0) {
       sweep_wait_h<BW + 1, BW>(h_cur);               // younger: the refill just issued in P1
@@ -769,7 +780,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
         rhs[p] = f * (r_e + hq_e);
       }
     }
+    SWT(3);
     lds_barrier();
+    SWT(4);
   };
   if (n_steps > 0) {
     const int a0 = sdir[0];
@@ -794,6 +807,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
       aprev = a1; a = a2; a1 = a3;
       a2 = __builtin_amdgcn_readfirstlane(v4); a3 = __builtin_amdgcn_readfirstlane(v5);
     }
+#ifdef BFMMM_TIMELINE
+    if (tid == 0) { dyn->stamps[25] = wall_clock64(); for (int x = 0; x < 5; ++x) dyn->stamps[26 + x] = tk[x]; }
+    if (tid == 256) for (int x = 0; x < 5; ++x) dyn->stamps[10 + x] = tk[x];
+#endif
     // the last step's delta still has to reach every row (nobody was "next")
     if (!waveA) {
       const int last = n_steps - 1;

@@ -22,7 +22,10 @@ for k, nm in enumerate(names):
 
 
 print("pair_gram (max over WGs, rel. kernel start): begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[[20,21,22,23,30,31]]-st[2]))
-print("sweep wave0 clocks/step: phaseA %d  barrier1 %d | B: lds-reads %d  waitH %d  fma+issueH %d  tail %d | barrier2 %d  between %d" % tuple(np.array(smp.get_state("stamps"))[[24,25,29,30,31,26,27,28]] / 21))
+st_ = np.array(smp.get_state("stamps"))
+print("sweep: setup %.2f us, loop %.2f us, tail %.2f us" % ((st_[24]-st_[8])*0.01, (st_[25]-st_[24])*0.01, (st_[9]-st_[25])*0.01))
+print("sweep clocks/step  A-wave0: between %d  P1 %d  barrier %d  P2 %d  barrier %d" % tuple(st_[26:31]/21))
+print("sweep clocks/step  B-wave0: between %d  P1 %d  barrier %d  P2 %d  barrier %d" % tuple(st_[10:15]/21))
 try:
     tr = np.array(smp.get_state("wgtrace")).reshape(-1, 3)
     nwg = 250
