@@ -293,12 +293,13 @@ __device__ inline double band_mv(const double* __restrict__ Hb, const double* v,
 // A non-positive pivot sets dyn->status bit 0 (the reference would take arma::pinv / the
 // eigen-decomposition fallback of mvnrnd there).
 // ---------------------------------------------------------------------------------------------
-template <int PP>
+template <int PP, int BW>
 __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   TIMELINE(c, 3);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
+  constexpr int W = 2 * BW + 2;     // doubles per row of an H2 block: G(p, p - BW .. p + BW), 0
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper
     job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
@@ -306,68 +307,110 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   }
   const int a = blockIdx.x;
   const int j = a / MD, mt = a - j * MD;
-  double* S = smem;                 // PP x PP : Prec, then U in its upper triangle (col-major, S[i + PP*k])
+  const int AP = A * P, PS = P + 2 * BW + 1;
+  double* S = smem;                 // PP x PP : Prec (col-major, S[i + PP*k])
   double* X = S + PP * PP;          // PP x PP : U^-1, row-major X[i*PP + c]
-  double* th = X + PP * PP;         // A x P
-  double* part = th + A * P;        // A x P
-  double* zv = part + A * P;        // PP
-  double* hstage = zv + PP;         // A x LG : row blocks H_{a,.}
-  {
-    // theta of the active directions and the row blocks H_{a,b}, b = 0..A-1 (staged in X, free until later)
-    constexpr int UN = 4;
-    for (int base = 0; base < A * P; base += 256 * UN) {
-      double v[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int e = min(base + tid + 256 * u, A * P - 1);
-        const int b = e / P, p = e - b * P;
-        v[u] = c.theta[(size_t)full_dir(d, b) * P + p];
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) { const int e = base + tid + 256 * u; if (e < A * P) th[e] = v[u]; }
-    }
-    double* Hrow = hstage;
-    for (int base = 0; base < A * d.LG; base += 256 * UN) {
-      double v[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int e = min(base + tid + 256 * u, A * d.LG - 1);
-        const int b = e / d.LG, off = e - b * d.LG;
-        v[u] = c.H[(size_t)hrow(d, a, b) * d.LG + off];
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) { const int e = base + tid + 256 * u; if (e < A * d.LG) Hrow[e] = v[u]; }
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < A * P; e += 256) {
-    const int b = e / P, p = e - b * P;
-    part[e] = band_mv(hstage + (size_t)b * d.LG, th + b * P, P, d.BW, p);
-  }
-  __syncthreads();
-  if (tid < P) {
-    double acc = c.tvec[a * P + tid];
-    for (int b = 0; b < A; ++b) acc -= part[b * P + tid];
-    c.rvec[a * P + tid] = acc;
-    c.hq[a * P + tid] = part[a * P + tid];
-  }
+  double* thp = X + PP * PP;        // A x PS : theta_b with BW zero pads before and BW + 1 after
+  double* part = thp + A * PS;      // A x P  : (H_ab theta_b)[p]
+  double* zv = part + AP;           // PP
+  double* hb2 = zv + PP;            // P x W  : rows of H_aa
+  double* dsc = hb2 + P * W;        // 16     : delta(j, .)
   const bool upd_nu = (mt == 0) && (c.mask & U_NU);
   const bool upd_phi = (mt > 0) && (c.mask & U_PHI);
-  if (!upd_nu && !upd_phi) return;
+  const bool upd = upd_nu || upd_phi;
   const Dyn* dyn = c.dyn;
+  // ---- everything this workgroup needs from global memory is requested up front, in one batch ----
+  constexpr int MAXI = 4;           // (b, p) items per thread and pass
+  v2d hreg[MAXI][BW + 1];
+  double tval[MAXI];
+  {
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+      const int e = min(tid + 256 * it, AP - 1);
+      const int b = e / P, p = e - b * P;
+      tval[it] = c.theta[(size_t)full_dir(d, b) * P + p];
+      const v2d* row = (const v2d*)(c.H2 + ((size_t)hrow(d, a, b) * P + p) * W);
+#pragma unroll
+      for (int k = 0; k <= BW; ++k) hreg[it][k] = row[k];
+    }
+  }
+  const double tv0 = c.tvec[a * P + min(tid >> 3, P - 1)];      // t_a[p] of the r-reduction's first pass
+  const double dlt = (mt > 0 && tid < M) ? c.delta[j + (size_t)K * tid] : 1.0;
   const double f = dyn->beta / dyn->sigma2;
-  const double* Hb = hstage + (size_t)a * d.LG;
+  const double tau_j = dyn->tau[j];
+  for (int x = tid; x < A * PS; x += 256) thp[x] = 0.0;
+  if (upd && tid >= 64 && tid < 64 + P) {     // the direction's normal variates, while the loads are in flight
+    const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+    const uint32_t idx0 = (mt == 0) ? (uint32_t)(j * P) : (uint32_t)((j * M + (mt - 1)) * P);
+    zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int e = tid + 256 * it;
+    if (e < AP) { const int b = e / P, p = e - b * P; thp[b * PS + BW + p] = tval[it]; }
+  }
+  for (int e = tid + 256 * MAXI; e < AP; e += 256) {     // beyond the batched part (more than 1024 elements)
+    const int b = e / P, p = e - b * P;
+    thp[b * PS + BW + p] = c.theta[(size_t)full_dir(d, b) * P + p];
+  }
+  if (tid < 16) dsc[tid] = dlt;
+  __syncthreads();
+  // ---- (H_ab theta_b)[p] for every b; the rows of H_aa are kept for the precision matrix ----
+  for (int base = 0; base < AP; base += 256 * MAXI) {
+    if (base > 0) {                 // more than 1024 elements: further passes reload their rows (rare)
+#pragma unroll
+      for (int it = 0; it < MAXI; ++it) {
+        const int e = min(base + tid + 256 * it, AP - 1);
+        const int b = e / P, p = e - b * P;
+        const v2d* row = (const v2d*)(c.H2 + ((size_t)hrow(d, a, b) * P + p) * W);
+#pragma unroll
+        for (int k = 0; k <= BW; ++k) hreg[it][k] = row[k];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+      const int e = base + tid + 256 * it;
+      if (e < AP) {
+        const int b = e / P, p = e - b * P;
+        const double* tb = thp + b * PS + p;        // tb[k] = theta_b[p + k - BW]
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k <= BW; ++k) v += hreg[it][k].x * tb[2 * k] + hreg[it][k].y * tb[2 * k + 1];
+        part[e] = v;
+        if (b == a) {
+#pragma unroll
+          for (int k = 0; k <= BW; ++k) { hb2[p * W + 2 * k] = hreg[it][k].x; hb2[p * W + 2 * k + 1] = hreg[it][k].y; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- r_a = t_a - sum_b H_ab theta_b : 8 lanes per p, fixed summation order ----
+  for (int p0 = 0; p0 < P; p0 += 32) {
+    const int p = p0 + (tid >> 3), g = tid & 7;
+    double acc = 0.0;
+    if (p < P)
+      for (int b = g; b < A; b += 8) acc += part[b * P + p];
+    acc = dpp_add<0xB1>(acc);
+    acc = dpp_add<0x4E>(acc);
+    acc = dpp_add<0x141>(acc);
+    const double tvp = (p0 == 0) ? tv0 : c.tvec[a * P + min(p, P - 1)];
+    if (p < P && g == 0) {
+      c.rvec[a * P + p] = tvp - acc;
+      c.hq[a * P + p] = part[a * P + p];
+    }
+  }
+  if (!upd) return;
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
-  if (mt > 0)
-    for (int m2 = 0; m2 < mt; ++m2) tt *= c.delta[j + (size_t)K * m2];
-  const double tau_j = dyn->tau[j];
+  for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
   for (int e = tid; e < PP * PP; e += 256) {
     const int p = e & (PP - 1), q = e / PP;
     double v = 0.0;
     if (p < P && q < P) {
       const int lo = min(p, q), dd = max(p, q) - lo;
-      v = (dd <= d.BW) ? f * Hb[dd * P + lo] : 0.0;
+      v = (dd <= BW) ? f * hb2[lo * W + BW + dd] : 0.0;
       if (mt == 0) {
         if (d.mv) { if (p == q) v += 1.0 / tau_j; }               // UpdateNu.h:197 (MV)
         else v += tau_j * c.Pmat[p + (size_t)P * q];                // UpdateNu.h:66
@@ -377,11 +420,6 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     }
     S[e] = v;
     X[e] = 0.0;
-  }
-  if (tid >= 64 && tid < 64 + P) {
-    const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-    const uint32_t idx0 = (mt == 0) ? (uint32_t)(j * P) : (uint32_t)((j * M + (mt - 1)) * P);
-    zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
   }
   __syncthreads();
   const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
@@ -582,21 +620,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
 //     LDS traffic besides rhs;
 //   * two LDS-only barriers per step; all indices are computed once.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ inline double dpp_add(double v) {   // v + dpp_permute<CTRL>(v) within a row of 16 lanes
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return v + __hiloint2double(hi, lo);
-}
-__device__ inline double row16_sum(double v) {   // every lane of a 16-lane row gets the row's sum
-  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);    // row_half_mirror
-  v = dpp_add<0x140>(v);    // row_mirror
-  return v;
-}
-
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 __device__ inline const double* ptr_off(const double* base, uint32_t byte_off) {   // uniform base + 32-bit lane offset
   return (const double*)((const char*)base + byte_off);
@@ -914,13 +937,26 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, c, NKS);
 }
 
+template <int PP>
+static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st) {
+  switch (c.d.BW) {
+    case 0: hipLaunchKernelGGL((k_factor<PP, 0>), dim3(grid), dim3(256), lds, st, c); break;
+    case 1: hipLaunchKernelGGL((k_factor<PP, 1>), dim3(grid), dim3(256), lds, st, c); break;
+    case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(grid), dim3(256), lds, st, c); break;
+    case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(grid), dim3(256), lds, st, c); break;
+    case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(grid), dim3(256), lds, st, c); break;
+    default: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid), dim3(256), lds, st, c); break;
+  }
+}
+
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
-  const size_t lds = (2 * (size_t)PP * PP + 2 * (size_t)c.d.A * c.d.P + PP + (size_t)c.d.A * c.d.LG) * sizeof(double);
+  const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
+  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1;   // + sigma^2's gamma variate
   const int grid = c.d.A + (n_draw + 255) / 256;
-  if (PP == 32) hipLaunchKernelGGL(k_factor<32>, dim3(grid), dim3(256), lds, st, c);
-  else hipLaunchKernelGGL(k_factor<64>, dim3(grid), dim3(256), lds, st, c);
+  if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
+  else launch_factor_pp<64>(c, grid, lds, st);
 }
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
@@ -954,8 +990,12 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
   set_max_lds((const void*)k_pair_gram);
-  set_max_lds((const void*)k_factor<32>);
-  set_max_lds((const void*)k_factor<64>);
+  set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
+  set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);
+  set_max_lds((const void*)k_factor<32, 2>); set_max_lds((const void*)k_factor<64, 2>);
+  set_max_lds((const void*)k_factor<32, 3>); set_max_lds((const void*)k_factor<64, 3>);
+  set_max_lds((const void*)k_factor<32, 4>); set_max_lds((const void*)k_factor<64, 4>);
+  set_max_lds((const void*)k_factor<32, 5>); set_max_lds((const void*)k_factor<64, 5>);
 }
 
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {
