@@ -508,7 +508,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   else if (s == "sigma_sq") { if (need(1)) return 1; out[0] = dyn.sigma2; }
   else if (s == "loglik") { if (need(1)) return 1; out[0] = dyn.loglik; }
   else if (s == "status") { if (need(1)) return 1; out[0] = (double)dyn.status; }
-  else if (s == "stamps") { if (need(32)) return 1; for (int q = 0; q < 32; ++q) out[q] = (double)(dyn.stamps[q] % 100000000000ULL); }
+  else if (s == "stamps") { if (need(64)) return 1; for (int q = 0; q < 64; ++q) out[q] = (double)(dyn.stamps[q] % 100000000000ULL); }
 #ifdef BFMMM_TIMELINE
   else if (s == "wgtrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_wgtrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
 #endif

@@ -25,20 +25,6 @@ __device__ inline double readlane_f64(double v, int lane) {     // lane is wave-
   return __hiloint2double(hi, lo);
 }
 
-template <int CTRL>
-__device__ inline double dpp_add(double v) {   // v + dpp_permute<CTRL>(v) within a row of 16 lanes
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return v + __hiloint2double(hi, lo);
-}
-__device__ inline double row16_sum(double v) {   // every lane of a 16-lane row gets the row's sum
-  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);    // row_half_mirror
-  v = dpp_add<0x140>(v);    // row_mirror
-  return v;
-}
-
 // wave 0: reverse Cholesky, X = U^-1 (written to LDS), L z
 template <int PP, int BWT>
 __device__ inline bool factor_wave(const double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {

@@ -73,14 +73,31 @@ __device__ inline double dotP(const double* a, const double* b, int P) {
   return s;
 }
 
+// the same sum over a whole tile row (entries P .. LPC-1 of the rows are zero): a compile-time trip count, so the
+// 2 LPC LDS reads are issued back to back instead of one dependent read per loop trip
+template <int LPC>
+__device__ inline double dotL(const double* a, const double* b) {
+  double s = 0.0;
+#pragma unroll
+  for (int p = 0; p < LPC; ++p) s += a[p] * b[p];
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Z update.  do_update == 0 only recomputes the partial sums of log Z (used when pi / alpha_3 are
 // sampled with Z held fixed).
 // LDS per group: U[K], GU[K], S (1 row), chi (MMAX), res (32)
 // ------------------------------------------------------------------------------------------------
 template <int BW, int LPC, bool COV>
-__global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
+__global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   TIMELINE(c, 0);
+#ifdef BFMMM_TIMELINE
+  unsigned long long zt[10]; int zi = 0;
+#define ZT() do { zt[zi++] = clock64(); } while (0)
+#else
+#define ZT() do { } while (0)
+#endif
+  ZT();
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
@@ -112,10 +129,12 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
     tU.zero_pads(2 * K + 3, lp);
     if (D > 0) tE.zero_pads(NR, lp);
-    if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
+    if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;   // [M] = 0: pad of the 2-unrolled loops
     tS.row(0)[lp] = cv.s;
   }
+  ZT();
   __syncthreads();
+  ZT();
   // parameter rows seen by this curve: theta itself, or theta + sum_d x_id thetaX (covariate adjustment)
   const double* thb = sTh + lp;
   int ths = P;
@@ -142,38 +161,53 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
     double ucov[KMAX];                 // covariate part of u_k (D > 0)
+    double uk[KMAX];
+    {
+      // u_k = nu_k + sum_m chi_im phi_km for all k at once: the m loop runs two eigenfunctions per trip with the
+      // 2K + 2 LDS reads of a trip in flight together (sChi[M] = 0 pads an odd M; row indices stay inside direction k)
+      double vb[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      double v = 0.0, vb = 0.0;
-      if (k < K && act) {
-        const double* th = thb + (size_t)k * (M + 1) * ths;
-        v = th[0];
-        if (MD > 1)
-          for (int m = 0; m < M; ++m) v += sChi[m] * th[(m + 1) * ths];
-        if (D > 0) {
-          const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
-          vb = tb[0];
-          if (MD > 1)
-            for (int m = 0; m < M; ++m) vb += sChi[m] * tb[(m + 1) * P];
-        }
+      for (int k = 0; k < KMAX; ++k) {
+        uk[k] = (k < K && act) ? thb[(size_t)k * (M + 1) * ths] : 0.0;
+        vb[k] = (D > 0 && k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
       }
-      if (k < K) tU.row(k)[lp] = v;
-      ucov[k] = v - vb;
+      if (MD > 1 && act)
+        for (int m = 0; m < M; m += 2) {
+          const double c0 = sChi[m], c1 = sChi[m + 1];
+          const int r0 = (m + 1), r1 = min(m + 2, M);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+              const double* th = thb + (size_t)k * (M + 1) * ths;
+              uk[k] += c0 * th[r0 * ths] + c1 * th[r1 * ths];
+              if (D > 0) {
+                const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
+                vb[k] += c0 * tb[r0 * P] + c1 * tb[r1 * P];
+              }
+            }
+        }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) tU.row(k)[lp] = uk[k];
+        ucov[k] = uk[k] - vb[k];
+      }
     }
+    ZT();
     __builtin_amdgcn_wave_barrier();
     for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
+    ZT();
     __builtin_amdgcn_wave_barrier();
-    // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2
+    // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2  -- one lane each
     const int ntask = K + K * (K + 1) / 2;
-    for (int q = lp; q < ntask; q += LPC) {
-      double r;
-      if (q < K) r = dotP(tU.row(q), tS.row(0), P);
-      else {
-        int a = 0, rem = q - K;
+    if (lp < ntask) {
+      const double* ra = tU.row(lp);
+      const double* rb = tS.row(0);
+      if (lp >= K) {
+        int a = 0, rem = lp - K;
         while (rem >= K - a) { rem -= K - a; ++a; }
-        r = dotP(tU.row(a), tG.row(a + rem), P);
+        ra = tU.row(a); rb = tG.row(a + rem);
       }
-      sRes[q] = r;
+      sRes[lp] = dotL<LPC>(ra, rb);
     }
     __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
@@ -184,6 +218,7 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       for (int k2 = 0; k2 < KMAX; ++k2)
         if (k2 >= k) Q[k][k2] = (k2 < K) ? sRes[K + tri_index(K, k, k2)] : 0.0;
     }
+    ZT();
     double Zfin[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zfin[k] = Zold[k];
@@ -192,15 +227,18 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       // proposal: Dirichlet(a_Z_PM * Z_old) through K gamma draws, lane k draws component k
       double a_old[KMAX], a_new[KMAX], Znew[KMAX];
       double mygam = 0.0, mylg = 0.0;
+      double a_mine = 1.0;       // lane k < K: a_old_k -- ONE gamma / lgamma sequence serves all K components
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         a_old[k] = c.h.a_Z_PM * Zold[k];
-        if (k < K && lp == k) {
-          const double a = (a_old[k] <= 0) ? 10.0 : a_old[k];            // Distributions.h:24-28
-          mygam = rgamma(key, UPD_Z_PROP, (uint32_t)(i * K + k), a, 1.0);
-          mylg = lgamma(a_old[k]);
-        }
+        if (k < K && lp == k) a_mine = a_old[k];
       }
+      if (lp < K) {
+        const double a = (a_mine <= 0) ? 10.0 : a_mine;                  // Distributions.h:24-28
+        mygam = rgamma(key, UPD_Z_PROP, (uint32_t)(i * K + lp), a, 1.0);
+        mylg = lgamma_pos(a_mine);
+      }
+      ZT();
       double gs = 0.0, lB_old = 0.0, sa_old = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
@@ -213,11 +251,12 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       double sa_new = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) if (k < K) sa_new += a_new[k];
-      double lgv = 0.0;
+      double lgarg = 1.0;        // one straight-line lgamma sequence for all K + 2 arguments
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) lgv = lgamma(a_new[k]);
-      if (lp == K) lgv = lgamma(sa_old);
-      if (lp == K + 1) lgv = lgamma(sa_new);
+      for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) lgarg = a_new[k];
+      if (lp == K) lgarg = sa_old;
+      if (lp == K + 1) lgarg = sa_new;
+      const double lgv = lgamma_pos(lgarg);
       double lB_new = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) if (k < K) lB_new += __shfl(lgv, k, LPC);
@@ -234,6 +273,7 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
         }
         lgz = log(arg);
       }
+      ZT();
       // quadratic form of the residual sum of squares in Z
       double q_old = cv.yy, q_new = cv.yy, pr_old = 0.0, pr_new = 0.0, dn = 0.0, dold = 0.0;
 #pragma unroll
@@ -274,9 +314,13 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
       for (int k = 0; k < KMAX; ++k)
         if (k < K && lp == k) { c.Z[i + (size_t)n * k] = Zfin[k]; zslot[i + (size_t)n * k] = Zfin[k]; }
     }
+    {
+      double zarg = 1.0;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K && lp == k) logz_mine = log(Zfin[k]);     // (one log sequence: every lane k evaluates its own)
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && lp == k) zarg = Zfin[k];
+      logz_mine = log(zarg);                              // one log sequence: lane k evaluates log Z_ik
+    }
     if (D > 0) {
       // offset seen by the Phi / nu block: o = sum_k Z_k ucov_k;  s~ = s - G o;  yy~ = yy - 2 o's + o'G o
       double o = 0.0;
@@ -294,6 +338,10 @@ __global__ __launch_bounds__(256) void k_curve_z(Ctx c, int do_update) {
   } else if (lp == 0) {
     sYp[grp] = 0.0;
   }
+  ZT();
+#ifdef BFMMM_TIMELINE
+  if (blockIdx.x == 7 && threadIdx.x == 0) for (int x = 0; x + 1 < zi; ++x) c.dyn->stamps[32 + x] = zt[x + 1] - zt[x];
+#endif
   // block partial of sum_i log Z_ik, fixed order over the groups of this block
   if (lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
   __syncthreads();
@@ -416,19 +464,18 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     //        then  c0's  and  c0'(s - G c0)
     const int nA = Mu * (Mu + 1) / 2;
     for (int q = lp; q < ntask; q += LPC) {
-      double r;
+      const double* ra = tX.row(0);
+      const double* rb = tX.row(1);
       if (q < nA) {
         int a = 0, rem = q;
         while (rem >= Mu - a) { rem -= Mu - a; ++a; }
-        r = dotP(tU.row(a), tG.row(a + rem), P);
+        ra = tU.row(a); rb = tG.row(a + rem);
       } else if (q < nA + Mu) {
-        r = dotP(tU.row(q - nA), tX.row(1), P);
+        ra = tU.row(q - nA);
       } else if (q == nA + Mu) {
-        r = dotP(tX.row(0), tX.row(2), P);
-      } else {
-        r = dotP(tX.row(0), tX.row(1), P);
+        rb = tX.row(2);
       }
-      sRes[q] = r;
+      sRes[q] = dotL<LPC>(ra, rb);
     }
     if (Mu > 0) {
       const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);

@@ -53,7 +53,7 @@ struct Dyn {
   double loglik;
   double pi[KMAX];
   double tau[KMAX];
-  unsigned long long stamps[32];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
+  unsigned long long stamps[64];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
 };
 
 struct Dims {
@@ -157,6 +157,29 @@ struct Timeline {
 #define TIMELINE(c, k) do { } while (0)
 #define TSTAMP(c, i) do { } while (0)
 #endif
+
+template <int CTRL>
+__device__ inline double dpp_add(double v) {   // v + dpp_permute<CTRL>(v) within a row of 16 lanes
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double row16_sum(double v) {   // every lane of a 16-lane row gets the row's sum
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  v = dpp_add<0x140>(v);    // row_mirror
+  return v;
+}
+
+// sum over the LPC (32 or 64) lanes of a curve group, every lane gets it; fixed order
+template <int LPC>
+__device__ inline double group_sum(double v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  if (LPC == 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
 
 // Batched global -> LDS copy: every thread issues UN independent loads before the first store, so
 // the copy costs one memory latency per UN*nthreads elements instead of one per nthreads.

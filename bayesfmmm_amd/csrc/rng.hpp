@@ -181,11 +181,37 @@ __host__ __device__ inline double rtruncnorm_lo(const RngKey& r, uint32_t upd, u
   return mu + sd * (x + al);
 }
 
+// lgamma for x > 0 (x == 0 gives +inf): upward recurrence to x >= 8, then the Stirling series
+//   lgamma(x) = (x - 1/2) log x - x + log(2 pi)/2 + sum_j B_2j / (2j (2j-1) x^(2j-1)),
+// truncated after x^-13 (below 2e-15 at x = 8).  About 150 straight-line instructions against the few thousand,
+// heavily divergent, of the device library's general-argument lgamma -- the Dirichlet proposal densities of the
+// Z / pi updates evaluate it 2K + 2 times per curve and sweep.
+__host__ __device__ inline double lgamma_pos(double x) {
+  double prod = 1.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool small_x = x < 8.0;
+    prod = small_x ? prod * x : prod;
+    x = small_x ? x + 1.0 : x;
+  }
+  const double r = 1.0 / x, r2 = r * r;
+  double ser = 1.0 / 156.0;
+  ser = ser * r2 - 691.0 / 360360.0;
+  ser = ser * r2 + 1.0 / 1188.0;
+  ser = ser * r2 - 1.0 / 1680.0;
+  ser = ser * r2 + 1.0 / 1260.0;
+  ser = ser * r2 - 1.0 / 360.0;
+  ser = ser * r2 + 1.0 / 12.0;
+  double lg = (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser * r;
+  if (prod != 1.0) lg -= log(prod);
+  return lg;
+}
+
 // log of the multivariate Beta function, calc_lB of Distributions.h:51-60
 __host__ __device__ inline double calc_lB(int K, const double* alpha) {
   double lb = 0.0, acc = 0.0;
-  for (int k = 0; k < K; ++k) { lb += lgamma(alpha[k]); acc += alpha[k]; }
-  return lb - lgamma(acc);
+  for (int k = 0; k < K; ++k) { lb += lgamma_pos(alpha[k]); acc += alpha[k]; }
+  return lb - lgamma_pos(acc);
 }
 
 }  // namespace bfmmm

@@ -53,3 +53,4 @@ nz = np.nonzero(tr_all[:, 0])[0]
 print("trace entries written:", len(nz), "max wg id", nz.max())
 late = [w for w in nz if tr_all[w, 0] > t0 + 500]
 print("entries starting > 5 us after t0:", late[:20], [(round((tr_all[w,0]-t0)*0.01,2), round((tr_all[w,2]-t0)*0.01,2)) for w in late[:20]])
+print("curve_z block 7 thread 0 clocks: load+stage %d | barrier %d | u_k %d | matvec %d | dots %d | unpack+gamma/lgamma %d | lgammas+log %d | quad+accept+store %d" % tuple(np.array(smp.get_state("stamps"))[32:40]))
