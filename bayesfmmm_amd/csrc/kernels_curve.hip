@@ -19,6 +19,8 @@
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
 
+#include <algorithm>
+
 namespace bfmmm {
 
 constexpr int MMAX = 16;   // eigenfunctions supported by the per-curve tiles
@@ -550,6 +552,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   size_t lds;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
   else lds = nth * (1 + D) + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * M + (M * (M + 1) / 2 + M + 2) + tileE);
+  if (which == 1) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \

@@ -930,7 +930,7 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
-  const size_t lds = (size_t)KS * std::max(row_g, row_s) * sizeof(double);
+  const size_t lds = std::max((size_t)KS * std::max(row_g, row_s), (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);
   hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(256), lds, st, c, KS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;

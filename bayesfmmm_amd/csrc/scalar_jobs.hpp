@@ -34,9 +34,19 @@ __device__ inline double block_sum256(double v, double* scratch) {
 __device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
 
 // ------------------------------------------------------------------------------------------------
+constexpr int PI_ALPHA_LDS_DOUBLES = KMAX * 256 + 10 * KMAX + 16;
+
 __device__ inline void job_pi_alpha(const Ctx& c) {
-  __shared__ double red[KMAX][256];
-  __shared__ double S[KMAX], g[KMAX], lg[6 * KMAX + 8], ph_s[1];
+  // scratch carved from k_pair_gram's dynamic LDS (the launcher guarantees PI_ALPHA_LDS_DOUBLES)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double (*red)[256] = (double (*)[256])smem;       // KMAX x 256
+  double* S = smem + KMAX * 256;                     // KMAX
+  double* g = S + KMAX;                              // KMAX
+  double* lg = g + KMAX;                             // 6 * KMAX + 8
+  double* ph_s = lg + 6 * KMAX + 8;                  // 2
+  double* lu = ph_s + 2;                             // 2
+  double* lp = lu + 2;                               // 2 * KMAX
+  double* dt = lp + 2 * KMAX;                        // 2
   const Dims& d = c.d;
   const int K = d.K, n = d.n, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
@@ -71,14 +81,17 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
     }
     if (tid < K) S[tid] = red[tid][0];
   }
-  // proposals: lane k < K draws the pi gamma, lane K the alpha_3 truncated normal
+  // proposals and acceptance uniforms, one wave each so that their different code paths run side by side:
+  // wave 0 lanes k < K: the pi gammas; wave 1: the alpha_3 truncated normal; wave 2: log(u) of the two MH tests
   double alpha3 = dyn->alpha3;
   const double sd = c.h.var_alpha3;
   if (tid < K) {
     const double a_old = c.h.a_pi_PM * dyn->pi[tid];
     g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
-  } else if (tid == K) {
+  } else if (tid == 64) {
     ph_s[0] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
+  } else if (tid == 128 || tid == 129) {
+    lu[tid - 128] = log(runif(key, (tid == 128) ? UPD_PI_ACC : UPD_A3_ACC, 0));
   }
   __syncthreads();
   double pi_old[KMAX], pi_new[KMAX];
@@ -86,19 +99,26 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
   for (int k = 0; k < K; ++k) gsum += g[k];
   for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
   const double a3_ph = ph_s[0];
-  // lgamma table, one lane each.  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
-  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5
-  if (tid < 6 * K) {
-    const int row = tid / K, k = tid - row * K;
-    const double pk = (row & 1) ? pi_new[k] : pi_old[k];
+  // lgamma table, one lane each (wave 0).  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
+  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5.  Wave 1: log pi_old / log pi_new;
+  // wave 2: the two truncated-normal densities.
+  if (tid < 6 * K + 6) {
+    const bool is_sum = tid >= 6 * K;
+    const int row = is_sum ? tid - 6 * K : tid / K, k = is_sum ? 0 : tid - row * K;
     const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
-    lg[tid] = lgamma(sc * pk);
-  } else if (tid < 6 * K + 6) {
-    const int row = tid - 6 * K;
-    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc += sc * ((row & 1) ? pi_new[k] : pi_old[k]);
-    lg[tid] = lgamma(acc);
+    double arg = 0.0;
+    for (int k2 = 0; k2 < K; ++k2) {
+      const double term = sc * ((row & 1) ? pi_new[k2] : pi_old[k2]);
+      if (is_sum) arg += term;
+      else if (k2 == k) arg = term;
+    }
+    lg[tid] = lgamma_pos(arg);
+  } else if (tid >= 64 && tid < 64 + 2 * K) {
+    const int e = tid - 64;
+    lp[e] = log((e < K) ? pi_old[e] : pi_new[e - K]);
+  } else if (tid == 128 || tid == 129) {
+    // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
+    dt[tid - 128] = (tid == 128) ? dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0) : dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
   }
   __syncthreads();
   if (tid == 0) {
@@ -113,7 +133,7 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
     if (mask & U_PI) {
       double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
       for (int k = 0; k < K; ++k) {
-        const double lo = log(pi_old[k]), ln = log(pi_new[k]);
+        const double lo = lp[k], ln = lp[K + k];
         lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
         lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
         pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
@@ -124,8 +144,7 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
       const double lpn = pn - lB(0);
       const double lpo = po - lB(1);
       const double acc = lpdf_new - lpdf_old + lpo - lpn;
-      const double u = runif(key, UPD_PI_ACC, 0);
-      if (log(u) < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
+      if (lu[0] < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
       for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
     }
     if (mask & U_ALPHA3) {
@@ -136,11 +155,9 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
       }
       l_old -= n * lB(2 + pi_is_new);
       l_new -= n * lB(4 + pi_is_new);
-      // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
-      l_old += dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0);
-      l_new += dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
-      const double u = runif(key, UPD_A3_ACC, 0);
-      if (log(u) < l_new - l_old) alpha3 = a3_ph;
+      l_old += dt[0];
+      l_new += dt[1];
+      if (lu[1] < l_new - l_old) alpha3 = a3_ph;
       dyn->alpha3 = alpha3;
     }
     c.c_alpha3[dyn->slot] = dyn->alpha3;
@@ -190,8 +207,20 @@ __device__ inline void job_hyper_draws(const Ctx& c, int first) {
   c.gstd[e] = v;
 }
 
+constexpr int HYPER_LDS_DOUBLES = 4 * KMAX * 16 + KMAX * 2 * 6 + KMAX + 2 + 2 * KMAX * PMAX;
+
 __device__ inline void job_hyper(const Ctx& c) {
-  __shared__ double Skm[KMAX * 16], aw[KMAX * 2 * 6], qrow[KMAX * PMAX], dl[KMAX * 16], slog[KMAX];
+  // scratch carved from the host kernel's dynamic LDS (the job's workgroup does not use it otherwise; the launcher
+  // guarantees HYPER_LDS_DOUBLES): no static LDS, so the job does not lower the occupancy of the curve workgroups
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Skm = smem;                 // KMAX * 16
+  double* dl = Skm + KMAX * 16;       // KMAX * 16
+  double* lgd = dl + KMAX * 16;       // KMAX * 16
+  double* tpre = lgd + KMAX * 16;     // KMAX * 16
+  double* aw = tpre + KMAX * 16;      // KMAX * 2 * 6
+  double* slog = aw + KMAX * 2 * 6;   // KMAX (+2 pad)
+  double* qrow = slog + KMAX + 2;     // KMAX * PMAX
+  double* snu = qrow + KMAX * PMAX;   // KMAX * PMAX
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
@@ -205,71 +234,87 @@ __device__ inline void job_hyper(const Ctx& c) {
   const double* gT = gD + K * M;
   const double* aProp = gT + K;
   const double* aUnif = aProp + 2 * K;
-  // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 ; row products of nu_k' P nu_k ----
-  if (do_delta && tid < K * M) {
-    const int k = tid / M, m = tid - k * M;
-    double acc = 0.0;
-    for (int p = 0; p < P; ++p) {
-      const double ph = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
-      acc += c.gamma[k + (size_t)K * (p + (size_t)P * m)] * (ph * ph);
-    }
-    Skm[tid] = acc;
-  }
-  if (do_tau && tid >= 64 && tid < 64 + K * P && tid < 256) {
-    const int e = tid - 64, k = e / P, p = e - k * P;
-    const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
-    double s = 0.0;
-    if (d.mv) s = nu[p];
-    else
-      for (int q = 0; q < P; ++q) s += c.Pmat[p + (size_t)P * q] * nu[q];
-    qrow[e] = nu[p] * s;
-  }
-  if (tid < K)
-    for (int m = 0; m < M; ++m) dl[tid * 16 + m] = c.delta[tid + (size_t)K * m];
-  __syncthreads();
-  // ---- phase 2: tau (K lanes), delta recursion (K lanes) ----
-  if (do_tau && tid >= 32 && tid < 32 + K) {
-    const int k = tid - 32;
-    double qf = 0.0;
-    if (K * P <= 192) { for (int p = 0; p < P; ++p) qf += qrow[k * P + p]; }
-    else {
-      const double* nu = c.theta + (size_t)(k * (M + 1)) * P;
-      for (int p = 0; p < P; ++p) {
-        double s = 0.0;
-        if (d.mv) s = nu[p];
-        else for (int q = 0; q < P; ++q) s += c.Pmat[p + (size_t)P * q] * nu[q];
-        qf += nu[p] * s;
+  // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 (8 lanes per (k, m), all loads of a lane in flight
+  //      together) ; nu staged for nu_k' P nu_k ----
+  if (do_delta) {
+    for (int g0 = 0; g0 < K * M; g0 += 32) {
+      const int km = g0 + (tid >> 3), q = tid & 7;
+      const bool on = km < K * M;
+      const int k = on ? km / M : 0, m = on ? km - k * M : 0;
+      double pr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = min(q + 8 * u, P - 1);
+        const double ph = c.theta[(size_t)(k * (M + 1) + m + 1) * P + p];
+        const double gm = c.gamma[k + (size_t)K * (p + (size_t)P * m)];
+        pr[u] = (on && q + 8 * u < P) ? gm * (ph * ph) : 0.0;
       }
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += pr[u];
+      acc = dpp_add<0xB1>(acc);
+      acc = dpp_add<0x4E>(acc);
+      acc = dpp_add<0x141>(acc);
+      if (on && q == 0) Skm[km] = acc;
     }
-    const double b = c.h.beta_nu + (0.5 * qf);
-    const double gg = gT[k] * (1.0 / b);
-    dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
   }
+  if (do_tau)
+    for (int e = tid; e < K * P; e += 256) { const int k = e / P, p = e - k * P; snu[e] = c.theta[(size_t)(k * (M + 1)) * P + p]; }
+  if (tid < K * M && tid < KMAX * 16) { const int k = tid / M, m = tid - k * M; dl[k * 16 + m] = c.delta[k + (size_t)K * m]; }
+  __syncthreads();
+  // nu_k' P nu_k : lane (k, p) takes row p of P (batches of 8 independent loads), summed per k in phase 2
+  if (do_tau)
+    for (int e = tid; e < K * P; e += 256) {
+      const int k = e / P, p = e - k * P;
+      double s = 0.0;
+      if (d.mv) s = snu[e];
+      else
+        for (int q0 = 0; q0 < P; q0 += 8) {
+          double pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pv[u] = c.Pmat[p + (size_t)P * min(q0 + u, P - 1)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (q0 + u < P) s += pv[u] * snu[k * P + q0 + u];
+        }
+      qrow[e] = snu[e] * s;
+    }
+  // ---- phase 2: delta recursion (K lanes).  tilde-tau products are carried along instead of rebuilt: the
+  //      multiplication order is the reference's (UpdateDelta.h:30-37, 47-54), the work O(M^2) instead of O(M^3) ----
   if (tid < K) {
     const int k = tid;
     double* dk = dl + k * 16;
     if (do_delta) {
+      double pre = 1.0;                                // prod_{nn < i} delta_new(k, nn)
       for (int i = 0; i < M; ++i) {
-        double param2 = 1.0;
-        if (i == 0) {
-          param2 += 0.5 * Skm[k * M + 0];
-          double tt = 1.0;
-          for (int m = 1; m < M; ++m) { tt *= dk[m]; param2 += 0.5 * tt * Skm[k * M + m]; }
-        } else {
-          for (int m = i; m < M; ++m) {
-            double tt = 1.0;
-            for (int nn = 0; nn <= m; ++nn)
-              if (nn != i) tt *= dk[nn];
-            param2 += 0.5 * tt * Skm[k * M + m];
-          }
-        }
+        double tt = pre;                               // prod_{nn <= m, nn != i} delta(k, nn), m = i
+        double param2 = 1.0 + 0.5 * tt * Skm[k * M + i];
+        for (int m = i + 1; m < M; ++m) { tt *= dk[m]; param2 += 0.5 * tt * Skm[k * M + m]; }
         dk[i] = gD[k * M + i] * (1.0 / param2);
+        pre *= dk[i];
       }
-      for (int m = 0; m < M; ++m) c.delta[k + (size_t)K * m] = dk[m];
     }
+    double tt = 1.0;                                   // tilde-tau(k, j) = prod_{j2 <= j} delta(k, j2), UpdateGamma.h:26-28
+    for (int m = 0; m < M; ++m) { tt *= dk[m]; tpre[k * 16 + m] = tt; }
+  }
+  __syncthreads();
+  if (do_tau && tid >= 32 && tid < 32 + K) {
+    const int k = tid - 32;
+    double qf = 0.0;
+    for (int p = 0; p < P; ++p) qf += qrow[k * P + p];
+    const double b = c.h.beta_nu + (0.5 * qf);
+    const double gg = gT[k] * (1.0 / b);
+    dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
+  }
+  if (tid < K * M) {
+    const int k = tid / M, m = tid - k * M;
+    if (do_delta) c.delta[k + (size_t)K * m] = dl[k * 16 + m];
+    lgd[k * 16 + m] = log(dl[k * 16 + m]);
+  }
+  __syncthreads();
+  if (tid < K) {
     double sl = 0.0;                                   // sum_{q >= 1} log delta(k, q), used by lpdf_a2
-    for (int q = 1; q < M; ++q) sl += log(dk[q]);
-    slog[k] = sl;
+    for (int q = 1; q < M; ++q) sl += lgd[tid * 16 + q];
+    slog[tid] = sl;
   }
   __syncthreads();
   // ---- phase 3: A terms (4 lanes per cell), gamma scaling ----
@@ -282,24 +327,27 @@ __device__ inline void job_hyper(const Ctx& c) {
     double v;
     if (job < 2) {
       const double a = (job == 0) ? cur : na;
-      if (first) {
-        v = -logGamma_ref(a) + (a - 1) * log(dl[j * 16]) + (c.h.alpha1l - 1) * log(a) - (a * c.h.beta1l);   // UpdateA.h:17-24
-      } else {
-        const double x = M - 1;                                                                             // UpdateA.h:33-44
-        v = -x * logGamma_ref(a) + (c.h.alpha2l - 1) * log(a) - (a * c.h.beta2l) + (a - 1) * slog[j];
-      }
-    } else if (job == 2) v = dtruncnorm_lo_log(cur, na, sd, 0.0);
-    else v = dtruncnorm_lo_log(na, cur, sd, 0.0);
+      const double lga = logGamma_ref(a), la = log(a);                // one sequence for both kinds of cell
+      if (first) v = -lga + (a - 1) * lgd[j * 16] + (c.h.alpha1l - 1) * la - (a * c.h.beta1l);          // UpdateA.h:17-24
+      else { const double x = M - 1; v = -x * lga + (c.h.alpha2l - 1) * la - (a * c.h.beta2l) + (a - 1) * slog[j]; }   // UpdateA.h:33-44
+    } else {
+      v = (job == 2) ? dtruncnorm_lo_log(cur, na, sd, 0.0) : dtruncnorm_lo_log(na, cur, sd, 0.0);
+    }
     aw[cell * 6 + 1 + job] = v;
   }
+  double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
   if (do_gamma) {
     for (int e = tid; e < nG; e += 256) {            // e = (i*P + l)*M + j  (reference loop order i, l, j)
       const int jj = e % M, il = e / M, l = il % P, i = il / P;
-      double ph = 1.0;
-      for (int j2 = 0; j2 <= jj; ++j2) ph *= dl[i * 16 + j2];
+      const double ph = tpre[i * 16 + jj];
       const double phi = c.theta[(size_t)(i * (M + 1) + jj + 1) * P + l];
-      c.gamma[i + (size_t)K * (l + (size_t)P * jj)] = gGam[e] * (2 / (c.h.nu_1 + ph * (phi * phi)));
+      const double gnew = gGam[e] * (2 / (c.h.nu_1 + ph * (phi * phi)));
+      const size_t at = i + (size_t)K * (l + (size_t)P * jj);
+      c.gamma[at] = gnew;
+      s_gam[at] = gnew;
     }
+  } else {
+    for (int e = tid; e < nG; e += 256) s_gam[e] = c.gamma[e];
   }
   __syncthreads();
   // ---- phase 4: A accept; chain slots ----
@@ -309,8 +357,6 @@ __device__ inline void job_hyper(const Ctx& c) {
     if (log(aUnif[tid]) < acc) c.Aa[(tid >> 1) + (size_t)K * (tid & 1)] = aProp[tid];
   }
   __syncthreads();
-  double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
-  for (int e = tid; e < nG; e += 256) s_gam[e] = c.gamma[e];
   if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
   if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
   if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
