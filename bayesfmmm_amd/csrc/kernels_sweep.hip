@@ -24,6 +24,7 @@
 #include "factor_core.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace bfmmm {
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
   if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
-    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 31); }
+    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 46); }
     return;
   }
   if (!do_pg) return;
@@ -131,23 +132,42 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
         }
       }
     };
-    TSTAMP(c, 20);
+    // G workgroups (16 record columns): element (il, cc) = (tid / 16 + 16 u, tid % 16), so a load costs one
+    // multiply-add and a store a constant LDS offset
+    const int ccg = tid & 15, ilg = tid >> 4;
+    const double* srcg = c.rec + min(col0 + ccg, d.LREC - 1);
+    const bool colok = col0 + ccg < colend;
+    auto loadG = [&](int ub0, double (&v)[UB]) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) v[u] = srcg[(size_t)min(i0 + ilg + 16 * (ub0 + u), n - 1) * d.LREC];
+    };
+    auto storeG = [&](int ub0, const double (&v)[UB]) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int il = ilg + 16 * (ub0 + u);
+        if (il < KS) sB[il * 16 + ccg] = (i0 + il < n && colok) ? v[u] : 0.0;
+      }
+    };
+    TSTAMP0(c, 40);
     double vw[UW], vb[UB];
     loadW(0, 0, vw);
-    loadB(0, vb);
+    if (single) loadB(0, vb); else loadG(0, vb);
+    TSTAMP0(c, 47);
     storeW(0, 0, vw);
-    storeB(0, vb);
+    TSTAMP0(c, 48);
+    if (single) storeB(0, vb); else storeG(0, vb);
     for (int il0 = 0; il0 < KS; il0 += 256)
       for (int cb = 0; cb < ncw; cb += UW) {
         if (il0 == 0 && cb == 0) continue;
         loadW(il0, cb, vw);
         storeW(il0, cb, vw);
       }
-    for (int base = 256 * UB; base < nB; base += 256 * UB) { loadB(base, vb); storeB(base, vb); }
-    TSTAMP(c, 21);
+    if (single) { for (int base = 256 * UB; base < nB; base += 256 * UB) { loadB(base, vb); storeB(base, vb); } }
+    else { for (int ub0 = UB; 16 * ub0 < KS; ub0 += UB) { loadG(ub0, vb); storeG(ub0, vb); } }
+    TSTAMP0(c, 41);
   }
   __syncthreads();
-  TSTAMP(c, 22);
+  TSTAMP0(c, 42);
   if (!single) {                             // pair rows, one thread per curve
     for (int il = tid; il < KS; il += 256) {
       const double* w = sW + il * RS;
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     }
     __syncthreads();
   }
-  TSTAMP(c, 23);
+  TSTAMP0(c, 43);
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const int ntile = single ? d.AT * d.CTS : d.RT;
@@ -193,22 +213,34 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     double4_t acc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < KS; kk += 4) {
-      const double* wrow = wsrc + (kk + kq) * wstride;
-      const double* brow = sB + (kk + kq) * ncol;
+    // U k-steps per trip: the 9 U LDS reads of a trip are issued together, so one LDS latency is paid per U steps
+    // and the later steps' operands arrive under the MFMAs of the earlier ones
+    auto ksteps = [&](int kk, auto ucount) {
+      constexpr int U = decltype(ucount)::value;
+      double wa[U][TPW], wb[U][TPW], bb[U][TPW];
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const double a = wrow[o1[q]] * wrow[o2[q]];
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[bcol[q]], acc[q], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        const double* wrow = wsrc + (kk + 4 * u + kq) * wstride;
+        const double* brow = sB + (kk + 4 * u + kq) * ncol;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) { wa[u][q] = wrow[o1[q]]; wb[u][q] = wrow[o2[q]]; bb[u][q] = brow[bcol[q]]; }
       }
-    }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u][q] * wb[u][q], bb[u][q], acc[q], 0, 0, 0);
+    };
+    int kk = 0;
+    for (; kk + 16 <= KS; kk += 16) ksteps(kk, std::integral_constant<int, 4>{});
+    for (; kk < KS; kk += 4) ksteps(kk, std::integral_constant<int, 1>{});
 #pragma unroll
     for (int q = 0; q < TPW; ++q)
       if (tv[q]) {
         double* out = c.pg_part + ((size_t)ks * d.NT + tix[q]) * 256 + lane;
         out[0] = acc[q][0]; out[64] = acc[q][1]; out[128] = acc[q][2]; out[192] = acc[q][3];
       }
-    TSTAMP(c, 30);
+    TSTAMP0(c, 44);
   }
 }
 

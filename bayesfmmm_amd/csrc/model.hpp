@@ -153,9 +153,11 @@ struct Timeline {
 };
 #define TIMELINE(c, k) Timeline tl_((c), (k))
 #define TSTAMP(c, i) do { if (threadIdx.x == 0) atomicMax(&(c).dyn->stamps[i], (unsigned long long)wall_clock64()); } while (0)
+#define TSTAMP0(c, i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) (c).dyn->stamps[i] = wall_clock64(); } while (0)
 #else
 #define TIMELINE(c, k) do { } while (0)
 #define TSTAMP(c, i) do { } while (0)
+#define TSTAMP0(c, i) do { } while (0)
 #endif
 
 template <int CTRL>

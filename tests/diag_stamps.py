@@ -21,7 +21,8 @@ for k, nm in enumerate(names):
 
 
 
-print("pair_gram (max over WGs, rel. kernel start): begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[[20,21,22,23,30,31]]-st[2]))
+print("pair_gram staging: loads issued %.2f, W stored (first data back) %.2f" % (st[47]-st[2], st[48]-st[2]))
+print("pair_gram WG(0,0), rel. kernel start: begin %.2f  staged %.2f  sync %.2f  pairs %.2f  mfma+store %.2f | pi_alpha job %.2f" % tuple(st[[40,41,42,43,44,46]]-st[2]))
 st_ = np.array(smp.get_state("stamps"))
 print("sweep: setup %.2f us, loop %.2f us, tail %.2f us" % ((st_[24]-st_[8])*0.01, (st_[25]-st_[24])*0.01, (st_[9]-st_[25])*0.01))
 print("sweep clocks/step  A-wave0: between %d  P1 %d  barrier %d  P2 %d  barrier %d" % tuple(st_[26:31]/21))
