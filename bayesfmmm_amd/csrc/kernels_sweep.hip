@@ -708,7 +708,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   double* dlp = rhs + 32;                    // 2 x DLS, by step parity
   double* red = dlp + 2 * DLS;               // 16
   int* htab = (int*)(red + 16);              // A x A : byte offset of block (b, a) in H2
-  int* sdir = htab + A * A;                  // directions of the steps (clamped tail)
+  int* sdir = htab + A * A;                  // directions of the steps (clamped tail), K*(M+1) + 8 entries
+  int* brank = sdir + K * (M + 1) + 8;       // direction owning rank r (ranks follow the order of the steps)
   const uint32_t slot = dyn->slot;
   const uint32_t mask = c.mask;
   const double beta = dyn->beta;
@@ -720,9 +721,28 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   const bool waveA = tid < 256;              // wave-uniform
   const bool isA = tid < 8 * P;
   const int pa = min(tid >> 3, P - 1), q = tid & 7;
+  // residual rows are owned in the ORDER OF THE STEPS: thread 256 + rk * P + p holds r_b[p] of the direction b that
+  // is updated at step rk (directions that are not updated this sweep come last).  A step only has to push its
+  // delta into the rows whose turn is still ahead -- the conditional mean of a direction never looks at r again
+  // after its own step, and the residual sum of squares is carried incrementally (see rss_acc) -- so the traffic
+  // of the off-chain updates halves and whole waves retire as the sweep advances.
+  {
+    const bool none_phi = (n_phi == 0 && MD > 1), none_nu = (n_nu == 0);
+    const int per_j = (none_phi ? MD - 1 : 0) + (none_nu ? 1 : 0);
+    for (int x = tid; x < A; x += nthr) {
+      const int jx = x / MD, mx = x - jx * MD;
+      int rk;
+      if (mx >= 1 && !none_phi) rk = jx * M + mx - 1;
+      else if (mx == 0 && !none_nu) rk = n_phi + jx;
+      else rk = n_steps + jx * per_j + ((mx >= 1) ? (none_nu ? 1 : 0) + mx - 1 : 0);
+      brank[rk] = x;
+    }
+  }
+  __syncthreads();
   const bool isB = tid >= 256 && tid - 256 < AP;
   const int e = min(max(tid - 256, 0), AP - 1);
-  const int b = e / P, p = e - b * P;
+  const int rk = e / P, p = e - rk * P;
+  const int b = brank[rk];
   uint32_t coff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) coff[u] = (uint32_t)(pa + P * min(q + 8 * u, P - 1)) * 8u;
@@ -730,10 +750,12 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   const uint32_t cstride = (uint32_t)(P * P) * 8u;
   const int fd = full_dir(d, b);
   double r_e = 0.0, hq_e = 0.0, tv_e = 0.0;
+  const int eb = b * P + p;                  // element of the direction-major vectors
+  double rss_acc = 0.0;                      // this thread's share of RSS - YY
   if (!waveA) {
-    r_e = c.rvec[e]; hq_e = c.hq[e]; tv_e = c.tvec[e];
-    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[e];
-    if (isB) { th[e] = t0; lz[e] = l0; }
+    r_e = c.rvec[eb]; hq_e = c.hq[eb]; tv_e = c.tvec[eb];
+    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[eb];
+    if (isB) { th[eb] = t0; lz[eb] = l0; rss_acc = -(t0 * (tv_e + r_e)); }   // RSS(theta_0) = YY - theta_0'(t + r_0)
   }
   if (tid < 32) rhs[tid] = 0.0;
   if (tid < 2 * DLS) dlp[tid] = 0.0;
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 #else
 #define SWT(i) do { } while (0)
 #endif
-  auto step = [&](int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
+  auto step = [&](int st, int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
     double* dl_w = dlp + par * DLS;                  // written in P1 of this step
     const double* dl_prev = dlp + (par ^ 1) * DLS;   // delta of the previous step
     SWT(0);
@@ -820,17 +842,24 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
       }
     } else {
       // ---- P1, off the chain: lagging update with the previous step's delta (b == a was updated urgently)
-      sweep_wait_h<BW + 1, BW>(h_lag);               // younger: h_cur's refill of the previous step
-      if (aprev >= 0 && b != a) r_e -= band_dot(h_lag, dl_prev + p);
-      issueH(h_lag, an >= 0 ? an : a);               // becomes H_{b, a_next}: used in P2 of the next step or P1 after it
+      // rows of step st - 1 (RSS term) and of the steps after st (residual); a wave whose rows are all behind is done
+      const bool lag = isB && rk > st && rk < n_steps, own = isB && rk == st - 1;
+      if (__builtin_amdgcn_ballot_w64(isB && rk + 1 >= st && rk < n_steps) != 0) {
+        sweep_wait_h<BW + 1, BW>(h_lag);             // younger: h_cur's refill of the previous step
+        const double v = band_dot(h_lag, dl_prev + p);
+        if (lag && aprev >= 0) r_e -= v;
+        // RSS(theta + delta e_a) - RSS(theta) = delta'(H_aa delta - 2 r_a), r_a taken before the step
+        if (own) rss_acc += dl_prev[BW + p] * (v - 2.0 * r_e);
+        issueH(h_lag, an >= 0 ? an : a);             // becomes H_{b, a_next}: used in P2 of the next step or P1 after it
+      }
     }
     SWT(1);
     lds_barrier();
     SWT(2);
     // ---- P2: the rows of the next direction take this step's delta now and publish the next rhs
-    if (!waveA && an >= 0) {
+    if (!waveA && an >= 0 && __builtin_amdgcn_ballot_w64(isB && rk == st + 1) != 0) {
       sweep_wait_h<BW + 1, BW>(h_cur);               // younger: the refill just issued in P1
-      if (isB && b == an) {
+      if (isB && rk == st + 1) {
         r_e -= band_dot(h_cur, dl_w + p);
         rhs[p] = f * (r_e + hq_e);
       }
@@ -841,7 +870,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   };
   if (n_steps > 0) {
     const int a0 = sdir[0];
-    if (isB && b == a0) rhs[p] = f * (r_e + hq_e);
+    if (isB && rk == 0) rhs[p] = f * (r_e + hq_e);
     CSet c0 = {}, c1 = {};
     SweepH<BW> h0 = {}, h1 = {};             // h0 = H_{b, a_st} for even st, h1 for odd st
     {
@@ -857,8 +886,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
     // step st+1     : P1 lagging uses h0 (H_{b, a_st}), then h0 <- H_{b, a_{st+2}};       P2 uses h1.
     for (int st = 0; st < n_steps; st += 2) {
       const int v4 = sdir[min(st + 4, n_steps + 2)], v5 = sdir[min(st + 5, n_steps + 3)];   // consumed after the steps
-      step(0, c0, h1, h0, a, (st + 1 < n_steps) ? a1 : -1, aprev, a2);
-      if (st + 1 < n_steps) step(1, c1, h0, h1, a1, (st + 2 < n_steps) ? a2 : -1, a, a3);
+      step(st, 0, c0, h1, h0, a, (st + 1 < n_steps) ? a1 : -1, aprev, a2);
+      if (st + 1 < n_steps) step(st + 1, 1, c1, h0, h1, a1, (st + 2 < n_steps) ? a2 : -1, a, a3);
       aprev = a1; a = a2; a1 = a3;
       a2 = __builtin_amdgcn_readfirstlane(v4); a3 = __builtin_amdgcn_readfirstlane(v5);
     }
@@ -866,13 +895,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
     if (tid == 0) { dyn->stamps[25] = wall_clock64(); for (int x = 0; x < 5; ++x) dyn->stamps[26 + x] = tk[x]; }
     if (tid == 256) for (int x = 0; x < 5; ++x) dyn->stamps[10 + x] = tk[x];
 #endif
-    // the last step's delta still has to reach every row (nobody was "next")
+    // RSS term of the last step (its delta does not have to reach any residual row any more)
     if (!waveA) {
       const int last = n_steps - 1;
-      const int al = __builtin_amdgcn_readfirstlane(sdir[last]);
-      (void)al;
-      if (last & 1) { sweep_wait_h<0, BW>(h1); r_e -= band_dot(h1, dlp + DLS + p); }
-      else { sweep_wait_h<0, BW>(h0); r_e -= band_dot(h0, dlp + p); }
+      if (last & 1) { sweep_wait_h<0, BW>(h1); if (isB && rk == last) rss_acc += dlp[DLS + BW + p] * (band_dot(h1, dlp + DLS + p) - 2.0 * r_e); }
+      else { sweep_wait_h<0, BW>(h0); if (isB && rk == last) rss_acc += dlp[BW + p] * (band_dot(h0, dlp + p) - 2.0 * r_e); }
     }
     // drain the prefetches of the (clamped) tail before their registers are reused
     sweep_wait_h<0, BW>(h0);
@@ -880,11 +907,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0.v[0]), "+v"(c0.v[1]), "+v"(c0.v[2]), "+v"(c0.v[3]), "+v"(c1.v[0]), "+v"(c1.v[1]), "+v"(c1.v[2]), "+v"(c1.v[3]) :: "memory");
   }
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
-  const double th_e = th[e];
+  const double th_e = th[eb];
   if (mask & U_SIGMA) {
-    // RSS = YY - sum_a theta_a'(t_a + r_a), fixed-order reduction
+    // RSS = YY + sum of the threads' shares (RSS(theta_0) - YY and the steps' increments), fixed-order reduction
     // (covariate-adjusted: YY is replaced by sum_i yy_i - 2 o_i's_i + o_i'G_i o_i, block partials of k_curve_z)
-    double acc = isB ? th_e * (tv_e + r_e) : 0.0;
+    double acc = isB ? -rss_acc : 0.0;
     if (d.D > 0)
       for (int x = tid; x < c.nblk_curve; x += nthr) acc -= c.yyp_part[x];
 #pragma unroll
@@ -995,7 +1022,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
     const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
-    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
+    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 16) * sizeof(int) + 16;
     switch (d.BW) {
       case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1), dim3(nthr), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1), dim3(nthr), lds, st, c); break;
