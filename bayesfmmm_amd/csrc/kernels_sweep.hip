@@ -710,6 +710,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   int* htab = (int*)(red + 16);              // A x A : byte offset of block (b, a) in H2
   int* sdir = htab + A * A;                  // directions of the steps (clamped tail), K*(M+1) + 8 entries
   int* brank = sdir + K * (M + 1) + 8;       // direction owning rank r (ranks follow the order of the steps)
+  int* flag = brank + K * (M + 1);           // phase-A waves that have published the current step's delta
   const uint32_t slot = dyn->slot;
   const uint32_t mask = c.mask;
   const double beta = dyn->beta;
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
     if (isB) { th[eb] = t0; lz[eb] = l0; rss_acc = -(t0 * (tv_e + r_e)); }   // RSS(theta_0) = YY - theta_0'(t + r_0)
   }
   if (tid < 32) rhs[tid] = 0.0;
+  if (tid == 0) *flag = 0;
   if (tid < 2 * DLS) dlp[tid] = 0.0;
   for (int x = tid; x < A * A; x += nthr) htab[x] = hrow(d, x / A, x % A) * P * W * 8;
   for (int x = tid; x < n_steps + 4; x += nthr) sdir[x] = step_dir(d, min(x, n_steps - 1), n_phi);
@@ -821,12 +823,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 #else
 #define SWT(i) do { } while (0)
 #endif
+  // One barrier per step.  Within a step the only hand-off that is on the dependent chain -- delta_st from the four
+  // phase-A waves to the rows of the NEXT direction -- goes through an LDS counter (each phase-A wave bumps it after
+  // its delta entries are written; LDS operations of a wave are processed in issue order), so the waves that only do
+  // off-chain work never make the chain wait for them in the middle of a step.
   auto step = [&](int st, int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
-    double* dl_w = dlp + par * DLS;                  // written in P1 of this step
+    double* dl_w = dlp + par * DLS;                  // written by phase A of this step
     const double* dl_prev = dlp + (par ^ 1) * DLS;   // delta of the previous step
     SWT(0);
     if (waveA) {
-      // ---- P1, critical chain: theta_a <- C_a rhs + L_a z_a
+      // ---- critical chain: theta_a <- C_a rhs + L_a z_a
       const double lza = lz[a * P + pa], tha = th[a * P + pa];
       const double x0 = rhs[q], x1 = rhs[q + 8], x2 = rhs[q + 16], x3 = rhs[q + 24];
       asm volatile("s_waitcnt vmcnt(4)" : "+v"(cs.v[0]), "+v"(cs.v[1]), "+v"(cs.v[2]), "+v"(cs.v[3]));   // younger: the other C set
@@ -840,28 +846,31 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
         dl_w[BW + pa] = nw - tha;
         th[a * P + pa] = nw;
       }
+      if ((tid & 63) == 0) atomicAdd(flag, 1);       // after this wave's delta entries (same wave, LDS is in order)
     } else {
-      // ---- P1, off the chain: lagging update with the previous step's delta (b == a was updated urgently)
-      // rows of step st - 1 (RSS term) and of the steps after st (residual); a wave whose rows are all behind is done
-      const bool lag = isB && rk > st && rk < n_steps, own = isB && rk == st - 1;
-      if (__builtin_amdgcn_ballot_w64(isB && rk + 1 >= st && rk < n_steps) != 0) {
-        sweep_wait_h<BW + 1, BW>(h_lag);             // younger: h_cur's refill of the previous step
+      const bool lag = isB && rk > st + 1 && rk < n_steps, own = isB && rk == st - 1;
+      const bool next_rows = isB && an >= 0 && (rk == st + 1 || rk == st + 2);
+      const bool wave_next = __builtin_amdgcn_ballot_w64(next_rows) != 0;
+      const bool wave_live = __builtin_amdgcn_ballot_w64(isB && rk + 1 >= st && rk < n_steps) != 0;
+      if (wave_next) {
+        // ---- the rows of the next direction (and of the one after it) take this step's delta as soon as it exists;
+        //      the next direction's rows then publish the next rhs
+        sweep_wait_h<0, BW>(h_cur);                  // the youngest group (issued one step ago)
+        const int target = 4 * (st + 1);
+        while (*(volatile int*)flag < target) { }
+        if (next_rows) {
+          r_e -= band_dot(h_cur, dl_w + p);
+          if (rk == st + 1) rhs[p] = f * (r_e + hq_e);
+        }
+      }
+      if (wave_live) {
+        // ---- off the chain: the previous step's delta for the rows further ahead, and its RSS term
+        sweep_wait_h<BW + 1, BW>(h_lag);             // younger: h_cur's group
         const double v = band_dot(h_lag, dl_prev + p);
         if (lag && aprev >= 0) r_e -= v;
         // RSS(theta + delta e_a) - RSS(theta) = delta'(H_aa delta - 2 r_a), r_a taken before the step
         if (own) rss_acc += dl_prev[BW + p] * (v - 2.0 * r_e);
-        issueH(h_lag, an >= 0 ? an : a);             // becomes H_{b, a_next}: used in P2 of the next step or P1 after it
-      }
-    }
-    SWT(1);
-    lds_barrier();
-    SWT(2);
-    // ---- P2: the rows of the next direction take this step's delta now and publish the next rhs
-    if (!waveA && an >= 0 && __builtin_amdgcn_ballot_w64(isB && rk == st + 1) != 0) {
-      sweep_wait_h<BW + 1, BW>(h_cur);               // younger: the refill just issued in P1
-      if (isB && rk == st + 1) {
-        r_e -= band_dot(h_cur, dl_w + p);
-        rhs[p] = f * (r_e + hq_e);
+        issueH(h_lag, an >= 0 ? an : a);             // becomes H_{b, a_next}
       }
     }
     SWT(3);
@@ -1022,7 +1031,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
     const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
-    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 16) * sizeof(int) + 16;
+    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 24) * sizeof(int) + 16;
     switch (d.BW) {
       case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1), dim3(nthr), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1), dim3(nthr), lds, st, c); break;
