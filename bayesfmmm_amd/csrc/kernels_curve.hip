@@ -90,9 +90,26 @@ __device__ inline double dotL(const double* a, const double* b) {
 // sampled with Z held fixed).
 // LDS per group: U[K], GU[K], S (1 row), chi (MMAX), res (32)
 // ------------------------------------------------------------------------------------------------
+#ifdef BFMMM_TIMELINE
+__device__ unsigned long long g_ztrace[3 * 1024];
+__device__ unsigned long long g_zphase[8 * 512];
+void fetch_ztrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ztrace), sizeof(unsigned long long) * 3 * 1024); }
+void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zphase), sizeof(unsigned long long) * 8 * 512); }
+#endif
+
 template <int BW, int LPC, bool COV>
 __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   TIMELINE(c, 0);
+#ifdef BFMMM_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    unsigned id, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_ztrace[3 * blockIdx.x] = wall_clock64();
+    g_ztrace[3 * blockIdx.x + 1] = ((unsigned long long)(id & 0xf) << 32) | hw;
+  }
+  struct EndTrace { __device__ ~EndTrace() { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ztrace[3 * blockIdx.x + 2] = wall_clock64(); } } et_;
+#endif
 #ifdef BFMMM_TIMELINE
   unsigned long long zt[10]; int zi = 0;
 #define ZT() do { zt[zi++] = clock64(); } while (0)
@@ -119,19 +136,80 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   double* sChi = gbase + (2 * K + 3) * T::STR;
   double* sRes = sChi + MMAX;
   T tE{sRes + 32};                                   // D > 0: effective nu / phi of this curve
-  copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
-  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
-  const double sigma2 = dyn->sigma2, alpha3 = dyn->alpha3, beta = dyn->beta;
+  // ---- all global loads are requested up front.  Z first: the proposal phase below needs nothing else, and loads
+  //      retire in issue order, so it can start while the record, theta and chi are still on their way ----
+  double Zold[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[min(i, n - 1) + (size_t)n * k] : 0.0;
+  double thv[4];                                     // first 1024 entries of theta (the rest, if any, follows below)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) thv[u] = c.theta[min((int)threadIdx.x + 256 * u, nth - 1)];
   Curve<BW, LPC> cv;
+  cv.load(c.rec + (size_t)min(i, n - 1) * d.LREC, P, d.LG, lp);
+  const double chi_l = (MD > 1 && lp < M) ? c.chi[min(i, n - 1) + (size_t)n * min(lp, M - 1)] : 0.0;
+  const double sigma2 = dyn->sigma2, alpha3 = dyn->alpha3, beta = dyn->beta;
+  // ---- proposal phase (UpdateMixedMembership.h:131-150): Dirichlet(a_Z_PM Z_old) through K gamma draws, their
+  //      lgamma terms and the acceptance uniform depend on Z_old and the keyed RNG only ----
+  double a_old[KMAX], mygam = 0.0, mylg = 0.0, log_uu = 0.0;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) a_old[k] = c.h.a_Z_PM * Zold[k];
+  if (valid && do_update) {
+    const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+    double a_mine = 1.0;       // lane k < K: a_old_k -- ONE gamma / lgamma sequence serves all K components
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) a_mine = a_old[k];
+    {
+      // Attempts 0 .. ZTRY-1 of every component's rejection loop run side by side on otherwise idle lanes
+      // (lane t K + k: attempt t of component k); the variate is the first accepted attempt, exactly as in the
+      // sequential loop, which only continues in the (rare) case that all ZTRY were rejected.
+      constexpr int ZTRY = 4;
+      const int lt = lp / K, lk = lp - lt * K;
+      double a_lane = 1.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K && lk == k) a_lane = a_old[k];
+      double g_try = 0.0;
+      int ok_try = 0;
+      GammaSetup gs_ = {1.0, 1.0, 1.0};
+      const uint32_t gidx = (uint32_t)(i * K + lk);
+      if (lt < ZTRY && ZTRY * K <= LPC) {
+        gs_ = rgamma_setup(key, UPD_Z_PROP, gidx, (a_lane <= 0) ? 10.0 : a_lane);      // Distributions.h:24-28
+        g_try = gs_.d;
+        ok_try = rgamma_attempt(key, UPD_Z_PROP, gidx, (uint32_t)lt, gs_, g_try) ? 1 : 0;
+      }
+      if (ZTRY * K <= LPC) {
+        double g = gs_.d;
+        int done = 0;
+#pragma unroll
+        for (int tq = 0; tq < ZTRY; ++tq) {
+          const int src = min(tq * K + lk, LPC - 1);
+          const double gt = __shfl(g_try, src, LPC);
+          const int okt = __shfl(ok_try, src, LPC);
+          if (!done) { g = gt; done = okt; }
+        }
+        if (lp < K) {
+          for (uint32_t tq = ZTRY; !done && tq < kMaxAttempts; ++tq) done = rgamma_attempt(key, UPD_Z_PROP, gidx, tq, gs_, g) ? 1 : 0;
+          mygam = g * gs_.boost;
+        }
+      } else if (lp < K) {
+        mygam = rgamma(key, UPD_Z_PROP, gidx, (a_lane <= 0) ? 10.0 : a_lane, 1.0);
+      }
+      if (lp < K) mylg = lgamma_pos(a_mine);
+    }
+    log_uu = log(runif(key, UPD_Z_ACC, (uint32_t)i));
+  }
+  // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
+  if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
+  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
-    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
     tU.zero_pads(2 * K + 3, lp);
     if (D > 0) tE.zero_pads(NR, lp);
-    if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;   // [M] = 0: pad of the 2-unrolled loops
+    if (lp <= M) sChi[lp] = chi_l;                   // [M] = 0: pad of the 2-unrolled loops
     tS.row(0)[lp] = cv.s;
   }
   ZT();
@@ -159,9 +237,6 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   }
   double logz_mine = 0.0;
   if (valid) {
-    double Zold[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
     double ucov[KMAX];                 // covariate part of u_k (D > 0)
     double uk[KMAX];
     {
@@ -225,21 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zfin[k] = Zold[k];
     if (do_update) {
-      const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-      // proposal: Dirichlet(a_Z_PM * Z_old) through K gamma draws, lane k draws component k
-      double a_old[KMAX], a_new[KMAX], Znew[KMAX];
-      double mygam = 0.0, mylg = 0.0;
-      double a_mine = 1.0;       // lane k < K: a_old_k -- ONE gamma / lgamma sequence serves all K components
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        a_old[k] = c.h.a_Z_PM * Zold[k];
-        if (k < K && lp == k) a_mine = a_old[k];
-      }
-      if (lp < K) {
-        const double a = (a_mine <= 0) ? 10.0 : a_mine;                  // Distributions.h:24-28
-        mygam = rgamma(key, UPD_Z_PROP, (uint32_t)(i * K + lp), a, 1.0);
-        mylg = lgamma_pos(a_mine);
-      }
+      double a_new[KMAX], Znew[KMAX];
       ZT();
       double gs = 0.0, lB_old = 0.0, sa_old = 0.0;
 #pragma unroll
@@ -303,11 +364,10 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
       const double lpdf_propose_new = dn - lB_old;
       const double lpdf_propose_old = dold - lB_new;
       double acceptance = z_new_lpdf - z_lpdf + lpdf_propose_old - lpdf_propose_new;
-      const double uu = runif(key, UPD_Z_ACC, (uint32_t)i);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K && Zold[k] <= 0) acceptance = 1;                        // UpdateMixedMembership.h:170-174
-      if (log(uu) < acceptance) {
+      if (log_uu < acceptance) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) Zfin[k] = Znew[k];
       }
@@ -343,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   ZT();
 #ifdef BFMMM_TIMELINE
   if (blockIdx.x == 7 && threadIdx.x == 0) for (int x = 0; x + 1 < zi; ++x) c.dyn->stamps[32 + x] = zt[x + 1] - zt[x];
+  if (blockIdx.x < 512 && threadIdx.x == 0) for (int x = 0; x + 1 < zi && x < 8; ++x) g_zphase[8 * blockIdx.x + x] = zt[x + 1] - zt[x];
 #endif
   // block partial of sum_i log Z_ik, fixed order over the groups of this block
   if (lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
@@ -373,7 +434,11 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     return;
   }
   if (mode == 0) return;
-  const int blk = blockIdx.x - 1;
+  // Workgroups 1-7 are idle: they keep curve block b at grid index 8 + b, i.e. on the XCD that runs block b of
+  // k_curve_z (workgroups go to the XCDs round-robin), so the Z / chi / record lines the two kernels hand each other
+  // iteration after iteration stay in that XCD's L2.
+  if (blockIdx.x < 8) return;
+  const int blk = blockIdx.x - 8;
   const int do_update = (mode == 2);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
@@ -558,7 +623,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
     if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, L, CV>), dim3(nblk), dim3(256), lds, st, c, do_update);  \
-    else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 1), dim3(256), lds, st, c, do_update);      \
+    else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 8), dim3(256), lds, st, c, do_update);      \
   } while (0)
   if (LPC == 32) { if (cov) LAUNCH_CURVE(32, true); else LAUNCH_CURVE(32, false); }
   else { if (cov) LAUNCH_CURVE(64, true); else LAUNCH_CURVE(64, false); }

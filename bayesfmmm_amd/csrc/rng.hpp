@@ -125,31 +125,48 @@ __host__ __device__ inline double rnorm(const RngKey& r, uint32_t upd, uint32_t 
 constexpr uint32_t kMaxAttempts = 256u;
 constexpr uint32_t kBoostAttempt = 0xFFFFu;
 
-// R::rgamma(shape, scale) in distribution (Marsaglia & Tsang 2000)
-__host__ __device__ inline double rgamma(const RngKey& r, uint32_t upd, uint32_t idx, double shape, double scale) {
+// R::rgamma(shape, scale) in distribution (Marsaglia & Tsang 2000).  Attempt t of the rejection loop is a pure
+// function of (key, update, index, t), so attempts can be evaluated in any order -- or side by side on idle
+// lanes (k_curve_z) -- and the variate is the first accepted one.
+struct GammaSetup { double d, c, boost; };
+
+__host__ __device__ inline GammaSetup rgamma_setup(const RngKey& r, uint32_t upd, uint32_t idx, double shape) {
   double a = shape, boost = 1.0, u0, u1;
   if (a < 1.0) {
     rng_block(r, upd, idx, kBoostAttempt, u0, u1);
     boost = pow(u0, 1.0 / a);
     a += 1.0;
   }
-  const double d = a - 1.0 / 3.0;
-  const double c = 1.0 / sqrt(9.0 * d);
-  double g = d;
-  for (uint32_t t = 0; t < kMaxAttempts; ++t) {
-    rng_block(r, upd, idx, t, u0, u1);
-    const double x = qnorm(u0);
-    double v = 1.0 + c * x;
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    g = d * v;
-    // Marsaglia-Tsang squeeze: a sufficient condition for the log test below, so the accept / reject
-    // decisions (and therefore the variates) are unchanged; it only skips the two logarithms
-    const double x2 = x * x;
-    if (u1 < 1.0 - 0.0331 * (x2 * x2)) break;
-    if (log(u1) < 0.5 * x2 + d - d * v + d * log(v)) break;
-  }
-  return g * boost * scale;
+  GammaSetup s;
+  s.d = a - 1.0 / 3.0;
+  s.c = 1.0 / sqrt(9.0 * s.d);
+  s.boost = boost;
+  return s;
+}
+
+// one attempt: returns true when it is accepted; g = d v either way (the loop's value after this attempt)
+__host__ __device__ inline bool rgamma_attempt(const RngKey& r, uint32_t upd, uint32_t idx, uint32_t t, const GammaSetup& s,
+                                               double& g) {
+  double u0, u1;
+  rng_block(r, upd, idx, t, u0, u1);
+  const double x = qnorm(u0);
+  double v = 1.0 + s.c * x;
+  if (v <= 0.0) return false;            // (g keeps its previous value, as in the sequential loop)
+  v = v * v * v;
+  g = s.d * v;
+  // Marsaglia-Tsang squeeze: a sufficient condition for the log test below, so the accept / reject
+  // decisions (and therefore the variates) are unchanged; it only skips the two logarithms
+  const double x2 = x * x;
+  if (u1 < 1.0 - 0.0331 * (x2 * x2)) return true;
+  return log(u1) < 0.5 * x2 + s.d - s.d * v + s.d * log(v);
+}
+
+__host__ __device__ inline double rgamma(const RngKey& r, uint32_t upd, uint32_t idx, double shape, double scale) {
+  const GammaSetup s = rgamma_setup(r, upd, idx, shape);
+  double g = s.d;
+  for (uint32_t t = 0; t < kMaxAttempts; ++t)
+    if (rgamma_attempt(r, upd, idx, t, s, g)) break;
+  return g * s.boost * scale;
 }
 
 // log density of N(mu, sd) truncated to [lo, +inf): RcppDist d_truncnorm(x, mu, sd, lo, Inf, 1)

@@ -26,7 +26,8 @@ print("pair_gram WG(0,0), rel. kernel start: begin %.2f  staged %.2f  sync %.2f 
 st_ = np.array(smp.get_state("stamps"))
 print("sweep: setup %.2f us, loop %.2f us, tail %.2f us" % ((st_[24]-st_[8])*0.01, (st_[25]-st_[24])*0.01, (st_[9]-st_[25])*0.01))
 print("sweep clocks/step  A-wave0: between %d  P1 %d  barrier %d  P2 %d  barrier %d" % tuple(st_[26:31]/21))
-print("sweep clocks/step  B-wave0: between %d  P1 %d  barrier %d  P2 %d  barrier %d" % tuple(st_[10:15]/21))
+print("sweep clocks/step  last B-wave: between %d  pre-poll %d  poll %d  rest-of-step %d  barrier %d" % tuple(st_[48:53]/21))
+print("sweep clocks/step  B-wave 4  : between %d  pre-poll %d  poll %d  rest-of-step %d  barrier %d" % tuple(st_[54:59]/21))
 try:
     tr = np.array(smp.get_state("wgtrace")).reshape(-1, 3)
     nwg = 250
@@ -55,3 +56,32 @@ print("trace entries written:", len(nz), "max wg id", nz.max())
 late = [w for w in nz if tr_all[w, 0] > t0 + 500]
 print("entries starting > 5 us after t0:", late[:20], [(round((tr_all[w,0]-t0)*0.01,2), round((tr_all[w,2]-t0)*0.01,2)) for w in late[:20]])
 print("curve_z block 7 thread 0 clocks: load+stage %d | barrier %d | u_k %d | matvec %d | dots %d | unpack+gamma/lgamma %d | lgammas+log %d | quad+accept+store %d" % tuple(np.array(smp.get_state("stamps"))[32:40]))
+try:
+    zt = np.array(smp.get_state("ztrace")).reshape(-1, 3)[:512]
+    z0 = zt[:, 0].min()
+    dur = (zt[:, 2] - zt[:, 0]) * 0.01
+    print("curve_z per-WG: start spread %.2f us, duration min %.2f median %.2f max %.2f us, last end +%.2f us" % ((zt[:, 0].max() - z0) * 0.01, dur.min(), np.median(dur), dur.max(), (zt[:, 2].max() - z0) * 0.01))
+    for x in range(8):
+        sel = [w for w in range(512) if (int(zt[w, 1]) >> 32) == x]
+        if sel: print("  xcc %d: %3d WGs, dur median %.2f max %.2f, end max +%.2f" % (x, len(sel), np.median(dur[sel]), dur[sel].max(), (zt[sel, 2].max() - z0) * 0.01))
+except Exception as ex:
+    print("no ztrace:", ex)
+try:
+    zt = np.array(smp.get_state("ztrace")).reshape(-1, 3)[:512]
+    tr = np.array(smp.get_state("wgtrace")).reshape(-1, 3)[:250]
+    print("xcc of curve_z blocks 0..9:", [int(zt[w, 1]) >> 32 for w in range(10)], " pair_gram wgs 0..9:", [int(tr[w, 1]) >> 32 for w in range(10)])
+    smp.run(bf.SWEEP_WARM, 1, first_iter=50)
+    zt2 = np.array(smp.get_state("ztrace")).reshape(-1, 3)[:512]
+    print("one more iteration -> curve_z blocks 0..9 on xcc:", [int(zt2[w, 1]) >> 32 for w in range(10)])
+except Exception as ex:
+    print("xcc probe failed:", ex)
+try:
+    zp = np.array(smp.get_state("zphase")).reshape(512, 8)
+    names = ["load+stage", "barrier", "u_k", "matvec", "dots", "gamma+lgamma", "lgammas+log", "quad+accept+store"]
+    tot = zp.sum(axis=1)
+    order = np.argsort(tot)
+    print("curve_z phase clocks over all 512 WGs (thread 0): total min %d median %d max %d" % (tot.min(), np.median(tot), tot.max()))
+    for q, nm in enumerate(names):
+        print("  %-18s min %6d  median %6d  max %6d   | in the 10 slowest WGs: median %6d" % (nm, zp[:, q].min(), np.median(zp[:, q]), zp[:, q].max(), np.median(zp[order[-10:], q])))
+except Exception as ex:
+    print("no zphase:", ex)
