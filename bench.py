@@ -191,8 +191,26 @@ def main():
             ms = fams[dom]["ms_per_launch"]
             bytes_dom = blocks[dom] * n * 8 * (P * P + P + 1)
             ach = bytes_dom / (ms * 1e-3) / 1e9
+            # measured HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (tools/profile_round.sh), condensed by tools/summarize_profile.py into profiles/ (read is corrected
+            # x2 as MI355X_MICROARCH.md prescribes for gfx950); null when no summary is committed
+            traffic = None
+            try:
+                import glob
+                summ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.json")))
+                if summ:
+                    pm = json.load(open(summ[-1]))
+                    kname = {"sweep": ["k_sweep_fast", "k_sweep"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
+                             "pair_gram": ["k_pair_gram", "k_pg_reduce"]}[dom]
+                    tb = 0.0
+                    for kn in kname:
+                        if kn in pm and pm[kn].get("hbm_read_bytes_per_launch") is not None:
+                            tb += pm[kn]["hbm_read_bytes_per_launch"] + (pm[kn].get("hbm_write_bytes_per_launch") or 0.0)
+                    traffic = tb if tb > 0 else None
+            except Exception:
+                traffic = None
             roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBS, traffic=None,
+                            frac=ach / HBM_PEAK_GBS, traffic=traffic,
                             iteration_achieved=b_alg * (args.steps / dt) / 1e9,
                             iteration_frac=b_alg * (args.steps / dt) / 1e9 / HBM_PEAK_GBS,
                             per_kernel_ms={k: round(v["ms_per_launch"], 6) for k, v in fams.items()})

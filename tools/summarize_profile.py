@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 databases written by tools/profile_round.sh into the small CSV / JSON summaries that are
+committed under profiles/ (per-kernel launch statistics of the kernel-trace pass; FETCH_SIZE / WRITE_SIZE per launch
+of the two --pmc passes, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE is doubled for wide
+coalesced reads -- both the raw and the corrected figure are kept)."""
+import json, re, sqlite3, sys
+from pathlib import Path
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+)", name)
+    return m.group(1) if m else name[:40]
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name").fetchall()
+    out = {}
+    for name, cnt, tot, avg, mn, mx in rows:
+        k = short(name)
+        o = out.setdefault(k, dict(calls=0, total_ns=0, min_ns=mn, max_ns=mx))
+        o["calls"] += cnt; o["total_ns"] += tot; o["min_ns"] = min(o["min_ns"], mn); o["max_ns"] = max(o["max_ns"], mx)
+    for o in out.values():
+        o["avg_ns"] = o["total_ns"] / o["calls"]
+    return out
+
+
+def pmc_per_launch(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = cur.execute(f"select {name_col}, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by {name_col}, counter_name").fetchall()
+    out = {}
+    for name, cname, val, nd in rows:
+        if cname != counter:
+            continue
+        k = short(name)
+        o = out.setdefault(k, dict(total=0.0, launches=0))
+        o["total"] += val; o["launches"] += nd
+    return {k: v["total"] / max(v["launches"], 1) for k, v in out.items()}
+
+
+def main():
+    src = Path(sys.argv[1]); tag = sys.argv[2]; dst = Path(sys.argv[3])
+    dst.mkdir(exist_ok=True)
+    ks = kernel_stats(src / "trace" / "run_results.db")
+    tot = sum(o["total_ns"] for o in ks.values())
+    with open(dst / f"{tag}_kernel_stats.csv", "w") as f:
+        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
+        for k, o in sorted(ks.items(), key=lambda kv: -kv[1]["total_ns"]):
+            f.write(f"{k},{o['calls']},{o['total_ns']},{o['avg_ns']:.1f},{o['min_ns']},{o['max_ns']},{100.0 * o['total_ns'] / tot:.2f}\n")
+    pmc = {}
+    for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        p = src / sub / "run_results.db"
+        if p.exists():
+            pmc[counter] = pmc_per_launch(p, counter)
+    summary = {}
+    for k in ks:
+        f_kb = pmc.get("FETCH_SIZE", {}).get(k); w_kb = pmc.get("WRITE_SIZE", {}).get(k)
+        summary[k] = dict(avg_us=ks[k]["avg_ns"] / 1e3, calls=ks[k]["calls"],
+                          fetch_size_kb_raw=f_kb, write_size_kb_raw=w_kb,
+                          # FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950: FETCH_SIZE counts 128-B requests at 64 B
+                          hbm_read_bytes_per_launch=None if f_kb is None else 2.0 * f_kb * 1024.0,
+                          hbm_write_bytes_per_launch=None if w_kb is None else w_kb * 1024.0)
+    json.dump(summary, open(dst / f"{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"])[:12]:
+        print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
+
+
+if __name__ == "__main__":
+    main()
