@@ -76,6 +76,7 @@ struct bfmmm_handle {
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
+  double* tt_save = nullptr;            // state saved across a tempered-transition block
   int profile = 0;
   double fam_ms[FAM_COUNT] = {0};
   int64_t fam_launches[FAM_COUNT] = {0};
@@ -607,8 +608,8 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   mark();
 }
 
-extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
-                         int phi_chi_zero, double beta) {
+static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+                    int phi_chi_zero, double beta, uint32_t tt_step) {
   if (!h) return fail("bfmmm_run: null handle");
   if (n_iters < 0 || first_iter < 0 || first_iter + n_iters > h->T) return fail("bfmmm_run: iterations exceed the allocated chain");
   HIPCHK(hipSetDevice(h->device));
@@ -624,7 +625,7 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   h->last_md = MD;
   Dyn dyn;
   if (dyn_get(h, dyn)) return 1;
-  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = 0; dyn.beta = beta; dyn.status = 0;
+  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
   dyn.pend_dir = -1;
   if (dyn_put(h, dyn)) return 1;
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
@@ -681,6 +682,84 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
   if (dyn.status & 1u)
     return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
                 "eigen-decomposition fallback here; not supported on the device)");
+  return 0;
+}
+
+extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+                         int phi_chi_zero, double beta) {
+  return run_impl(h, mask, first_iter, n_iters, seed, chain, phi_chi_zero, beta, 0);
+}
+
+// Tempered-transition block of BFMMM_MTT_warm_start (BFMMM.h:1556-1657) for chain iteration `iter`, whose regular
+// updates have already run (the sampler's working state is slot `iter`).  The 2 N_t tempered sweeps are ordinary
+// iterations of the same kernels with beta from the ladder and the RNG counter word tt_step = l; they write chain
+// slot `iter` directly.  CalculateTTAcceptance (CalculateTTAcceptance.h:22-97) depends on a tempered state only
+// through (sigma^2, RSS), which every sweep's residual pass leaves in Dyn, so the acceptance costs nothing extra.
+// Rejected: the saved state is restored and slot `iter` rewritten from it.  Accepted: as in the reference every block
+// of the next iteration starts from the accepted state EXCEPT gamma, which BFMMM.h:1660-1671 does not re-copy.
+extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int iter, int N_t, double beta_N_t,
+                                         uint64_t seed, uint32_t chain, double* logA_out, int* accepted_out) {
+  if (!h) return fail("bfmmm_tempered_transition: null handle");
+  if (h->c.d.D > 0 || h->c.d.mv) return fail("bfmmm_tempered_transition: only the functional model without covariates is supported");
+  if (N_t < 1 || iter < 0 || iter >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const Ctx& c = h->c;
+  const Dims& d = c.d;
+  const size_t n_th = (size_t)d.K * (d.M + 1) * d.P, n_chi = (size_t)d.n * d.M, n_Z = (size_t)d.n * d.K,
+               n_dl = (size_t)d.K * d.M, n_A = (size_t)d.K * 2, n_g = (size_t)d.K * d.P * d.M;
+  if (!h->tt_save) { if (dalloc(h, &h->tt_save, n_th + n_chi + n_Z + n_dl + n_A + n_g)) return 1; }
+  double* sv = h->tt_save;
+  double* sv_th = sv; double* sv_chi = sv_th + n_th; double* sv_Z = sv_chi + n_chi; double* sv_dl = sv_Z + n_Z;
+  double* sv_A = sv_dl + n_dl; double* sv_g = sv_A + n_A;
+  auto d2d = [&](double* dst, const double* src, size_t cnt) { return hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->st); };
+  HIPCHK(d2d(sv_th, c.theta, n_th)); HIPCHK(d2d(sv_chi, c.chi, n_chi)); HIPCHK(d2d(sv_Z, c.Z, n_Z));
+  HIPCHK(d2d(sv_dl, c.delta, n_dl)); HIPCHK(d2d(sv_A, c.Aa, n_A)); HIPCHK(d2d(sv_g, c.gamma, n_g));
+  Dyn dyn0;
+  if (dyn_get(h, dyn0)) return 1;
+  // geometric ladder, BFMMM.h:1452-1460 (the loop overwrites the last rung: ladder[i] = geom_mult^i)
+  std::vector<double> ladder((size_t)N_t, 1.0);
+  ladder[N_t - 1] = beta_N_t;
+  const double geom_mult = std::pow(beta_N_t, 1.0 / N_t);
+  for (int i = 1; i < N_t; ++i) ladder[i] = ladder[i - 1] * geom_mult;
+  const int L = 2 * N_t + 1;
+  std::vector<double> sig((size_t)L), rss((size_t)L);
+  sig[0] = dyn0.sigma2; rss[0] = dyn0.rss;
+  int temp_ind = 0;
+  for (int l = 1; l < L; ++l) {
+    if (run_impl(h, mask | U_LOGLIK, iter, 1, seed, chain, 0, ladder[temp_ind], (uint32_t)l)) return 1;
+    Dyn dl;
+    if (dyn_get(h, dl)) return 1;
+    sig[l] = dl.sigma2; rss[l] = dl.rss;
+    if (l < N_t) temp_ind = temp_ind + 1;
+    if (l > N_t) temp_ind = temp_ind - 1;
+  }
+  const double N = (double)d.n_obs_total;
+  auto PZ = [&](double b, int l) { return (-(b / 2) * std::log(sig[l])) * N - (b / (2 * sig[l])) * rss[l]; };
+  double logA = 0;
+  const int m = L - 1;
+  for (int i = 0; i < N_t - 1; ++i) {
+    logA = logA + PZ(ladder[i + 1], i);
+    logA = logA - PZ(ladder[i], i);
+    logA = logA - PZ(ladder[i + 1], m - i);
+    logA = logA + PZ(ladder[i], m - i);
+  }
+  const double logu = std::log(runif(make_key(seed, chain, (uint32_t)iter, 0), UPD_TT_ACC, 0));
+  const int accepted = (logu < logA) ? 1 : 0;
+  if (accepted) {
+    HIPCHK(d2d(c.gamma, sv_g, n_g));                 // the next iteration starts from the pre-transition gamma
+    HIPCHK(hipStreamSynchronize(h->st));
+  } else {
+    HIPCHK(d2d(c.theta, sv_th, n_th)); HIPCHK(d2d(c.chi, sv_chi, n_chi)); HIPCHK(d2d(c.Z, sv_Z, n_Z));
+    HIPCHK(d2d(c.delta, sv_dl, n_dl)); HIPCHK(d2d(c.Aa, sv_A, n_A)); HIPCHK(d2d(c.gamma, sv_g, n_g));
+    if (dyn_put(h, dyn0)) return 1;
+    if (run_impl(h, U_LOGLIK, iter, 1, seed, chain, 0, 1.0, 0)) return 1;     // rewrites chain slot `iter` from the state
+  }
+  Dyn dn;
+  if (dyn_get(h, dn)) return 1;
+  dn.iter = (uint32_t)(iter + 1); dn.slot = (uint32_t)(iter + 1); dn.tt_step = 0; dn.beta = 1.0;
+  if (dyn_put(h, dn)) return 1;
+  if (logA_out) *logA_out = logA;
+  if (accepted_out) *accepted_out = accepted;
   return 0;
 }
 

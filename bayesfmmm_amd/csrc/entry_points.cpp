@@ -412,8 +412,12 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
                                       bfmmm_result** out) {
   if (!out || !mt || !te) return efail("null argument");
   if (validate(a, 2)) return 1;
-  if (a->n_temp_trans != 0)
-    return efail("tempered transitions (n_temp_trans > 0) are not implemented in this build");
+  // UserFunctions.cpp:1475-1489
+  if (a->beta_N_t <= 0 || a->beta_N_t > 1) return efail("'beta_N_t' must be between 0 and 1");
+  if (a->N_t < 1) return efail("'N_t' must be a positive integer");
+  if (a->n_temp_trans < 0) return efail("'n_temp_trans' must be a non-negative integer");
+  if (a->n_temp_trans > 0 && (a->X || a->model == BFMMM_MODEL_MULTIVARIATE))
+    return efail("tempered transitions are implemented for the functional model without covariates only");
   if (a->r_stored_iters != 0)
     return efail("batched on-disk chains (r_stored_iters > 0 with 'dir') are not implemented in this build");
   if (a->thinning_num != 1) return efail("thinning_num != 1 only applies to on-disk batches, which are not implemented in this build");
@@ -491,6 +495,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
     }
   }
   // ---- one chain of the full sweep from the medians (BFMMM.h:1486-1498, 1500-1554) ----
+  int tt_blocks = 0, tt_accepted = 0;
   bfmmm_config cfg;
   make_cfg(a, T, &cfg);
   bfmmm_handle* h = nullptr;
@@ -509,8 +514,24 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
            bfmmm_set_state(h, "gamma", gamma_est.data(), (int64_t)K * P * M) ||
            bfmmm_set_state(h, "Phi", Phi_est.data(), (int64_t)K * P * M) || bfmmm_set_state(h, "A", A_est.data(), (int64_t)K * 2) ||
            bfmmm_set_state(h, "nu", nu_est.data(), (int64_t)K * P) || bfmmm_set_state(h, "tau", tau_est.data(), K) ||
-           bfmmm_set_state(h, "sigma_sq", &sigma_est, 1) || bfmmm_set_state(h, "chi", chi_est.data(), (int64_t)n * M) ||
-           bfmmm_run(h, mask_ws, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+           bfmmm_set_state(h, "sigma_sq", &sigma_est, 1) || bfmmm_set_state(h, "chi", chi_est.data(), (int64_t)n * M);
+  if (!rc) {
+    if (a->n_temp_trans == 0) {
+      rc = bfmmm_run(h, mask_ws, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+    } else {
+      // BFMMM.h:1500-1672: the sweep of iteration i, then -- every n_temp_trans iterations -- the tempered-transition block
+      int i0 = 0, n_blocks = 0, n_acc = 0;
+      for (int i = 0; i < T && !rc; ++i)
+        if (i > 0 && (i % a->n_temp_trans) == 0) {
+          double logA; int acc;
+          rc = bfmmm_run(h, mask_ws, i0, i + 1 - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0) ||
+               bfmmm_tempered_transition(h, mask_ws, i, a->N_t, a->beta_N_t, a->seed, (uint32_t)a->chain_offset, &logA, &acc);
+          i0 = i + 1; n_blocks += 1; n_acc += acc;
+        }
+      if (!rc && i0 < T) rc = bfmmm_run(h, mask_ws, i0, T - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+      tt_blocks = n_blocks; tt_accepted = n_acc;
+    }
+  }
   if (rc) { efail_lib(); bfmmm_destroy(h); return 1; }
   // r_stored_iters defaults to tot_mcmc_iters + 1 slots (UserFunctions.cpp:1510-1541): slot T repeats slot T-1
   const int TT = T + 1;
@@ -525,6 +546,10 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
        fetch_cov(h, r, a, T, a->covariance_adj != 0, 1);
   bfmmm_destroy(h);
   if (rc) { bfmmm_result_free(r); return 1; }
+  if (a->n_temp_trans > 0) {     // (the reference only prints its running acceptance rate, BFMMM.h:1675; exposed here)
+    put(r, "tt_blocks", {(double)tt_blocks}, {1});
+    put(r, "tt_accepted", {(double)tt_accepted}, {1});
+  }
   *out = r;
   return 0;
 }

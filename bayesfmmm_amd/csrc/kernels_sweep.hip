@@ -768,15 +768,17 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
   // than a step of the chain.  Touch both once with fire-and-forget wide loads so that the per-step register
   // prefetch only ever sees L2 hits.
   if (n_steps > 0) {
-    v2d w0 = {0, 0}, w1 = {0, 0}, w2 = {0, 0}, w3 = {0, 0};
+    // one 4-byte load per 128-byte line is enough to pull the line in
+    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     auto touch = [&](const double* src, int count) {
-      const int n2 = count / 2;
-      for (int x = tid; x < n2; x += 4 * nthr) {
-        const uint32_t o = (uint32_t)x * 16u, st4 = (uint32_t)nthr * 16u, lim = (uint32_t)(n2 - 1) * 16u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w1) : "v"(min(o + st4, lim)), "s"(src));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w2) : "v"(min(o + 2 * st4, lim)), "s"(src));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w3) : "v"(min(o + 3 * st4, lim)), "s"(src));
+      const int nl = (count * 8 + 127) / 128;          // lines
+      const uint32_t lim = (uint32_t)count * 8u - 4u;
+      for (int x = tid; x < nl; x += 4 * nthr) {
+        const uint32_t o = (uint32_t)x * 128u, st4 = (uint32_t)nthr * 128u;
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(w1) : "v"(min(o + st4, lim)), "s"(src));
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(w2) : "v"(min(o + 2 * st4, lim)), "s"(src));
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(w3) : "v"(min(o + 3 * st4, lim)), "s"(src));
       }
     };
     touch(c.H2, d.R * P * W);

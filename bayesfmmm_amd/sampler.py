@@ -109,6 +109,16 @@ class Sampler:
     def run(self, mask, n_iters, first_iter=0, seed=1, chain=0, phi_chi_zero=False, beta=1.0):
         _lib.check(self.lib.bfmmm_run(self.h, mask, first_iter, n_iters, seed, chain, int(phi_chi_zero), beta))
 
+    def tempered_transition(self, mask, iteration, N_t, beta_N_t, seed=1, chain=0):
+        """Tempered-transition block of BFMMM_warm_start (BFMMM.h:1556-1657) for the chain iteration that `run` has just
+        produced; returns (log acceptance probability, accepted)."""
+        import ctypes as C
+        la = C.c_double(0.0)
+        acc = C.c_int(0)
+        _lib.check(self.lib.bfmmm_tempered_transition(self.h, mask, iteration, N_t, beta_N_t, seed, chain,
+                                                      C.byref(la), C.byref(acc)))
+        return la.value, bool(acc.value)
+
     def get_chain(self, name, n_slots=None):
         T = self.T if n_slots is None else n_slots
         shp = {"nu": (self.K, self.P, T), "chi": (self.n, self.M, T), "Z": (self.n, self.K, T), "pi": (self.K, T),

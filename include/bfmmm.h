@@ -115,6 +115,14 @@ int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain);
 int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
               int phi_chi_zero, double beta);
 
+/* Tempered-transition block of BFMMM_MTT_warm_start (inst/include/BayesFMMM/BFMMM.h:1556-1657, ladder :1452-1460,
+ * acceptance CalculateTTAcceptance.h:22-97) for chain iteration `iter`, to be called right after bfmmm_run has
+ * produced that iteration: 2 N_t tempered sweeps of the updates in `mask` (temperatures up and down the geometric
+ * ladder ending at beta_N_t), then the Metropolis test.  Chain slot `iter` and the working state end up holding the
+ * accepted or the original draw; *logA / *accepted report the test.  Functional model without covariates only. */
+int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int iter, int N_t, double beta_N_t, uint64_t seed,
+                              uint32_t chain, double* logA, int* accepted);
+
 /* Copies chain draws to the host: slots [0, n_slots) of `name`, laid out as the reference returns
  * them: "nu" K x P x T, "chi" n x M x T, "Z" n x K x T, "pi" K x T, "alpha_3" T, "A" K x 2 x T,
  * "delta" K x M x T, "sigma_sq" T, "tau" T x K, "gamma"/"Phi" T arrays of K x P x M, "loglik" T. */

@@ -151,3 +151,173 @@ void orc_run_sweeps(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32
   free(tilde_tau);
   free(tilde_tau_xi);
 }
+
+/* ==============================================================================================
+ * Tempered transitions of BFMMM_MTT_warm_start (functional model, no covariates).
+ * ============================================================================================== */
+
+/* Geometric ladder, BFMMM.h:1452-1460.  (As in the reference the loop overwrites the last rung that was first
+ * set to beta_N_t: beta_ladder(i) = geom_mult^i with geom_mult = beta_N_t^(1/N_t).) */
+void orc_beta_ladder(int N_t, double beta_N_t, double* ladder) {
+  for (int i = 0; i < N_t; ++i) ladder[i] = 1.0;
+  ladder[N_t - 1] = beta_N_t;
+  const double geom_mult = pow(beta_N_t, 1.0 / N_t);
+  for (int i = 1; i < N_t; ++i) ladder[i] = ladder[i - 1] * geom_mult;
+}
+
+/* calculatePZeta, CalculateTTAcceptance.h:22-51 (state = slot `iter` of the TT arrays) */
+double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_chain* c) {
+  const int n = d->n, K = d->K, P = d->P, M = d->M;
+  const double* nu = c->nu + (size_t)K * P * iter;
+  const double* Phi = c->Phi + (size_t)K * P * M * iter;
+  const double* Z = c->Z + (size_t)n * K * iter;
+  const double* chi = c->chi + (size_t)n * M * iter;
+  const double sigma = c->sigma[iter];
+  double logAcceptance = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t o = d->off[i], ni = d->off[i + 1] - o;
+    for (int64_t l = 0; l < ni; ++l) {
+      const double* b = d->B + (size_t)(o + l) * P;
+      double mean = 0;
+      for (int k = 0; k < K; ++k) {
+        if (Z[i + (size_t)n * k] != 0) {
+          double dt = 0;
+          for (int p = 0; p < P; ++p) dt += nu[k + (size_t)K * p] * b[p];
+          mean = mean + Z[i + (size_t)n * k] * dt;
+          for (int m = 0; m < M; ++m) {
+            double dp = 0;
+            for (int p = 0; p < P; ++p) dp += Phi[k + (size_t)K * (p + (size_t)P * m)] * b[p];
+            mean = mean + Z[i + (size_t)n * k] * chi[i + (size_t)n * m] * dp;
+          }
+        }
+      }
+      const double res = d->y[o + l] - mean;
+      logAcceptance = logAcceptance + ((-(beta_i / 2) * log(sigma)) - (beta_i / (2 * sigma)) * (res * res));
+    }
+  }
+  return logAcceptance;
+}
+
+/* CalculateTTAcceptance, CalculateTTAcceptance.h:64-97: `tt` holds the 2 N_t + 1 tempered states */
+double orc_CalculateTTAcceptance(const orc_data* d, int N_t, const double* beta, const orc_chain* tt) {
+  double logAcceptance = 0;
+  const int m = tt->T - 1;
+  for (int i = 0; i < N_t - 1; ++i) {
+    logAcceptance = logAcceptance + orc_calculatePZeta(d, beta[i + 1], i, tt);        /* heating up */
+    logAcceptance = logAcceptance - orc_calculatePZeta(d, beta[i], i, tt);
+    logAcceptance = logAcceptance - orc_calculatePZeta(d, beta[i + 1], m - i, tt);    /* cooling down */
+    logAcceptance = logAcceptance + orc_calculatePZeta(d, beta[i], m - i, tt);
+  }
+  return logAcceptance;
+}
+
+static double* dalloc0(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+/* The tempered-transition block of iteration i, BFMMM.h:1556-1657.  On return slot i of `c` holds the accepted or
+ * the original state and slot i+1 is re-initialised from it (every block but gamma, as in the reference).
+ * Keyed RNG: (seed, chain, iteration i, tt_step l) for the tempered sweeps, (.., tt_step 0, UPD_TT_ACC) for the test. */
+void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int i, int N_t,
+                  double beta_N_t, orc_chain* c, double* logA_out, int* accepted_out) {
+  const int n = d->n, K = d->K, P = d->P, M = d->M, T = c->T;
+  const int L = 2 * N_t + 1;
+  double* ladder = dalloc0((size_t)N_t);
+  orc_beta_ladder(N_t, beta_N_t, ladder);
+  orc_chain tt;
+  memset(&tt, 0, sizeof tt);
+  tt.T = L;
+  const size_t s_nu = (size_t)K * P, s_chi = (size_t)n * M, s_Z = (size_t)n * K, s_pi = K, s_dl = (size_t)K * M,
+               s_A = (size_t)K * 2, s_g = (size_t)K * P * M;
+  tt.nu = dalloc0(s_nu * L); tt.chi = dalloc0(s_chi * L); tt.Z = dalloc0(s_Z * L); tt.pi = dalloc0(s_pi * L);
+  tt.alpha3 = dalloc0(L); tt.delta = dalloc0(s_dl * L); tt.A = dalloc0(s_A * L); tt.sigma = dalloc0(L);
+  tt.tau = dalloc0((size_t)L * K); tt.gamma = dalloc0(s_g * L); tt.Phi = dalloc0(s_g * L); tt.loglik = dalloc0(L);
+  /* initialize placeholders: slots 0 and 1 <- slot i (BFMMM.h:1557-1581) */
+  for (int s = 0; s < 2; ++s) {
+    memcpy(tt.nu + s_nu * s, c->nu + s_nu * i, sizeof(double) * s_nu);
+    memcpy(tt.chi + s_chi * s, c->chi + s_chi * i, sizeof(double) * s_chi);
+    memcpy(tt.pi + s_pi * s, c->pi + s_pi * i, sizeof(double) * s_pi);
+    tt.sigma[s] = c->sigma[i];
+    memcpy(tt.Z + s_Z * s, c->Z + s_Z * i, sizeof(double) * s_Z);
+    memcpy(tt.delta + s_dl * s, c->delta + s_dl * i, sizeof(double) * s_dl);
+    memcpy(tt.gamma + s_g * s, c->gamma + s_g * i, sizeof(double) * s_g);
+    memcpy(tt.Phi + s_g * s, c->Phi + s_g * i, sizeof(double) * s_g);
+    memcpy(tt.A + s_A * s, c->A + s_A * i, sizeof(double) * s_A);
+    for (int k = 0; k < K; ++k) tt.tau[s + (size_t)L * k] = c->tau[i + (size_t)T * k];
+    tt.alpha3[s] = c->alpha3[i];
+  }
+  double* tilde_tau = dalloc0((size_t)K * M);
+  int temp_ind = 0;
+  for (int l = 1; l < L; ++l) {              /* BFMMM.h:1586-1634 */
+    orc_rng r = {seed, chain, (uint32_t)i, (uint32_t)l};
+    const double bl = ladder[temp_ind];
+    orc_updateZ_PM(d, &r, bl, l, L, h->a_Z_PM, &tt);
+    orc_updatePi_PM(d, &r, l, L, h->c, h->a_pi_PM, &tt);
+    orc_updateAlpha3(d, &r, l, L, h->b, h->var_alpha3, &tt);
+    orc_tilde_tau(K, M, tt.delta + s_dl * l, tilde_tau);
+    orc_updatePhi(d, &r, bl, l, L, tilde_tau, &tt);
+    orc_updateDelta(d, &r, l, L, &tt);
+    orc_updateA(d, &r, l, L, h, &tt);
+    orc_updateGamma(d, &r, l, L, h->nu_1, &tt);
+    orc_updateNu(d, &r, bl, l, L, &tt);
+    orc_updateTau(d, &r, l, L, h->alpha_nu, h->beta_nu, &tt);
+    orc_updateSigma(d, &r, bl, 1, l, L, h->alpha_0, h->beta_0, &tt);
+    orc_updateChi(d, &r, bl, l, L, &tt);
+    if (l < N_t) temp_ind = temp_ind + 1;
+    if (l > N_t) temp_ind = temp_ind - 1;
+  }
+  const double logA = orc_CalculateTTAcceptance(d, N_t, ladder, &tt);
+  orc_rng r0 = {seed, chain, (uint32_t)i, 0};
+  const double logu = log(orc_runif(&r0, UPD_TT_ACC, 0));
+  int accepted = 0;
+  if (logu < logA) {                         /* BFMMM.h:1641-1657 */
+    const int f = L - 1;
+    accepted = 1;
+    memcpy(c->nu + s_nu * i, tt.nu + s_nu * f, sizeof(double) * s_nu);
+    memcpy(c->chi + s_chi * i, tt.chi + s_chi * f, sizeof(double) * s_chi);
+    memcpy(c->pi + s_pi * i, tt.pi + s_pi * f, sizeof(double) * s_pi);
+    c->sigma[i] = tt.sigma[f];
+    memcpy(c->Z + s_Z * i, tt.Z + s_Z * f, sizeof(double) * s_Z);
+    memcpy(c->delta + s_dl * i, tt.delta + s_dl * f, sizeof(double) * s_dl);
+    memcpy(c->gamma + s_g * i, tt.gamma + s_g * f, sizeof(double) * s_g);
+    memcpy(c->Phi + s_g * i, tt.Phi + s_g * f, sizeof(double) * s_g);
+    memcpy(c->A + s_A * i, tt.A + s_A * f, sizeof(double) * s_A);
+    for (int k = 0; k < K; ++k) c->tau[i + (size_t)T * k] = tt.tau[f + (size_t)L * k];
+    c->alpha3[i] = tt.alpha3[f];
+  }
+  /* initialize next state (BFMMM.h:1660-1671): every block except gamma */
+  if (i + 1 < T) {
+    memcpy(c->nu + s_nu * (i + 1), c->nu + s_nu * i, sizeof(double) * s_nu);
+    memcpy(c->chi + s_chi * (i + 1), c->chi + s_chi * i, sizeof(double) * s_chi);
+    memcpy(c->pi + s_pi * (i + 1), c->pi + s_pi * i, sizeof(double) * s_pi);
+    c->sigma[i + 1] = c->sigma[i];
+    memcpy(c->Z + s_Z * (i + 1), c->Z + s_Z * i, sizeof(double) * s_Z);
+    memcpy(c->delta + s_dl * (i + 1), c->delta + s_dl * i, sizeof(double) * s_dl);
+    memcpy(c->A + s_A * (i + 1), c->A + s_A * i, sizeof(double) * s_A);
+    for (int k = 0; k < K; ++k) c->tau[(i + 1) + (size_t)T * k] = c->tau[i + (size_t)T * k];
+    memcpy(c->Phi + s_g * (i + 1), c->Phi + s_g * i, sizeof(double) * s_g);
+    c->alpha3[i + 1] = c->alpha3[i];
+  }
+  if (logA_out) *logA_out = logA;
+  if (accepted_out) *accepted_out = accepted;
+  free(tilde_tau); free(ladder);
+  free(tt.nu); free(tt.chi); free(tt.Z); free(tt.pi); free(tt.alpha3); free(tt.delta); free(tt.A); free(tt.sigma);
+  free(tt.tau); free(tt.gamma); free(tt.Phi); free(tt.loglik);
+}
+
+/* BFMMM_MTT_warm_start with n_temp_trans > 0 (BFMMM.h:1502-1672): the untempered sweep of iteration i, then -- when
+ * i % n_temp_trans == 0 and i > 0 -- the tempered-transition block, then loglik(i).  logA / accepted: one entry per
+ * iteration (NaN / -1 where no block ran). */
+void orc_run_warm_tt(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int T, int first_iter,
+                     int n_iter, int N_t, int n_temp_trans, double beta_N_t, orc_chain* c, double* logA, int* accepted) {
+  for (int i = first_iter; i < first_iter + n_iter && i < T; ++i) {
+    orc_run_sweeps(d, h, seed, chain, ORC_SWEEP_WARM, 0, T, i, 1, c);
+    if (logA) logA[i] = NAN;
+    if (accepted) accepted[i] = -1;
+    if (n_temp_trans > 0 && (i % n_temp_trans) == 0 && i > 0) {
+      double la; int acc;
+      orc_tt_block(d, h, seed, chain, i, N_t, beta_N_t, c, &la, &acc);
+      if (logA) logA[i] = la;
+      if (accepted) accepted[i] = acc;
+      c->loglik[i] = orc_calcLikelihood(d, i, c);       /* BFMMM.h:1670 (after the block) */
+    }
+  }
+}

@@ -55,6 +55,30 @@ def test_three_stage_pipeline(example):
     assert np.median(mcmc["sigma_sq"][T // 2:T]) < 0.2 * ysd
 
 
+def test_warm_start_with_tempered_transitions(example):
+    """BFMMM_warm_start(n_temp_trans = 25, N_t = 3, beta_N_t = 0.7): the documented tempered-transition options
+    (UserFunctions.cpp:1151-1153) run through the entry point; a run with the option off is unchanged by its presence."""
+    from bayesfmmm_amd import _lib, api
+    e = example
+    T = 150
+    common = (e["K"], e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    est1 = api.BFMMM_Nu_Z_multiple_try(T, 1, *common, seed=3)
+    est2 = api.BFMMM_Theta_est(T, 1, *common, est1, seed=4)
+    plain = api.BFMMM_warm_start(T, *common, est1, est2, seed=5)
+    tt = api.BFMMM_warm_start(T, *common, est1, est2, seed=5, n_temp_trans=25, N_t=3, beta_N_t=0.7)
+    assert tt["tt_blocks"] == 5 and 0 <= tt["tt_accepted"] <= 5          # iterations 25, 50, 75, 100, 125
+    assert np.isfinite(tt["loglik"][:T]).all() and np.allclose(tt["Z"][:, :, :T].sum(axis=1), 1.0)
+    # identical up to and including iteration 24 (same keyed variates), the first block acts on slot 25
+    np.testing.assert_array_equal(tt["nu"][:, :, :25], plain["nu"][:, :, :25])
+    assert "tt_blocks" not in plain
+    ysd = np.concatenate(e["Y"]).var()
+    assert np.median(tt["sigma_sq"][T // 2:T]) < 0.2 * ysd
+    with pytest.raises(_lib.BfmmmError, match="'beta_N_t' must be between 0 and 1"):
+        api.BFMMM_warm_start(T, *common, est1, est2, n_temp_trans=10, N_t=2, beta_N_t=1.5)
+    with pytest.raises(_lib.BfmmmError, match="'N_t' must be a positive integer"):
+        api.BFMMM_warm_start(T, *common, est1, est2, n_temp_trans=10, N_t=0)
+
+
 def test_reference_argument_checks(example):
     from bayesfmmm_amd import _lib, api
     e = example
