@@ -28,6 +28,7 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
+void launch_loglik_flush(const Ctx& c, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 void launch_cov_block(const Ctx& c, hipStream_t st);
 void prepare_cov_kernels();
@@ -604,7 +605,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   launch_curve(c, 1, p.chi ? (p.chi_update ? 2 : 1) : 0, st);
   if (c.d.D > 0) launch_cov_block(c, st);      // eta, tau_eta, Xi, delta_xi, A_xi, gamma_xi (+ residual sums)
   mark();
-  launch_loglik(c, p.use_rss_part, 0, st);
+  if (!c.defer_loglik) launch_loglik(c, p.use_rss_part, 0, st);      // otherwise: job_hyper + the next k_pair_gram (scalar_jobs.hpp)
   mark();
 }
 
@@ -622,11 +623,16 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if ((size_t)NKS * c.d.NT * 256 > h->pg_part_doubles) return fail("bfmmm_run: internal workspace too small");
   Plan plan = make_plan(mask, MD);
   if (c.d.D > 0) { plan.z = true; plan.chi = true; plan.use_rss_part = 1; }
+  // without covariates the iteration ends with k_curve_chi: its scalar-job workgroup advances the counters and the
+  // log-likelihood is reduced by the next iteration's k_pair_gram job (one kernel boundary less per iteration)
+  c.defer_loglik = (c.d.D == 0) ? 1 : 0;
+  c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
   Dyn dyn;
   if (dyn_get(h, dyn)) return 1;
   dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
   dyn.pend_dir = -1;
+  dyn.ll_pending = 0;
   if (dyn_put(h, dyn)) return 1;
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
   HIPCHK(hipEventRecord(h->ev0, h->st));
@@ -636,7 +642,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       launch_iteration(h, c, plan, NKS, KS, h->st, &evs);
       HIPCHK(hipStreamSynchronize(h->st));
       const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
-      const bool ran[6] = {plan.z, true, plan.factor, true, true, true};
+      const bool ran[6] = {plan.z, true, plan.factor, true, true, c.defer_loglik == 0};
       for (int q = 0; q < 6; ++q) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, evs[q], evs[q + 1]);
@@ -667,6 +673,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       for (; it + GRAPH_UNROLL <= n_iters; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
     for (; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
   }
+  if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);
   if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter, first_iter + n_iters, h->st);

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
       sRes[q] = dotL<LPC>(ra, rb);
     }
     if (Mu > 0) {
-      const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+      const RngKey key = make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step);
       if (lp < M) sZn[lp] = rnorm(key, UPD_CHI, (uint32_t)(i * M + lp));
     }
     __builtin_amdgcn_wave_barrier();
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     if (Mu > 0) {
       // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
       double dl[MMAX];
-      double* cslot = c.c_chi + (size_t)dyn->slot * n * M;
+      double* cslot = c.c_chi + (size_t)dyn->slot_hyper * n * M;
 #pragma unroll
       for (int m = 0; m < MMAX; ++m) {
         dl[m] = 0.0;

@@ -990,6 +990,12 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_s
   }
 }
 
+// reduces a still-pending log-likelihood (launched once at the end of a run)
+__global__ __launch_bounds__(256) void k_loglik_flush(Ctx c) {
+  __shared__ double red[256];
+  if (c.dyn->ll_pending) deferred_loglik(c, red);
+}
+
 // broadcast the current value of blocks a sweep does not update into chain slots [s0, s1)
 __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1) {
   const size_t total = len * (size_t)(s1 - s0);
@@ -1052,6 +1058,8 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   hipLaunchKernelGGL(k_sweep, dim3(1), dim3(SW_THREADS), lds, st, c);
   return 0;
 }
+
+void launch_loglik_flush(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_loglik_flush, dim3(1), dim3(256), 0, st, c); }
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
   hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, st, c, use_rss_part, r_stored);

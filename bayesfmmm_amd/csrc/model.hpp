@@ -42,10 +42,12 @@ struct Dyn {
   uint32_t slot;        // chain slot that sweep writes (iter % r_stored_iters)
   uint32_t tt_step;     // tempered-transition sub-step (0 outside)
   uint32_t status;      // sticky error bits (1: precision matrix not positive definite)
-  uint32_t iter_hyper;  // snapshot of iter / slot taken by k_sweep for the off-critical-path k_hyper,
-  uint32_t slot_hyper;  //   which may still be running when k_loglik advances the counters
+  uint32_t iter_hyper;  // snapshot of iter / slot taken by the sweep kernel for k_curve_chi, whose scalar-job workgroup
+  uint32_t slot_hyper;  //   advances iter / slot at its end while curve workgroups may still be running
   int32_t pend_dir;     // eta / Xi direction whose delta_cur has not been applied to c_i, g_i yet (-1: none)
-  uint32_t pad0_;
+  uint32_t ll_pending;  // a log-likelihood (slot ll_slot) is still to be reduced from the residual partial sums
+  uint32_t ll_slot;
+  uint32_t ll_use_part;
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
   double alpha3;
@@ -126,6 +128,8 @@ struct Ctx {
   double* Lz2;                  // A2 x P
   double* step_part;            // NBS x P         partial sums of w (s_i - g_i) of the current step
   double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
+  int defer_loglik;             // the iteration has no k_loglik: bookkeeping in job_hyper, reduction in the next k_pair_gram
+  int ll_use_part;              // (deferred) log-likelihood from the per-curve residual partial sums
   int covariance_adj;           // Xi block on (BFMMM.h:4602 vs :4067)
   int A2;                       // eta / xi directions: K*D (+ K*M*D)
   int NB2, NBS;

@@ -34,6 +34,34 @@ __device__ inline double block_sum256(double v, double* scratch) {
 __device__ inline double logGamma_ref(double x) { return log(tgamma(x)); }   // Distributions.h:13-15
 
 // ------------------------------------------------------------------------------------------------
+// calcLikelihood (CalculateLikelihood.h:19-44; MV :150-160) of the iteration whose residual sums are pending: fixed-order
+// sum of the per-block partials of k_curve_chi (or the sweep's quadratic-form RSS), then the closed form in sigma^2.
+// 256 threads; `red` is 256 doubles of LDS scratch.
+__device__ inline void deferred_loglik(const Ctx& c, double* red) {
+  Dyn* dyn = c.dyn;
+  const int tid = threadIdx.x;
+  double rss = dyn->rss;
+  if (dyn->ll_use_part) {
+    double acc = 0.0;
+    const int per = (c.nblk_curve + 255) / 256;
+    for (int b = tid * per; b < min(c.nblk_curve, (tid + 1) * per); ++b) acc += c.rss_part[b];
+    rss = block_sum256(acc, red);
+  }
+  if (tid == 0) {
+    const double s2 = dyn->sigma2;
+    double ll;
+    if (c.d.mv)   // calcLikelihoodMV: (y_obs.n_cols / 2) is an integer division, CalculateLikelihood.h:155
+      ll = -(double)c.d.n * ((c.d.P / 2) * log(2 * 3.14159265358979323846 * s2)) - (1 / (s2 * 2)) * rss;
+    else
+      ll = -(double)c.d.n_obs_total * (0.91893853320467274178 + log(sqrt(s2))) - rss / (2.0 * s2);
+    dyn->rss = rss;
+    dyn->loglik = ll;
+    if (c.mask & U_LOGLIK) c.c_loglik[dyn->ll_slot] = ll;
+    dyn->ll_pending = 0u;
+  }
+  __syncthreads();
+}
+
 constexpr int PI_ALPHA_LDS_DOUBLES = KMAX * 256 + 10 * KMAX + 16;
 
 __device__ inline void job_pi_alpha(const Ctx& c) {
@@ -51,6 +79,7 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
   const int K = d.K, n = d.n, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
   const uint32_t mask = c.mask;
+  if (dyn->ll_pending) deferred_loglik(c, smem);
   if (!(mask & (U_PI | U_ALPHA3))) {
     if (tid == 0) {
       c.c_alpha3[dyn->slot] = dyn->alpha3;
@@ -224,7 +253,7 @@ __device__ inline void job_hyper(const Ctx& c) {
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
-  const uint32_t mask = c.mask, slot = dyn->slot;
+  const uint32_t mask = c.mask, slot = dyn->slot_hyper;
   const bool phi_on = MD > 1;
   const bool do_delta = (mask & U_DELTA) && phi_on, do_A = (mask & U_A) && phi_on, do_gamma = (mask & U_GAMMA) && phi_on;
   const bool do_tau = (mask & U_TAU) != 0;
@@ -360,6 +389,16 @@ __device__ inline void job_hyper(const Ctx& c) {
   if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
   if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
   if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
+  // end-of-iteration bookkeeping (when the iteration has no k_loglik): the curve workgroups of this kernel work from the
+  // sweep's snapshot (iter_hyper / slot_hyper), so the counters can advance here; the log-likelihood of the finished
+  // iteration is reduced by the next kernel that has an idle workgroup (deferred_loglik)
+  if (c.defer_loglik && tid == 0) {
+    dyn->ll_slot = slot;
+    dyn->ll_use_part = (uint32_t)c.ll_use_part;
+    dyn->ll_pending = 1u;
+    dyn->iter = dyn->iter_hyper + 1u;
+    dyn->slot = dyn->iter_hyper + 1u;
+  }
 }
 
 }  // namespace bfmmm
