@@ -36,6 +36,7 @@ void prepare_cov_kernels();
 void fetch_wgtrace(unsigned long long* out);
 void fetch_ztrace(unsigned long long* out);
 void fetch_zphase(unsigned long long* out);
+void fetch_fct(unsigned long long* out);
 #endif
 }  // namespace bfmmm
 
@@ -514,6 +515,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   else if (s == "status") { if (need(1)) return 1; out[0] = (double)dyn.status; }
   else if (s == "stamps") { if (need(64)) return 1; for (int q = 0; q < 64; ++q) out[q] = (double)(dyn.stamps[q] % 100000000000ULL); }
 #ifdef BFMMM_TIMELINE
+  else if (s == "fct") { if (need(8)) return 1; unsigned long long w[8]; fetch_fct(w); for (int q = 0; q < 8; ++q) out[q] = (double)(w[q] % 100000000000ULL); }
   else if (s == "zphase") { if (need(4096)) return 1; std::vector<unsigned long long> w(4096); fetch_zphase(w.data()); for (int q = 0; q < 4096; ++q) out[q] = (double)w[q]; }
   else if (s == "ztrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_ztrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
   else if (s == "wgtrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_wgtrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }

@@ -16,6 +16,13 @@
 
 namespace bfmmm {
 
+#ifdef BFMMM_TIMELINE
+static __device__ unsigned long long g_fct[8];
+#define FCT(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_fct[i] = wall_clock64(); } while (0)
+#else
+#define FCT(i) do { } while (0)
+#endif
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -57,6 +64,7 @@ __device__ inline bool factor_wave(const double* S, double* X, const double* zv,
     }
     if (lane == k) { u[0] = ukk; rinv = rk; }
   }
+  FCT(0);
   // column `lane` of X = U^-1 by back substitution; xw[t] = X(i + t, lane)
   const double zreg = (lane < P) ? zv[lane] : 0.0;
   double xw[BWT + 1];
@@ -75,6 +83,7 @@ __device__ inline bool factor_wave(const double* S, double* X, const double* zv,
     for (int t = BWT; t >= 2; --t) xw[t] = xw[t - 1];
     xw[1] = xi;
   }
+  FCT(1);
   if (lane < P) Lz_out[lane] = lzacc;
   return bad;
 }
@@ -94,6 +103,7 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
     }
   }
   __syncthreads();
+  FCT(2);
   // C = X' X on the matrix cores: tile (pt, qt) of 16 x 16, K = P rounded up to 4 (rows k > min(p, q) of X are zero)
   {
     constexpr int NTL = PP / 16;
@@ -114,6 +124,7 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       }
     }
   }
+  FCT(3);
   if (Lg)
     for (int e = tid; e < PP * PP; e += 256) {
       const int p = e & (PP - 1), q = e / PP;

@@ -30,6 +30,10 @@ namespace bfmmm {
 
 
 
+#ifdef BFMMM_TIMELINE
+void fetch_fct(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fct), sizeof(unsigned long long) * 8); }
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // counter (vmcnt(0)), which would serialise the global prefetches the sweep keeps in flight
 // across its barriers.
@@ -339,6 +343,12 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   }
   const int a = blockIdx.x;
   const int j = a / MD, mt = a - j * MD;
+#ifdef BFMMM_TIMELINE
+#define FST(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) c.dyn->stamps[48 + (i)] = wall_clock64(); } while (0)
+#else
+#define FST(i) do { } while (0)
+#endif
+  FST(0);
   const int AP = A * P, PS = P + 2 * BW + 1;
   double* S = smem;                 // PP x PP : Prec (col-major, S[i + PP*k])
   double* X = S + PP * PP;          // PP x PP : U^-1, row-major X[i*PP + c]
@@ -376,7 +386,9 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     const uint32_t idx0 = (mt == 0) ? (uint32_t)(j * P) : (uint32_t)((j * M + (mt - 1)) * P);
     zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
   }
+  FST(1);
   __syncthreads();
+  FST(2);
 #pragma unroll
   for (int it = 0; it < MAXI; ++it) {
     const int e = tid + 256 * it;
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     }
   }
   __syncthreads();
+  FST(3);
   // ---- r_a = t_a - sum_b H_ab theta_b : 8 lanes per p, fixed summation order ----
   for (int p0 = 0; p0 < P; p0 += 32) {
     const int p = p0 + (tid >> 3), g = tid & 7;
@@ -433,6 +446,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
       c.hq[a * P + p] = part[a * P + p];
     }
   }
+  FST(4);
   if (!upd) return;
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
@@ -453,9 +467,11 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     S[e] = v;
     X[e] = 0.0;
   }
+  FST(5);
   __syncthreads();
   const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
                                    c.Lz + (size_t)a * P, tid);
+  FST(6);
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 

@@ -85,3 +85,6 @@ try:
         print("  %-18s min %6d  median %6d  max %6d   | in the 10 slowest WGs: median %6d" % (nm, zp[:, q].min(), np.median(zp[:, q]), zp[:, q].max(), np.median(zp[order[-10:], q])))
 except Exception as ex:
     print("no zphase:", ex)
+print("factor WG1 (us from its start): loads issued+zv %.2f | barrier %.2f | band products done %.2f | r reduce %.2f | Prec built %.2f | factor_core %.2f" % tuple((st[49:55]-st[48])))
+fc = np.array(smp.get_state("fct")) * 0.01
+print("factor_core: cholesky %.2f us | back-substitution %.2f | barrier %.2f | MFMA C + stores %.2f (then L copy)" % (fc[0]-st[53], fc[1]-fc[0], fc[2]-fc[1], fc[3]-fc[2]))
