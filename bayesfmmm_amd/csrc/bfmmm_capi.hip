@@ -709,7 +709,7 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
 extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int iter, int N_t, double beta_N_t,
                                          uint64_t seed, uint32_t chain, double* logA_out, int* accepted_out) {
   if (!h) return fail("bfmmm_tempered_transition: null handle");
-  if (h->c.d.D > 0 || h->c.d.mv) return fail("bfmmm_tempered_transition: only the functional model without covariates is supported");
+  if (h->c.d.D > 0) return fail("bfmmm_tempered_transition: covariate-adjusted models are not supported");
   if (N_t < 1 || iter < 0 || iter >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const Ctx& c = h->c;

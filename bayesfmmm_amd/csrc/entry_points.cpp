@@ -416,8 +416,8 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   if (a->beta_N_t <= 0 || a->beta_N_t > 1) return efail("'beta_N_t' must be between 0 and 1");
   if (a->N_t < 1) return efail("'N_t' must be a positive integer");
   if (a->n_temp_trans < 0) return efail("'n_temp_trans' must be a non-negative integer");
-  if (a->n_temp_trans > 0 && (a->X || a->model == BFMMM_MODEL_MULTIVARIATE))
-    return efail("tempered transitions are implemented for the functional model without covariates only");
+  if (a->n_temp_trans > 0 && a->X)
+    return efail("tempered transitions are implemented for the models without covariates only");
   if (a->r_stored_iters != 0)
     return efail("batched on-disk chains (r_stored_iters > 0 with 'dir') are not implemented in this build");
   if (a->thinning_num != 1) return efail("thinning_num != 1 only applies to on-disk batches, which are not implemented in this build");

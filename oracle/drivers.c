@@ -174,6 +174,25 @@ double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_
   const double* chi = c->chi + (size_t)n * M * iter;
   const double sigma = c->sigma[iter];
   double logAcceptance = 0;
+  if (d->mv) {   /* calculatePZetaMV, CalculateTTAcceptance.h:109-133 (row i of Y = the P observations of "curve" i) */
+    double* mean = (double*)malloc(sizeof(double) * (size_t)P);
+    for (int i = 0; i < n; ++i) {
+      for (int p = 0; p < P; ++p) mean[p] = 0;
+      for (int k = 0; k < K; ++k) {
+        if (Z[i + (size_t)n * k] != 0) {
+          for (int p = 0; p < P; ++p) mean[p] = mean[p] + Z[i + (size_t)n * k] * nu[k + (size_t)K * p];
+          for (int m = 0; m < M; ++m)
+            for (int p = 0; p < P; ++p)
+              mean[p] = mean[p] + Z[i + (size_t)n * k] * chi[i + (size_t)n * m] * Phi[k + (size_t)K * (p + (size_t)P * m)];
+        }
+      }
+      double ss = 0;
+      for (int p = 0; p < P; ++p) { const double r = d->y[d->off[i] + p] - mean[p]; ss += r * r; }
+      logAcceptance = logAcceptance + ((-(beta_i / 2) * log(sigma) * P) - (beta_i / (2 * sigma)) * ss);
+    }
+    free(mean);
+    return logAcceptance;
+  }
   for (int i = 0; i < n; ++i) {
     const int64_t o = d->off[i], ni = d->off[i + 1] - o;
     for (int64_t l = 0; l < ni; ++l) {

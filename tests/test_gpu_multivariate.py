@@ -108,3 +108,22 @@ def test_mv_example_pipeline():
     assert np.allclose(mcmc["Z"][:, :, :T].sum(axis=1), 1.0)
     with pytest.raises(Exception, match="'K' must be an integer greater than or equal to 2"):
         api.BMVMMM_Nu_Z_multiple_try(T, 1, 1, Y, M)
+
+
+def test_mv_tempered_transitions_match_oracle():
+    """BMVMMM warm start with tempered transitions (BFMMM.h:2677-2760, CalculateTTAcceptanceMV) against the oracle."""
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    T, N_t, ntt, bN = 7, 3, 3, 0.5
+    sim, model, ch, smp = setup(seed=21, T=T)
+    h = O.make_hyper(sim["K"])
+    push_state(smp, ch)
+    logA_ref, acc_ref = O.run_warm_tt(model, h, ch, N_t, ntt, bN, seed=8)
+    smp.run(S.SWEEP_WARM, 4, first_iter=0, seed=8)
+    la3, a3 = smp.tempered_transition(S.SWEEP_WARM, 3, N_t, bN, seed=8)
+    smp.run(S.SWEEP_WARM, 3, first_iter=4, seed=8)
+    la6, a6 = smp.tempered_transition(S.SWEEP_WARM, 6, N_t, bN, seed=8)
+    for la, a, i in ((la3, a3, 3), (la6, a6, 6)):
+        assert int(a) == acc_ref[i] and abs(la - logA_ref[i]) < 1e-6 * max(1.0, abs(logA_ref[i])), (i, la, logA_ref[i])
+    for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]:
+        assert rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm))) < 2e-6, nm
