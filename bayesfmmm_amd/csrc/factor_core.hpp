@@ -50,8 +50,12 @@ __device__ inline bool factor_wave(const double* S, double* X, const double* zv,
     for (int t = 1; t <= BWT; ++t) dloc -= u[t] * u[t];
     const double dk = readlane_f64(dloc, k);
     if (!(dk > 0.0)) bad = true;
-    const double ukk = sqrt(dk);
-    const double rk = 1.0 / ukk;
+    // 1 / sqrt(dk) from the hardware estimate and two Newton steps (the pivot is on the 30-step dependent chain:
+    // a correctly rounded sqrt followed by a division costs three times as many dependent instructions)
+    double rk = __builtin_amdgcn_rsq(dk);
+    rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+    rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+    const double ukk = dk * rk;
     double uk[BWT + 1];
 #pragma unroll
     for (int m = 1; m < BWT; ++m) uk[m] = readlane_f64(u[m], k);      // U(k, k + m)

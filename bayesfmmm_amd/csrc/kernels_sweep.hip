@@ -377,6 +377,18 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     }
   }
   const double tv0 = c.tvec[a * P + min(tid >> 3, P - 1)];      // t_a[p] of the r-reduction's first pass
+  // prior entries of the band of Prec this thread will build: element (p, p + t), t <= BWP (two per thread at most)
+  double pri[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
+    const bool in = t <= d.BWP && q < P;
+    const int pc = min(p, P - 1), qc = min(q, P - 1);
+    double v = 0.0;
+    if (mt == 0) v = d.mv ? 0.0 : c.Pmat[pc + (size_t)P * qc];
+    else v = c.gamma[j + (size_t)K * (pc + (size_t)P * (mt - 1))];
+    pri[u] = (in && (mt == 0 || t == 0)) ? v : 0.0;
+  }
   const double dlt = (mt > 0 && tid < M) ? c.delta[j + (size_t)K * tid] : 1.0;
   const double f = dyn->beta / dyn->sigma2;
   const double tau_j = dyn->tau[j];
@@ -451,21 +463,17 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
   for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
-  for (int e = tid; e < PP * PP; e += 256) {
-    const int p = e & (PP - 1), q = e / PP;
-    double v = 0.0;
-    if (p < P && q < P) {
-      const int lo = min(p, q), dd = max(p, q) - lo;
-      v = (dd <= BW) ? f * hb2[lo * W + BW + dd] : 0.0;
-      if (mt == 0) {
-        if (d.mv) { if (p == q) v += 1.0 / tau_j; }               // UpdateNu.h:197 (MV)
-        else v += tau_j * c.Pmat[p + (size_t)P * q];                // UpdateNu.h:66
-      } else if (p == q) {
-        v += tt * c.gamma[j + (size_t)K * (p + (size_t)P * (mt - 1))];   // UpdatePhi.h:76-78
-      }
+  // only the band of Prec is read by the factorisation (factor_core): (BWP + 1) x P entries
+  for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
+    if (t <= d.BWP && q < P) {
+      double v = (t <= BW) ? f * hb2[p * W + BW + t] : 0.0;
+      if (mt == 0) v += d.mv ? ((t == 0) ? 1.0 / tau_j : 0.0) : tau_j * pri[u];    // UpdateNu.h:197 (MV) / :66
+      else v += tt * pri[u];                                                       // UpdatePhi.h:76-78 (diagonal)
+      S[p + PP * q] = v;
     }
-    S[e] = v;
-    X[e] = 0.0;
   }
   FST(5);
   __syncthreads();
