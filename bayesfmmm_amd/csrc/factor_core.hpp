@@ -34,7 +34,7 @@ __device__ inline double readlane_f64(double v, int lane) {     // lane is wave-
 
 // wave 0: reverse Cholesky, X = U^-1 (written to LDS), L z
 template <int PP, int BWT>
-__device__ inline bool factor_wave(const double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
+__device__ inline bool factor_wave(double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
   double s[BWT + 1], u[BWT + 1];       // s[t] = Prec(i, i + t),  u[t] = U(i, i + t)
 #pragma unroll
   for (int t = 0; t <= BWT; ++t) {
@@ -69,20 +69,38 @@ __device__ inline bool factor_wave(const double* S, double* X, const double* zv,
     if (lane == k) { u[0] = ukk; rinv = rk; }
   }
   FCT(0);
-  // column `lane` of X = U^-1 by back substitution; xw[t] = X(i + t, lane)
-  const double zreg = (lane < P) ? zv[lane] : 0.0;
+  // column `lane` of X = U^-1 by back substitution; xw[t] = X(i + t, lane).  Row i of U (its band, 1 / U(i,i)) and
+  // z_i are needed by every lane: lane i parks them in LDS once (the band of Prec in S has been consumed) and the
+  // loop reads them back with wave-uniform addresses, one row ahead, instead of 2 (BWT + 2) v_readlane per row.
+  constexpr int BS = BWT + 2;          // doubles per parked row: 1/U(i,i), U(i,i+1..i+BWT), z_i
+  double* bc = S;
+  if (lane < P) {
+    bc[lane * BS] = rinv;
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) bc[lane * BS + t] = u[t];
+    bc[lane * BS + BWT + 1] = zv[lane];
+  }
+  __builtin_amdgcn_wave_barrier();
   double xw[BWT + 1];
 #pragma unroll
   for (int t = 0; t <= BWT; ++t) xw[t] = 0.0;
   double lzacc = 0.0;
+  double nxt[BS];
+#pragma unroll
+  for (int t = 0; t < BS; ++t) nxt[t] = bc[(P - 1) * BS + t];
   for (int i = P - 1; i >= 0; --i) {
-    const double ri = readlane_f64(rinv, i);
+    double cur[BS];
+#pragma unroll
+    for (int t = 0; t < BS; ++t) cur[t] = nxt[t];
+    const int ip = max(i - 1, 0);
+#pragma unroll
+    for (int t = 0; t < BS; ++t) nxt[t] = bc[ip * BS + t];
     double acc = 0.0;
 #pragma unroll
-    for (int t = 1; t <= BWT; ++t) acc += readlane_f64(u[t], i) * xw[t];
-    const double xi = (lane == i) ? ri : ((lane > i) ? -(acc * ri) : 0.0);
+    for (int t = 1; t <= BWT; ++t) acc += cur[t] * xw[t];
+    const double xi = (lane == i) ? cur[0] : ((lane > i) ? -(acc * cur[0]) : 0.0);
     if (lane < PP) X[i * PP + lane] = xi;
-    lzacc += xi * readlane_f64(zreg, i);
+    lzacc += xi * cur[BWT + 1];
 #pragma unroll
     for (int t = BWT; t >= 2; --t) xw[t] = xw[t - 1];
     xw[1] = xi;
