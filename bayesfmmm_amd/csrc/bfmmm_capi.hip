@@ -681,7 +681,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter, first_iter + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
-  if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS staging (A*LG + 2*P*P > 6144 doubles)"); }
+  if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS (5 A P doubles + A^2 ints must fit 160 KB)"); }
   HIPCHK(hipGetLastError());
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));

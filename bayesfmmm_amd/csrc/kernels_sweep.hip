@@ -505,7 +505,7 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi) {
   return (s - n_phi) * d.MD;
 }
 
-__global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
   TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -522,7 +522,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   double* rhs = lz + AP;                     // PMAX
   double* dlp = rhs + PMAX;                  // PMAX + 2*BWMAX (zero pads)
   double* red = dlp + PMAX + 2 * BWMAX;      // 32
-  const int pf_len = A * LG + P * P;
+  // direct != 0: the column blocks and C_a do not fit the LDS double buffer (A*LG + P*P > 6144 doubles or the total
+  // beyond 160 KB): no staging, every step reads them from L2 (slower per step, but no size limit)
+  const int pf_len = direct ? 0 : A * LG + P * P;
   double* pbuf0 = red + 32;
   double* pbuf1 = pbuf0 + pf_len;
   int* htab = (int*)(pbuf1 + pf_len);        // A x A : H row of block (b, a)
@@ -575,8 +577,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
   };
   if (n_steps > 0) {
     const int a0 = step_dir(d, 0, n_phi);
-    pf_load(a0);
-    pf_store(pbuf0);
+    if (!direct) { pf_load(a0); pf_store(pbuf0); }
     if (tid < P) rhs[tid] = f * (r[a0 * P + tid] + hq[a0 * P + tid]);
   }
   __syncthreads();
@@ -585,10 +586,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     const bool more = st + 1 < n_steps;
     const int an = more ? step_dir(d, st + 1, n_phi) : -1;
     const double* buf = (st & 1) ? pbuf1 : pbuf0;
-    const double* Cg = buf + (size_t)A * LG;
-#ifndef BFMMM_EXP_NOPF
-    if (more) pf_load(an);
-#endif
+    const double* Cg = direct ? c.Cmat + (size_t)a * P * P : buf + (size_t)A * LG;
+    if (more && !direct) pf_load(an);
     // phase A: new = C rhs + L z
     for (int p = tid >> 3; p < P; p += SW_THREADS / 8) {
       const int seg = tid & 7;
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
     // phase B: r_b -= H_ba dl ; hq_a ; next rhs
     for (int e = tid; e < AP; e += SW_THREADS) {
       const int b = e / P, p = e - b * P;
-      const double* Hb = buf + (size_t)b * LG;
+      const double* Hb = direct ? c.H + (size_t)htab[b * A + a] * LG : buf + (size_t)b * LG;
       const double* dl = dlp + BW + p;
       double v = Hb[p] * dl[0];
       for (int dd = 1; dd <= BW; ++dd) v += Hb[dd * P + p] * dl[dd] + Hb[dd * P + p - dd] * dl[-dd];
@@ -616,7 +615,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c) {
       if (b == a) hq[e] += v;                       // H_aa theta_a follows theta_a
       if (b == an) rhs[p] = f * (rn + hq[e]);
     }
-    if (more) pf_store((st & 1) ? pbuf0 : pbuf1);
+    if (more && !direct) pf_store((st & 1) ? pbuf0 : pbuf1);
     lds_barrier();
   }
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
@@ -1074,12 +1073,16 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     }
     return 0;
   }
-  const size_t pf_len = (size_t)d.A * d.LG + (size_t)d.P * d.P;
-  if (pf_len > (size_t)NPF * SW_THREADS) return 1;
-  const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf_len;
-  const size_t lds = doubles * sizeof(double) + (size_t)d.A * d.A * sizeof(int) + 16;
+  size_t pf_len = (size_t)d.A * d.LG + (size_t)d.P * d.P;
+  auto lds_for = [&](size_t pf) {
+    const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf;
+    return doubles * sizeof(double) + (size_t)d.A * d.A * sizeof(int) + 16;
+  };
+  int direct = 0;
+  if (pf_len > (size_t)NPF * SW_THREADS || lds_for(pf_len) > 160 * 1024) { direct = 1; pf_len = 0; }
+  const size_t lds = lds_for(pf_len);
   if (lds > 160 * 1024) return 1;
-  hipLaunchKernelGGL(k_sweep, dim3(1), dim3(SW_THREADS), lds, st, c);
+  hipLaunchKernelGGL(k_sweep, dim3(1), dim3(SW_THREADS), lds, st, c, direct);
   return 0;
 }
 

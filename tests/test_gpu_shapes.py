@@ -1,0 +1,69 @@
+"""Shape sweep: the HIP path against the oracle for problem shapes other than the benchmark's (number of clusters,
+eigenfunctions, spline degree, knots, ragged curves) -- exercises every band-width instantiation, both sweep kernels
+(register-resident and general) and the odd-size tails of the tiled kernels."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_parity import ORC_FIELD, push_state, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def simulate(n, K, M, degree, n_internal, seed, n_pts=60):
+    rng = np.random.default_rng(seed)
+    t_full = np.linspace(0.0, 100.0, n_pts)
+    ik = np.linspace(0.0, 100.0, n_internal + 2)[1:-1]
+    bk = np.array([0.0, 100.0])
+    B_full = O.bspline_basis(t_full, ik, degree, bk)
+    P = B_full.shape[1]
+    nu = np.cumsum(rng.standard_normal((K, P)), axis=1)
+    Phi = np.stack([(M - m) / M * 0.4 * rng.standard_normal((K, P)) for m in range(M)], axis=2)
+    chi = rng.standard_normal((n, M))
+    Z = rng.dirichlet(np.full(K, 1.5), size=n)
+    ts, Bs, ys = [], [], []
+    for i in range(n):
+        keep = np.sort(rng.choice(n_pts, size=rng.integers(n_pts // 2, n_pts + 1), replace=False))
+        B = B_full[keep]
+        c = Z[i] @ (nu + np.einsum("m,kpm->kp", chi[i], Phi))
+        ts.append(t_full[keep]); Bs.append(B); ys.append(B @ c + 0.1 * rng.standard_normal(len(keep)))
+    return dict(t=ts, B=Bs, y=ys, nu=nu, Phi=Phi, chi=chi, Z=Z, K=K, M=M, P=P, n=n, internal_knots=ik, boundary_knots=bk,
+                degree=degree)
+
+
+@pytest.mark.parametrize("K,M,degree,n_internal,n", [
+    (2, 1, 1, 3, 33),      # band width 1, a single eigenfunction
+    (4, 5, 2, 6, 70),      # band width 2, A*P = 216
+    (6, 2, 3, 8, 90),      # the largest K, P = 12
+    (3, 7, 4, 10, 50),     # band width 4, odd M, P = 15
+    (2, 3, 5, 20, 40),     # band width 5, P = 26
+    (5, 9, 3, 26, 64),     # A*P = 1500 > 704: the general sweep kernel, P = 30
+])
+def test_warm_trajectory_matches_oracle_across_shapes(K, M, degree, n_internal, n):
+    import bayesfmmm_amd as bf
+    T = 4
+    sim = simulate(n, K, M, degree, n_internal, seed=100 + K * 10 + M)
+    model = O.Model(sim["y"], sim["B"], K, M)
+    ch = O.Chain(model, T)
+    rng = np.random.default_rng(7)
+    P = sim["P"]
+    ch.nu[:, :, 0] = sim["nu"] + 0.2 * rng.standard_normal((K, P))
+    ch.Phi[..., 0] = sim["Phi"] + 0.1 * rng.standard_normal((K, P, M))
+    ch.chi[:, :, 0] = sim["chi"] + 0.2 * rng.standard_normal((n, M))
+    ch.Z[:, :, 0] = rng.dirichlet(np.full(K, 2.0), size=n)
+    ch.pi[:, 0] = rng.dirichlet(np.full(K, 5.0))
+    ch.alpha3[0] = 3.5
+    ch.delta[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, M))
+    ch.A[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, 2))
+    ch.gamma[..., 0] = rng.gamma(2.0, 0.7, size=(K, P, M))
+    ch.tau[0, :] = rng.gamma(3.0, 0.5, size=K)
+    ch.sigma[0] = 0.02
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=degree, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, sim["y"], sim["t"], sim["internal_knots"], sim["boundary_knots"])
+    push_state(smp, ch)
+    h = O.make_hyper(K)
+    O.run_sweeps(model, h, ch, O.SWEEP_WARM, seed=3)
+    smp.run(bf.sampler.SWEEP_WARM, T, seed=3)
+    for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]:
+        err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
+        assert err < 1e-6, (nm, err)
