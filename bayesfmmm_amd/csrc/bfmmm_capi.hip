@@ -79,6 +79,7 @@ struct bfmmm_handle {
   int last_md = -1;
   int launch_error = 0;
   double* tt_save = nullptr;            // state saved across a tempered-transition block
+  bool state_dirty = true;             // the state was changed from the host: proposals prepared on the device are stale
   int profile = 0;
   double fam_ms[FAM_COUNT] = {0};
   int64_t fam_launches[FAM_COUNT] = {0};
@@ -232,7 +233,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 5 * K + 8) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 5 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -389,6 +390,7 @@ static int dyn_put(bfmmm_handle* h, const Dyn& dyn) {
 
 extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* v, int64_t count) {
   if (!h || !name || !v) return fail("bfmmm_set_state: null argument");
+  h->state_dirty = true;
   HIPCHK(hipSetDevice(h->device));
   const Dims& d = h->c.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M;
@@ -526,6 +528,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
 
 // Initial states of BFMMM_Nu_Z (BFMMM.h:1039-1071) and BFMMM_Theta (:1210-1235)
 extern "C" int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain) {
+  if (h) h->state_dirty = true;
   if (!h) return fail("bfmmm_init_state: null handle");
   const Dims& d = h->c.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M;
@@ -635,6 +638,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
   dyn.pend_dir = -1;
   dyn.ll_pending = 0;
+  if (h->state_dirty) { dyn.zprep_valid = 0; h->state_dirty = false; }
   if (dyn_put(h, dyn)) return 1;
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
   HIPCHK(hipEventRecord(h->ev0, h->st));
@@ -760,6 +764,7 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
   } else {
     HIPCHK(d2d(c.theta, sv_th, n_th)); HIPCHK(d2d(c.chi, sv_chi, n_chi)); HIPCHK(d2d(c.Z, sv_Z, n_Z));
     HIPCHK(d2d(c.delta, sv_dl, n_dl)); HIPCHK(d2d(c.Aa, sv_A, n_A)); HIPCHK(d2d(c.gamma, sv_g, n_g));
+    dyn0.zprep_valid = 0;        // the prepared Z proposals were overwritten by the tempered sweeps
     if (dyn_put(h, dyn0)) return 1;
     if (run_impl(h, U_LOGLIK, iter, 1, seed, chain, 0, 1.0, 0)) return 1;     // rewrites chain slot `iter` from the state
   }

@@ -18,6 +18,7 @@
 #include "model.hpp"
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
+#include "z_proposal.hpp"
 
 #include <algorithm>
 
@@ -152,54 +153,15 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   cv.load(c.rec + (size_t)min(i, n - 1) * d.LREC, P, d.LG, lp);
   const double chi_l = (MD > 1 && lp < M) ? c.chi[min(i, n - 1) + (size_t)n * min(lp, M - 1)] : 0.0;
   const double sigma2 = dyn->sigma2, alpha3 = dyn->alpha3, beta = dyn->beta;
-  // ---- proposal phase (UpdateMixedMembership.h:131-150): Dirichlet(a_Z_PM Z_old) through K gamma draws, their
-  //      lgamma terms and the acceptance uniform depend on Z_old and the keyed RNG only ----
-  double a_old[KMAX], mygam = 0.0, mylg = 0.0, log_uu = 0.0;
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) a_old[k] = c.h.a_Z_PM * Zold[k];
+  // ---- proposal phase (UpdateMixedMembership.h:131-150): everything of the update that does not depend on the data
+  //      (z_proposal.hpp).  Normally it was prepared during the previous iteration's k_factor; otherwise (first
+  //      iteration of a run, tempered sweeps, changed state) it is evaluated here, while the loads are in flight ----
+  ZProposal zp;
   if (valid && do_update) {
-    const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
-    double a_mine = 1.0;       // lane k < K: a_old_k -- ONE gamma / lgamma sequence serves all K components
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) a_mine = a_old[k];
-    {
-      // Attempts 0 .. ZTRY-1 of every component's rejection loop run side by side on otherwise idle lanes
-      // (lane t K + k: attempt t of component k); the variate is the first accepted attempt, exactly as in the
-      // sequential loop, which only continues in the (rare) case that all ZTRY were rejected.
-      constexpr int ZTRY = 4;
-      const int lt = lp / K, lk = lp - lt * K;
-      double a_lane = 1.0;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) if (k < K && lk == k) a_lane = a_old[k];
-      double g_try = 0.0;
-      int ok_try = 0;
-      GammaSetup gs_ = {1.0, 1.0, 1.0};
-      const uint32_t gidx = (uint32_t)(i * K + lk);
-      if (lt < ZTRY && ZTRY * K <= LPC) {
-        gs_ = rgamma_setup(key, UPD_Z_PROP, gidx, (a_lane <= 0) ? 10.0 : a_lane);      // Distributions.h:24-28
-        g_try = gs_.d;
-        ok_try = rgamma_attempt(key, UPD_Z_PROP, gidx, (uint32_t)lt, gs_, g_try) ? 1 : 0;
-      }
-      if (ZTRY * K <= LPC) {
-        double g = gs_.d;
-        int done = 0;
-#pragma unroll
-        for (int tq = 0; tq < ZTRY; ++tq) {
-          const int src = min(tq * K + lk, LPC - 1);
-          const double gt = __shfl(g_try, src, LPC);
-          const int okt = __shfl(ok_try, src, LPC);
-          if (!done) { g = gt; done = okt; }
-        }
-        if (lp < K) {
-          for (uint32_t tq = ZTRY; !done && tq < kMaxAttempts; ++tq) done = rgamma_attempt(key, UPD_Z_PROP, gidx, tq, gs_, g) ? 1 : 0;
-          mygam = g * gs_.boost;
-        }
-      } else if (lp < K) {
-        mygam = rgamma(key, UPD_Z_PROP, gidx, (a_lane <= 0) ? 10.0 : a_lane, 1.0);
-      }
-      if (lp < K) mylg = lgamma_pos(a_mine);
-    }
-    log_uu = log(runif(key, UPD_Z_ACC, (uint32_t)i));
+    const bool pre = dyn->zprep_valid && dyn->zprep_iter == dyn->iter && dyn->zprep_tt == dyn->tt_step &&
+                     dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed && D == 0;
+    if (pre) z_proposal_load(c, i, zp);
+    else z_proposal<LPC>(c, make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
   }
   // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
 #pragma unroll
@@ -299,84 +261,46 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
     double Zfin[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zfin[k] = Zold[k];
+    bool took_new = false;
     if (do_update) {
-      double a_new[KMAX], Znew[KMAX];
-      ZT();
-      double gs = 0.0, lB_old = 0.0, sa_old = 0.0;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        Znew[k] = (k < K) ? __shfl(mygam, k, LPC) : 0.0;
-        if (k < K) { gs += Znew[k]; lB_old += __shfl(mylg, k, LPC); sa_old += a_old[k]; }
-      }
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) { Znew[k] = Znew[k] / gs; a_new[k] = c.h.a_Z_PM * Znew[k]; }
-      // lane k: lgamma(a_new_k); lane K: lgamma(sum a_old); lane K+1: lgamma(sum a_new)
-      double sa_new = 0.0;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) if (k < K) sa_new += a_new[k];
-      double lgarg = 1.0;        // one straight-line lgamma sequence for all K + 2 arguments
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) if (k < K && lp == k) lgarg = a_new[k];
-      if (lp == K) lgarg = sa_old;
-      if (lp == K + 1) lgarg = sa_new;
-      const double lgv = lgamma_pos(lgarg);
-      double lB_new = 0.0;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) if (k < K) lB_new += __shfl(lgv, k, LPC);
-      lB_old -= __shfl(lgv, K, LPC);
-      lB_new -= __shfl(lgv, K + 1, LPC);
-      // log Z_old,k on lane k and log Z_new,k on lane KMAX + k: one log sequence for all 2K values
-      double lgz = 0.0;
-      {
-        double arg = 1.0;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          if (k < K && lp == k) arg = Zold[k];
-          if (k < K && lp == KMAX + k) arg = Znew[k];
-        }
-        lgz = log(arg);
-      }
-      ZT();
       // quadratic form of the residual sum of squares in Z
-      double q_old = cv.yy, q_new = cv.yy, pr_old = 0.0, pr_new = 0.0, dn = 0.0, dold = 0.0;
+      double q_old = cv.yy, q_new = cv.yy;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
           q_old -= 2.0 * Zold[k] * av[k];
-          q_new -= 2.0 * Znew[k] * av[k];
+          q_new -= 2.0 * zp.Znew[k] * av[k];
 #pragma unroll
           for (int k2 = 0; k2 < KMAX; ++k2) {
             if (k2 < K) {
               const double qq = (k2 >= k) ? Q[k][k2] : Q[k2][k];
               q_old += Zold[k] * Zold[k2] * qq;
-              q_new += Znew[k] * Znew[k2] * qq;
+              q_new += zp.Znew[k] * zp.Znew[k2] * qq;
             }
           }
-          const double lo = __shfl(lgz, k, LPC), ln = __shfl(lgz, KMAX + k, LPC);
-          pr_old += (alpha3 * dyn->pi[k] - 1.0) * lo;
-          pr_new += (alpha3 * dyn->pi[k] - 1.0) * ln;
-          dn += (a_old[k] - 1.0) * ln;       // density of proposing new from old
-          dold += (a_new[k] - 1.0) * lo;     // density of proposing old from new
         }
       }
-      const double z_lpdf = pr_old - beta * (q_old / (2.0 * sigma2));
-      const double z_new_lpdf = pr_new - beta * (q_new / (2.0 * sigma2));
-      const double lpdf_propose_new = dn - lB_old;
-      const double lpdf_propose_old = dold - lB_new;
-      double acceptance = z_new_lpdf - z_lpdf + lpdf_propose_old - lpdf_propose_new;
+      const double z_lpdf = zp.pr_old - beta * (q_old / (2.0 * sigma2));
+      const double z_new_lpdf = zp.pr_new - beta * (q_new / (2.0 * sigma2));
+      double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K && Zold[k] <= 0) acceptance = 1;                        // UpdateMixedMembership.h:170-174
-      if (log_uu < acceptance) {
+      if (zp.log_uu < acceptance) {
+        took_new = true;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) Zfin[k] = Znew[k];
+        for (int k = 0; k < KMAX; ++k) Zfin[k] = zp.Znew[k];
       }
       double* zslot = c.c_Z + (size_t)dyn->slot * n * K;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K && lp == k) { c.Z[i + (size_t)n * k] = Zfin[k]; zslot[i + (size_t)n * k] = Zfin[k]; }
     }
-    {
+    if (do_update) {                                      // log Z_ik of the kept state: both were needed by the proposal densities
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && lp == k) logz_mine = took_new ? zp.ln[k] : zp.lo[k];
+    } else {
       double zarg = 1.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)

@@ -22,6 +22,7 @@
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
 #include "factor_core.hpp"
+#include "z_proposal.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -337,8 +338,10 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
   constexpr int W = 2 * BW + 2;     // doubles per row of an H2 block: G(p, p - BW .. p + BW), 0
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper
-    job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
+  if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
+    const int ndraw = (hyper_gstd_count(d) + 1 + 255) / 256;
+    if ((int)blockIdx.x < A + ndraw) job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
+    else job_z_prepare(c, (int)blockIdx.x - A - ndraw);
     return;
   }
   const int a = blockIdx.x;
@@ -1053,7 +1056,8 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
   const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1;   // + sigma^2's gamma variate
-  const int grid = c.d.A + (n_draw + 255) / 256;
+  const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
+  const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep;
   if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
   else launch_factor_pp<64>(c, grid, lds, st);
 }

@@ -48,6 +48,9 @@ struct Dyn {
   uint32_t ll_pending;  // a log-likelihood (slot ll_slot) is still to be reduced from the residual partial sums
   uint32_t ll_slot;
   uint32_t ll_use_part;
+  uint32_t zprep_valid, zprep_iter, zprep_tt, zprep_chain;   // tag of the Z proposals prepared ahead (z_proposal.hpp)
+  uint32_t pad1_;
+  unsigned long long zprep_seed;
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
   double alpha3;
@@ -106,6 +109,7 @@ struct Ctx {
   double* hq;                   // A x P            H_aa theta_a
   double* Lz;                   // A x P            chol_lower(C_a) z_a, z_a the direction's N(0,I) draw
   double* gstd;                 // state-independent variates of job_hyper (scalar_jobs.hpp)
+  double* zprep;                // (3K + 5) x n  Z proposals prepared one iteration ahead (z_proposal.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty
