@@ -469,8 +469,13 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
       sRes[q] = dotL<LPC>(ra, rb);
     }
     if (Mu > 0) {
-      const RngKey key = make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step);
-      if (lp < M) sZn[lp] = rnorm(key, UPD_CHI, (uint32_t)(i * M + lp));
+      // the normals were drawn by spare workgroups of this iteration's k_factor (job_chi_normals); in place otherwise
+      const bool pre = dyn->znorm_valid && dyn->znorm_iter == dyn->iter_hyper && dyn->znorm_tt == dyn->tt_step &&
+                       dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed;
+      if (lp < M) {
+        if (pre) sZn[lp] = c.chi_norm[i + (size_t)n * lp];
+        else sZn[lp] = rnorm(make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step), UPD_CHI, (uint32_t)(i * M + lp));
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)

@@ -140,6 +140,21 @@ __device__ inline void job_z_prepare(const Ctx& c, int wg) {
   }
 }
 
+// Spare workgroups of k_factor: the n x M standard normals of THIS iteration's chi update (UpdateChi.h:57-59), which
+// depend on the keyed RNG alone.  256 per workgroup.
+__device__ inline void job_chi_normals(const Ctx& c, int wg) {
+  const Dims& d = c.d;
+  Dyn* dyn = c.dyn;
+  if (wg == 0 && threadIdx.x == 0) {
+    dyn->znorm_iter = dyn->iter; dyn->znorm_tt = dyn->tt_step; dyn->zprep_chain = c.chain; dyn->zprep_seed = c.seed;
+    dyn->znorm_valid = 1u;
+  }
+  const int e = wg * 256 + threadIdx.x;
+  if (e >= d.n * d.M) return;
+  const int i = e / d.M, m = e - i * d.M;
+  c.chi_norm[i + (size_t)d.n * m] = rnorm(make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), UPD_CHI, (uint32_t)e);
+}
+
 // reads a prepared proposal back (every lane of the curve's group gets all of it)
 __device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp) {
   const int n = c.d.n, K = c.d.K;
