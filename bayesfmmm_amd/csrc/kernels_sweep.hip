@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   constexpr int W = 2 * BW + 2;     // doubles per row of an H2 block: G(p, p - BW .. p + BW), 0
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
-    const int ndraw = (hyper_gstd_count(d) + 1 + 255) / 256;
+    const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int nzp = ((c.mask & U_Z) && d.D == 0) ? (d.n + 15) / 16 : 0;
     if ((int)blockIdx.x < A + ndraw) job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
     else if ((int)blockIdx.x < A + ndraw + nzp) job_z_prepare(c, (int)blockIdx.x - A - ndraw);
@@ -1057,7 +1057,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
   const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
-  const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1;   // + sigma^2's gamma variate
+  const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
   const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm;

@@ -208,9 +208,19 @@ __device__ inline void job_hyper_draws(const Ctx& c, int first) {
   const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
   const int nG = K * P * M;
   const int e = first + threadIdx.x;
-  if (e > hyper_gstd_count(d)) return;
+  if (e > hyper_gstd_count(d) + 8 * K) return;
   double v;
-  if (e == hyper_gstd_count(d)) {
+  if (e > hyper_gstd_count(d)) {
+    // state-independent pieces of the A update's acceptance ratio (UpdateA.h:17-44, 79-112): cell = (j, i), piece q:
+    //   0 / 1: logGamma(a), log(a) at the current value; 2 / 3: the same at the proposal (drawn above with the same key)
+    const int x = e - hyper_gstd_count(d) - 1, cell = x >> 2, q = x & 3;
+    const int j = cell / 2, i = cell - 2 * j;
+    const double sd = (i == 0) ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
+    const double cur = c.Aa[j + (size_t)K * i];
+    const double na = rtruncnorm_lo(key, UPD_A_PROP, (uint32_t)(j * 2 + i), cur, sd, 0.0);
+    const double a = (q < 2) ? cur : na;
+    v = (q & 1) ? log(a) : logGamma_ref(a);
+  } else if (e == hyper_gstd_count(d)) {
     // standard gamma variate of the sigma^2 draw (its shape is state-independent): UpdateSigma.h:49 / :150
     const bool tempered = (dyn->tt_step != 0);
     double shape = tempered ? (dyn->beta * (double)d.n_obs_total) / 2 : (d.mv ? (double)(d.n_obs_total / 2) : (double)d.half_sum);
@@ -263,6 +273,7 @@ __device__ inline void job_hyper(const Ctx& c) {
   const double* gT = gD + K * M;
   const double* aProp = gT + K;
   const double* aUnif = aProp + 2 * K;
+  const double* aTerm = c.gstd + hyper_gstd_count(d) + 1;      // 4 per cell: logGamma / log at cur, at the proposal
   // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 (8 lanes per (k, m), all loads of a lane in flight
   //      together) ; nu staged for nu_k' P nu_k ----
   if (do_delta) {
@@ -297,14 +308,18 @@ __device__ inline void job_hyper(const Ctx& c) {
       const int k = e / P, p = e - k * P;
       double s = 0.0;
       if (d.mv) s = snu[e];
-      else
-        for (int q0 = 0; q0 < P; q0 += 8) {
-          double pv[8];
+      else {
+        // the penalty is banded (half-width BWP, the same assumption the factorisation makes): the other products of
+        // row p are exact zeros, so skipping them leaves the sum of UpdateTau.h:26-28 unchanged
+        double pv[2 * BWMAX + 1];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) pv[u] = c.Pmat[p + (size_t)P * min(q0 + u, P - 1)];
+        for (int u = 0; u < 2 * BWMAX + 1; ++u) pv[u] = c.Pmat[p + (size_t)P * min(max(p - d.BWP + u, 0), P - 1)];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) if (q0 + u < P) s += pv[u] * snu[k * P + q0 + u];
+        for (int u = 0; u < 2 * BWMAX + 1; ++u) {
+          const int q = p - d.BWP + u;
+          if (u <= 2 * d.BWP && q >= 0 && q < P) s += pv[u] * snu[k * P + q];
         }
+      }
       qrow[e] = snu[e] * s;
     }
   // ---- phase 2: delta recursion (K lanes).  tilde-tau products are carried along instead of rebuilt: the
@@ -356,7 +371,7 @@ __device__ inline void job_hyper(const Ctx& c) {
     double v;
     if (job < 2) {
       const double a = (job == 0) ? cur : na;
-      const double lga = logGamma_ref(a), la = log(a);                // one sequence for both kinds of cell
+      const double lga = aTerm[cell * 4 + 2 * job], la = aTerm[cell * 4 + 2 * job + 1];     // drawn ahead (job_hyper_draws)
       if (first) v = -lga + (a - 1) * lgd[j * 16] + (c.h.alpha1l - 1) * la - (a * c.h.beta1l);          // UpdateA.h:17-24
       else { const double x = M - 1; v = -x * lga + (c.h.alpha2l - 1) * la - (a * c.h.beta2l) + (a - 1) * slog[j]; }   // UpdateA.h:33-44
     } else {

@@ -88,3 +88,4 @@ except Exception as ex:
 print("factor WG1 (us from its start): loads issued+zv %.2f | barrier %.2f | band products done %.2f | r reduce %.2f | Prec built %.2f | factor_core %.2f" % tuple((st[49:55]-st[48])))
 fc = np.array(smp.get_state("fct")) * 0.01
 print("factor_core: cholesky %.2f us | back-substitution %.2f | barrier %.2f | MFMA C + stores %.2f (then L copy)" % (fc[0]-st[53], fc[1]-fc[0], fc[2]-fc[1], fc[3]-fc[2]))
+print("curve_chi: hyper job ends at +%.2f us of the kernel (kernel busy %.2f)" % (st[58]-st[10], st[11]-st[10]))
