@@ -153,7 +153,7 @@ def main():
     # extra: aggregate throughput of C independent chains sharing GPU 0 (multi-try chains are independent;
     # the single-chain sweep is latency-bound and leaves most CUs idle)
     multi = None
-    if rank == 0 and args.concurrent_chains > 1:
+    if rank == 0 and args.concurrent_chains > 1 and world == 1:
         import threading
         C_ = args.concurrent_chains
         cfg2 = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"],
@@ -225,7 +225,7 @@ def main():
             "roofline": roofline,
             "multi_chain": multi,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     if dist is not None:
