@@ -233,7 +233,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -638,7 +638,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
   dyn.pend_dir = -1;
   dyn.ll_pending = 0;
-  if (h->state_dirty) { dyn.zprep_valid = 0; h->state_dirty = false; }
+  if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; h->state_dirty = false; }
   dyn.znorm_valid = 0;
   if (dyn_put(h, dyn)) return 1;
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
@@ -766,6 +766,7 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
     HIPCHK(d2d(c.theta, sv_th, n_th)); HIPCHK(d2d(c.chi, sv_chi, n_chi)); HIPCHK(d2d(c.Z, sv_Z, n_Z));
     HIPCHK(d2d(c.delta, sv_dl, n_dl)); HIPCHK(d2d(c.Aa, sv_A, n_A)); HIPCHK(d2d(c.gamma, sv_g, n_g));
     dyn0.zprep_valid = 0;        // the prepared Z proposals were overwritten by the tempered sweeps
+    dyn0.piprep_valid = 0;
     if (dyn_put(h, dyn0)) return 1;
     if (run_impl(h, U_LOGLIK, iter, 1, seed, chain, 0, 1.0, 0)) return 1;     // rewrites chain slot `iter` from the state
   }

@@ -173,14 +173,32 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   }
   __syncthreads();
   TSTAMP0(c, 42);
-  if (!single) {                             // pair rows, one thread per curve
-    for (int il = tid; il < KS; il += 256) {
-      const double* w = sW + il * RS;
-      double* p = sP + il * RP;
-      int e = 0;
-      for (int a = 0; a < K; ++a) { const double za = w[a]; for (int b = a; b < K; ++b) p[e++] = za * w[b]; }
-      for (int a = 0; a < MD; ++a) { const double ca = w[K + a]; for (int b = a; b < MD; ++b) p[e++] = ca * w[K + b]; }
-      p[e] = 0.0;
+  if (!single) {
+    // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 8, .. of curves tx, tx + 32, ..; the
+    // slot -> (a, b) table is decoded once (packed upper triangles of Z x Z and chit x chit)
+    int* ptab = (int*)(sP + (size_t)KS * RP);
+    const int NP = d.NZZ + d.NCC;
+    if (tid < NP) {
+      int e = tid, off = 0, dim = K;
+      if (e >= d.NZZ) { e -= d.NZZ; off = K; dim = MD; }
+      int a = 0;
+      while (e >= dim - a) { e -= dim - a; ++a; }
+      ptab[tid] = (off + a) | ((off + a + e) << 16);
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    for (int il0 = 0; il0 < KS; il0 += 256) {
+      for (int e = ty; e < NP; e += 8) {
+        const int pk = ptab[e], ia = pk & 0xffff, ib = pk >> 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int il = il0 + tx + 32 * j;
+          if (il < KS) sP[il * RP + e] = sW[il * RS + ia] * sW[il * RS + ib];
+        }
+      }
+      if (ty == 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[il * RP + NP] = 0.0; }
     }
     __syncthreads();
   }
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     const int nzp = ((c.mask & U_Z) && d.D == 0) ? (d.n + 15) / 16 : 0;
     if ((int)blockIdx.x < A + ndraw) job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
     else if ((int)blockIdx.x < A + ndraw + nzp) job_z_prepare(c, (int)blockIdx.x - A - ndraw);
+    else if ((int)blockIdx.x == gridDim.x - 1 && (c.mask & (U_PI | U_ALPHA3))) job_pi_prepare(c);
     else job_chi_normals(c, (int)blockIdx.x - A - ndraw - nzp);
     return;
   }
@@ -1034,7 +1053,7 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
-  const size_t lds = std::max((size_t)KS * std::max(row_g, row_s), (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);
+  const size_t lds = std::max((size_t)KS * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
   hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(256), lds, st, c, KS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;
@@ -1060,7 +1079,8 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
-  const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm;
+  const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // the last workgroup: next iteration's pi / alpha_3 tables
+  const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;
   if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
   else launch_factor_pp<64>(c, grid, lds, st);
 }

@@ -50,6 +50,7 @@ struct Dyn {
   uint32_t ll_use_part;
   uint32_t zprep_valid, zprep_iter, zprep_tt, zprep_chain;   // tag of the Z proposals prepared ahead (z_proposal.hpp)
   uint32_t znorm_valid, znorm_iter, znorm_tt;    // tag of the chi normals drawn ahead by spare k_factor workgroups
+  uint32_t piprep_valid, piprep_iter, pad2_;     // tag of the pi / alpha_3 tables prepared ahead
   unsigned long long zprep_seed;
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)
@@ -111,6 +112,7 @@ struct Ctx {
   double* gstd;                 // state-independent variates of job_hyper (scalar_jobs.hpp)
   double* zprep;                // (3K + 5) x n  Z proposals prepared one iteration ahead (z_proposal.hpp)
   double* chi_norm;             // n x M  standard normals of this iteration's chi update (z_proposal.hpp)
+  double* piprep;               // tables of the next iteration's pi / alpha_3 job (scalar_jobs.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty

@@ -63,18 +63,80 @@ __device__ inline void deferred_loglik(const Ctx& c, double* red) {
 }
 
 constexpr int PI_ALPHA_LDS_DOUBLES = KMAX * 256 + 10 * KMAX + 16;
+constexpr int PI_TAB_DOUBLES = 9 * KMAX + 16;      // g | lg | ph_s | lu | lp | dt  (contiguous, see pi_alpha_layout)
+
+struct PiAlphaTabs { double *g, *lg, *ph_s, *lu, *lp, *dt; };
+__device__ inline PiAlphaTabs pi_alpha_layout(double* base) {
+  PiAlphaTabs t;
+  t.g = base; t.lg = t.g + KMAX; t.ph_s = t.lg + 6 * KMAX + 8; t.lu = t.ph_s + 2; t.lp = t.lu + 2; t.dt = t.lp + 2 * KMAX;
+  return t;
+}
+
+// Data-independent part of the pi / alpha_3 updates (updatePi_PM UpdatePi.h:84-116, updateAlpha3 UpdateAlpha3.h:36-63):
+// the proposals, the acceptance uniforms and every lgamma / log / truncated-normal term of the two ratios.  Only the
+// sums S_k = sum_i log Z_ik depend on the data.  256 threads; tables in LDS (t); ends with a barrier.
+//   lgamma table rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new, 4 ph*pi_old, 5 ph*pi_new; then the
+//   6 lgamma(sum) terms at 6K..6K+5.
+__device__ inline void pi_alpha_tables(const Ctx& c, const RngKey& key, const PiAlphaTabs& t) {
+  const int K = c.d.K, tid = threadIdx.x;
+  const Dyn* dyn = c.dyn;
+  const double alpha3 = dyn->alpha3;
+  const double sd = c.h.var_alpha3;
+  // one wave each so that the different code paths run side by side: wave 0 lanes k < K: the pi gammas; wave 1: the
+  // alpha_3 truncated normal; wave 2: log(u) of the two MH tests
+  if (tid < K) {
+    const double a_old = c.h.a_pi_PM * dyn->pi[tid];
+    t.g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
+  } else if (tid == 64) {
+    t.ph_s[0] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
+  } else if (tid == 128 || tid == 129) {
+    t.lu[tid - 128] = log(runif(key, (tid == 128) ? UPD_PI_ACC : UPD_A3_ACC, 0));
+  }
+  __syncthreads();
+  double pi_old[KMAX], pi_new[KMAX];
+  double gsum = 0.0;
+  for (int k = 0; k < K; ++k) gsum += t.g[k];
+  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = t.g[k] / gsum; }
+  const double a3_ph = t.ph_s[0];
+  if (tid < 6 * K + 6) {
+    const bool is_sum = tid >= 6 * K;
+    const int row = is_sum ? tid - 6 * K : tid / K, k = is_sum ? 0 : tid - row * K;
+    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
+    double arg = 0.0;
+    for (int k2 = 0; k2 < K; ++k2) {
+      const double term = sc * ((row & 1) ? pi_new[k2] : pi_old[k2]);
+      if (is_sum) arg += term;
+      else if (k2 == k) arg = term;
+    }
+    t.lg[tid] = lgamma_pos(arg);
+  } else if (tid >= 64 && tid < 64 + 2 * K) {
+    const int e = tid - 64;
+    t.lp[e] = log((e < K) ? pi_old[e] : pi_new[e - K]);
+  } else if (tid == 128 || tid == 129) {
+    // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
+    t.dt[tid - 128] = (tid == 128) ? dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0) : dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
+  }
+  __syncthreads();
+}
+
+// Spare workgroup of k_factor (iteration t): the tables of iteration t + 1's pi / alpha_3 job (pi, alpha_3 are final for
+// iteration t once k_pair_gram has run).  Tagged like the Z proposals (Dyn::piprep_*).
+__device__ inline void job_pi_prepare(const Ctx& c) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  Dyn* dyn = c.dyn;
+  const PiAlphaTabs t = pi_alpha_layout(smem);
+  pi_alpha_tables(c, make_key(c.seed, c.chain, dyn->iter + 1u, 0u), t);
+  for (int e = threadIdx.x; e < PI_TAB_DOUBLES; e += 256) c.piprep[e] = smem[e];
+  if (threadIdx.x == 0) { dyn->piprep_iter = dyn->iter + 1u; dyn->zprep_chain = c.chain; dyn->zprep_seed = c.seed; dyn->piprep_valid = 1u; }
+}
 
 __device__ inline void job_pi_alpha(const Ctx& c) {
   // scratch carved from k_pair_gram's dynamic LDS (the launcher guarantees PI_ALPHA_LDS_DOUBLES)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*red)[256] = (double (*)[256])smem;       // KMAX x 256
   double* S = smem + KMAX * 256;                     // KMAX
-  double* g = S + KMAX;                              // KMAX
-  double* lg = g + KMAX;                             // 6 * KMAX + 8
-  double* ph_s = lg + 6 * KMAX + 8;                  // 2
-  double* lu = ph_s + 2;                             // 2
-  double* lp = lu + 2;                               // 2 * KMAX
-  double* dt = lp + 2 * KMAX;                        // 2
+  const PiAlphaTabs t = pi_alpha_layout(S + KMAX);
+  double *g = t.g, *lg = t.lg, *ph_s = t.ph_s, *lu = t.lu, *lp = t.lp, *dt = t.dt;
   const Dims& d = c.d;
   const int K = d.K, n = d.n, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
@@ -87,7 +149,14 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
     }
     return;
   }
-  const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  // the data-independent tables: prepared during the previous iteration's k_factor, or evaluated here
+  const bool pre = dyn->piprep_valid && dyn->piprep_iter == dyn->iter && dyn->tt_step == 0 &&
+                   dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed;
+  if (pre) {
+    for (int e = tid; e < PI_TAB_DOUBLES; e += 256) t.g[e] = c.piprep[e];
+  } else {
+    pi_alpha_tables(c, make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), t);
+  }
   // S_k = sum_i log Z_ik from the block partials of k_curve_z: one fixed-order tree for all k at once
   {
     double acc[KMAX];
@@ -110,46 +179,13 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
     }
     if (tid < K) S[tid] = red[tid][0];
   }
-  // proposals and acceptance uniforms, one wave each so that their different code paths run side by side:
-  // wave 0 lanes k < K: the pi gammas; wave 1: the alpha_3 truncated normal; wave 2: log(u) of the two MH tests
-  double alpha3 = dyn->alpha3;
-  const double sd = c.h.var_alpha3;
-  if (tid < K) {
-    const double a_old = c.h.a_pi_PM * dyn->pi[tid];
-    g[tid] = rgamma(key, UPD_PI_PROP, (uint32_t)tid, (a_old <= 0) ? 10.0 : a_old, 1.0);
-  } else if (tid == 64) {
-    ph_s[0] = rtruncnorm_lo(key, UPD_A3_PROP, 0, alpha3, sd, 0.0);
-  } else if (tid == 128 || tid == 129) {
-    lu[tid - 128] = log(runif(key, (tid == 128) ? UPD_PI_ACC : UPD_A3_ACC, 0));
-  }
   __syncthreads();
+  double alpha3 = dyn->alpha3;
   double pi_old[KMAX], pi_new[KMAX];
   double gsum = 0.0;
   for (int k = 0; k < K; ++k) gsum += g[k];
   for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
   const double a3_ph = ph_s[0];
-  // lgamma table, one lane each (wave 0).  rows (x K): 0 a_pi*pi_old, 1 a_pi*pi_new, 2 a3*pi_old, 3 a3*pi_new,
-  // 4 ph*pi_old, 5 ph*pi_new; then the 6 lgamma(sum) terms at 6K..6K+5.  Wave 1: log pi_old / log pi_new;
-  // wave 2: the two truncated-normal densities.
-  if (tid < 6 * K + 6) {
-    const bool is_sum = tid >= 6 * K;
-    const int row = is_sum ? tid - 6 * K : tid / K, k = is_sum ? 0 : tid - row * K;
-    const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
-    double arg = 0.0;
-    for (int k2 = 0; k2 < K; ++k2) {
-      const double term = sc * ((row & 1) ? pi_new[k2] : pi_old[k2]);
-      if (is_sum) arg += term;
-      else if (k2 == k) arg = term;
-    }
-    lg[tid] = lgamma_pos(arg);
-  } else if (tid >= 64 && tid < 64 + 2 * K) {
-    const int e = tid - 64;
-    lp[e] = log((e < K) ? pi_old[e] : pi_new[e - K]);
-  } else if (tid == 128 || tid == 129) {
-    // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
-    dt[tid - 128] = (tid == 128) ? dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0) : dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
-  }
-  __syncthreads();
   if (tid == 0) {
     auto lB = [&](int row) {   // calc_lB of (scale_row * pi_row), Distributions.h:51-60
       double s = 0.0;
