@@ -137,12 +137,12 @@ static void pg_geometry(const Dims& d, int& NTG, int& NKS, int& KS) {
   // for the G workgroups, the pair-weight row (k_pair_gram); a workgroup never stages more than 96 KB.
   const int row_g = (d.K + d.MD + 1) + 16 + (d.NZZ + d.NCC + 1);
   const int row_s = (d.K + d.MD + 1) + d.CTS * 16;
-  const int ks_cap = std::max(4, (int)((96 * 1024) / (sizeof(double) * (size_t)std::max(row_g, row_s))) / 4 * 4);
+  const int ks_cap = std::max(16, (int)((96 * 1024) / (sizeof(double) * (size_t)std::max(row_g, row_s)) - 2) / 16 * 16);
   // one workgroup per CU: (CTG + 2) column groups x NKS k-slices <= 256 whenever the LDS cap allows, so that
   // every workgroup is resident at once (a 257th would wait a whole workgroup lifetime for a free CU)
   NKS = std::max(1, std::min(256 / (d.CTG + 2), d.n / 16));
   KS = (d.n + NKS - 1) / NKS;
-  KS = (KS + 3) / 4 * 4;
+  KS = (KS + 15) / 16 * 16;                  // MFMA k-slots are taken in trips of 4 steps per slot (two 16-byte LDS reads)
   KS = std::min(KS, ks_cap);
   NKS = (d.n + KS - 1) / KS;
   NTG = 1;

@@ -59,7 +59,9 @@ __device__ unsigned long long g_wgtrace[3 * 1024];
 void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtrace), sizeof(unsigned long long) * 3 * 1024); }
 #endif
 
-__global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
+constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
+                                  // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
+__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c, int KS, int do_pg) {
   TIMELINE(c, 1);
 #ifdef BFMMM_TIMELINE
   const int wgid = blockIdx.x + gridDim.x * blockIdx.y;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
   if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
-    if (ks == 0) { job_pi_alpha(c); TSTAMP(c, 46); }
+    if (ks == 0 && threadIdx.x < 256) { job_pi_alpha(c); TSTAMP(c, 46); }      // the scalar jobs are written for 256 threads
     return;
   }
   if (!do_pg) return;
@@ -87,15 +89,19 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int colend = single ? d.LG + d.P : d.LG;
   const int i0 = ks * KS;
   const int RS = K + MD + 1, ONE = K;
-  const int RP = d.NZZ + d.NCC + 1;
-  double* sW = smem;                         // KS x RS
-  double* sB = sW + (size_t)KS * RS;         // KS x ncol
-  double* sP = sB + (size_t)KS * ncol;       // KS x RP   (G workgroups only)
+  const int NP = d.NZZ + d.NCC, RP = NP + 1;
+  // LDS: every quantity is stored CURVE-CONTIGUOUS (row f of a table = the KS curves of the slice, stride KSP), and
+  // MFMA k-slot kq of step s is curve kq * KS/4 + s: a lane's operands of two consecutive steps are then adjacent,
+  // so one 16-byte LDS read feeds two MFMAs.
+  const int KSP = KS + 2;                    // even (16-byte alignment of the rows) and 2 mod 8 (row starts spread over banks)
+  double* sW = smem;                         // RS x KSP  raw weights: Z_1..Z_K | 1, chi_1..chi_M | 0
+  double* sB = sW + (size_t)RS * KSP;        // ncol x KSP  record columns
+  double* sP = sB + (size_t)ncol * KSP;      // RP x KSP  pair weights (G workgroups only)
   const int tid = threadIdx.x;
   // staging: a thread issues all its global loads (one curve's Z / chi entries, UB record entries)
   // before its first LDS store, so the workgroup pays about one memory round trip
   {
-    constexpr int UW = 12, UB = 12;
+    constexpr int UW = 12, UB = 6;
     const int ncw = K + MD - 1;              // source columns: Z_1..Z_K, chi_1..chi_M
     const int nB = KS * ncol;
     auto loadW = [&](int il0, int cb, double (&v)[UW]) {
@@ -113,44 +119,44 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
 #pragma unroll
       for (int u = 0; u < UW; ++u) {
         const int col = cb + u;
-        if (col < ncw) sW[il * RS + ((col < K) ? col : col + 1)] = live ? v[u] : 0.0;
+        if (col < ncw) sW[((col < K) ? col : col + 1) * KSP + il] = live ? v[u] : 0.0;
       }
-      if (cb == 0) { sW[il * RS + ONE] = 1.0; sW[il * RS + K + MD] = 0.0; }
+      if (cb == 0) { sW[ONE * KSP + il] = 1.0; sW[(K + MD) * KSP + il] = 0.0; }
     };
-    auto loadB = [&](int base, double (&v)[UB]) {
+    auto loadB = [&](int base, double (&v)[UB]) {        // s-part workgroups (ncol = CTS * 16)
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int q = min(base + tid + 256 * u, nB - 1);
-        const int il = single ? q / ncol : q >> 4, cc = q - il * ncol;
+        const int q = min(base + tid + PG_THREADS * u, nB - 1);
+        const int il = q / ncol, cc = q - il * ncol;
         const int i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
         // covariate-adjusted models contract against s~_i = s_i - G_i o_i (k_curve_z) instead of s_i
-        v[u] = (single && d.D > 0) ? c.stil[(size_t)i * d.P + min(cc, d.P - 1)] : c.rec[(size_t)i * d.LREC + col];
+        v[u] = (d.D > 0) ? c.stil[(size_t)i * d.P + min(cc, d.P - 1)] : c.rec[(size_t)i * d.LREC + col];
       }
     };
     auto storeB = [&](int base, const double (&v)[UB]) {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int q = base + tid + 256 * u;
+        const int q = base + tid + PG_THREADS * u;
         if (q < nB) {
-          const int il = single ? q / ncol : q >> 4, cc = q - il * ncol;
-          sB[q] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
+          const int il = q / ncol, cc = q - il * ncol;
+          sB[cc * KSP + il] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
         }
       }
     };
-    // G workgroups (16 record columns): element (il, cc) = (tid / 16 + 16 u, tid % 16), so a load costs one
+    // G workgroups (16 record columns): element (il, cc) = (tid / 16 + 32 u, tid % 16), so a load costs one
     // multiply-add and a store a constant LDS offset
     const int ccg = tid & 15, ilg = tid >> 4;
     const double* srcg = c.rec + min(col0 + ccg, d.LREC - 1);
     const bool colok = col0 + ccg < colend;
     auto loadG = [&](int ub0, double (&v)[UB]) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) v[u] = srcg[(size_t)min(i0 + ilg + 16 * (ub0 + u), n - 1) * d.LREC];
+      for (int u = 0; u < UB; ++u) v[u] = srcg[(size_t)min(i0 + ilg + (PG_THREADS / 16) * (ub0 + u), n - 1) * d.LREC];
     };
     auto storeG = [&](int ub0, const double (&v)[UB]) {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int il = ilg + 16 * (ub0 + u);
-        if (il < KS) sB[il * 16 + ccg] = (i0 + il < n && colok) ? v[u] : 0.0;
+        const int il = ilg + (PG_THREADS / 16) * (ub0 + u);
+        if (il < KS) sB[ccg * KSP + il] = (i0 + il < n && colok) ? v[u] : 0.0;
       }
     };
     TSTAMP0(c, 40);
@@ -161,23 +167,22 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     storeW(0, 0, vw);
     TSTAMP0(c, 48);
     if (single) storeB(0, vb); else storeG(0, vb);
-    for (int il0 = 0; il0 < KS; il0 += 256)
+    for (int il0 = 0; il0 < KS; il0 += PG_THREADS)
       for (int cb = 0; cb < ncw; cb += UW) {
         if (il0 == 0 && cb == 0) continue;
         loadW(il0, cb, vw);
         storeW(il0, cb, vw);
       }
-    if (single) { for (int base = 256 * UB; base < nB; base += 256 * UB) { loadB(base, vb); storeB(base, vb); } }
-    else { for (int ub0 = UB; 16 * ub0 < KS; ub0 += UB) { loadG(ub0, vb); storeG(ub0, vb); } }
+    if (single) { for (int base = PG_THREADS * UB; base < nB; base += PG_THREADS * UB) { loadB(base, vb); storeB(base, vb); } }
+    else { for (int ub0 = UB; (PG_THREADS / 16) * ub0 < KS; ub0 += UB) { loadG(ub0, vb); storeG(ub0, vb); } }
     TSTAMP0(c, 41);
   }
   __syncthreads();
   TSTAMP0(c, 42);
   if (!single) {
-    // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 8, .. of curves tx, tx + 32, ..; the
+    // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 16, .. of curves tx, tx + 32, ..; the
     // slot -> (a, b) table is decoded once (packed upper triangles of Z x Z and chit x chit)
-    int* ptab = (int*)(sP + (size_t)KS * RP);
-    const int NP = d.NZZ + d.NCC;
+    int* ptab = (int*)(sP + (size_t)RP * KSP);
     if (tid < NP) {
       int e = tid, off = 0, dim = K;
       if (e >= d.NZZ) { e -= d.NZZ; off = K; dim = MD; }
@@ -188,17 +193,17 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     __syncthreads();
     const int tx = tid & 31, ty = tid >> 5;
     for (int il0 = 0; il0 < KS; il0 += 256) {
-      for (int e = ty; e < NP; e += 8) {
+      for (int e = ty; e < NP; e += PG_THREADS / 32) {
         const int pk = ptab[e], ia = pk & 0xffff, ib = pk >> 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int il = il0 + tx + 32 * j;
-          if (il < KS) sP[il * RP + e] = sW[il * RS + ia] * sW[il * RS + ib];
+          if (il < KS) sP[e * KSP + il] = sW[ia * KSP + il] * sW[ib * KSP + il];
         }
       }
       if (ty == 0)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[il * RP + NP] = 0.0; }
+        for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[NP * KSP + il] = 0.0; }
     }
     __syncthreads();
   }
@@ -207,16 +212,17 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
   const int lr = lane & 15, kq = lane >> 4;
   const int ntile = single ? d.AT * d.CTS : d.RT;
   const double* wsrc = single ? sW : sP;
-  const int wstride = single ? RS : RP, ZERO = wstride - 1;
-  // each wave walks its tiles TPW at a time with independent accumulators: the LDS latency of one
-  // tile's operands hides behind the other tiles' MFMAs
-  constexpr int TPW = 3;
-  for (int t0 = wave; t0 < ntile; t0 += 4 * TPW) {
+  const int ZERO = single ? RS - 1 : RP - 1;
+  const int KQ = KS / 4;                     // steps; k-slot kq of step s is curve kq * KQ + s  (KS is a multiple of 16)
+  // each wave walks its tiles TPW at a time with independent accumulators
+  constexpr int TPW = 2;
+  constexpr int NW = PG_THREADS / 64;
+  for (int t0 = wave; t0 < ntile; t0 += NW * TPW) {
     int tix[TPW], bcol[TPW], o1[TPW], o2[TPW];
     bool tv[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-      const int tt = t0 + 4 * q;
+      const int tt = t0 + NW * q;
       tv[q] = tt < ntile;
       o1[q] = o2[q] = ZERO; bcol[q] = lr; tix[q] = 0;
       if (tv[q]) {
@@ -236,27 +242,47 @@ __global__ __launch_bounds__(256) void k_pair_gram(Ctx c, int KS, int do_pg) {
     double4_t acc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // U k-steps per trip: the 9 U LDS reads of a trip are issued together, so one LDS latency is paid per U steps
-    // and the later steps' operands arrive under the MFMAs of the earlier ones
-    auto ksteps = [&](int kk, auto ucount) {
-      constexpr int U = decltype(ucount)::value;
-      double wa[U][TPW], wb[U][TPW], bb[U][TPW];
+    const v2d* pa[TPW]; const v2d* pb[TPW]; const v2d* pc[TPW];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double* wrow = wsrc + (kk + 4 * u + kq) * wstride;
-        const double* brow = sB + (kk + 4 * u + kq) * ncol;
+    for (int q = 0; q < TPW; ++q) {
+      pa[q] = (const v2d*)(wsrc + o1[q] * KSP + kq * KQ);
+      pb[q] = (const v2d*)(wsrc + o2[q] * KSP + kq * KQ);
+      pc[q] = (const v2d*)(sB + bcol[q] * KSP + kq * KQ);
+    }
+    // The LDS pipe moves 1.5 KB per MFMA and wave -- three quarters of the time the matrix pipe needs for it -- so the
+    // two must overlap: a trip is two pairs of k-steps (12 TPW MFMAs); the operands of trip t + 1 are read into the
+    // other register set before the MFMAs of trip t are issued (the scheduling barriers keep the compiler from
+    // moving the reads back next to their uses).
+    struct OpSet { v2d wa[2][TPW], wb[2][TPW], bb[2][TPW]; };
+    auto load_trip = [&](OpSet& o, int s2) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) { wa[u][q] = wrow[o1[q]]; wb[u][q] = wrow[o2[q]]; bb[u][q] = brow[bcol[q]]; }
-      }
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q)
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u][q] * wb[u][q], bb[u][q], acc[q], 0, 0, 0);
+        for (int q = 0; q < TPW; ++q) { o.wa[u][q] = pa[q][s2 + u]; o.wb[u][q] = pb[q][s2 + u]; o.bb[u][q] = pc[q][s2 + u]; }
     };
-    int kk = 0;
-    for (; kk + 16 <= KS; kk += 16) ksteps(kk, std::integral_constant<int, 4>{});
-    for (; kk < KS; kk += 4) ksteps(kk, std::integral_constant<int, 1>{});
+    auto mfma_trip = [&](const OpSet& o, int npair) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (u < npair)
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) {
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][q].x * o.wb[u][q].x, o.bb[u][q].x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][q].y * o.wb[u][q].y, o.bb[u][q].y, acc[q], 0, 0, 0);
+          }
+    };
+    const int ntrip = KQ / 4;                // KS is a multiple of 16: trip t covers the step pairs 2t, 2t + 1
+    OpSet s0, s1;
+    load_trip(s0, 0);
+    for (int t = 0; t < ntrip; t += 2) {
+      if (t + 1 < ntrip) load_trip(s1, 2 * (t + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_trip(s0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < ntrip) load_trip(s0, 2 * (t + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ntrip) mfma_trip(s1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int q = 0; q < TPW; ++q)
       if (tv[q]) {
@@ -1053,8 +1079,8 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
-  const size_t lds = std::max((size_t)KS * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
-  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(256), lds, st, c, KS, do_pg);
+  const size_t lds = std::max((size_t)(KS + 2) * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
+  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(PG_THREADS), lds, st, c, KS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, c, NKS);
