@@ -93,25 +93,34 @@ __device__ inline void pi_alpha_tables(const Ctx& c, const RngKey& key, const Pi
     t.lu[tid - 128] = log(runif(key, (tid == 128) ? UPD_PI_ACC : UPD_A3_ACC, 0));
   }
   __syncthreads();
+  // (fully unrolled over KMAX with k < K predicates: runtime-indexed local arrays would live in scratch memory, and a
+  //  kernel that needs scratch pays for its set-up at every wave launch)
   double pi_old[KMAX], pi_new[KMAX];
   double gsum = 0.0;
-  for (int k = 0; k < K; ++k) gsum += t.g[k];
-  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = t.g[k] / gsum; }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) if (k < K) gsum += t.g[k];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { pi_old[k] = (k < K) ? dyn->pi[k] : 0.0; pi_new[k] = (k < K) ? t.g[k] / gsum : 0.0; }
   const double a3_ph = t.ph_s[0];
   if (tid < 6 * K + 6) {
     const bool is_sum = tid >= 6 * K;
     const int row = is_sum ? tid - 6 * K : tid / K, k = is_sum ? 0 : tid - row * K;
     const double sc = (row < 2) ? c.h.a_pi_PM : ((row < 4) ? alpha3 : a3_ph);
     double arg = 0.0;
-    for (int k2 = 0; k2 < K; ++k2) {
-      const double term = sc * ((row & 1) ? pi_new[k2] : pi_old[k2]);
-      if (is_sum) arg += term;
-      else if (k2 == k) arg = term;
-    }
+#pragma unroll
+    for (int k2 = 0; k2 < KMAX; ++k2)
+      if (k2 < K) {
+        const double term = sc * ((row & 1) ? pi_new[k2] : pi_old[k2]);
+        if (is_sum) arg += term;
+        else if (k2 == k) arg = term;
+      }
     t.lg[tid] = lgamma_pos(arg);
   } else if (tid >= 64 && tid < 64 + 2 * K) {
     const int e = tid - 64;
-    t.lp[e] = log((e < K) ? pi_old[e] : pi_new[e - K]);
+    double arg = 1.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { if (k < K && e == k) arg = pi_old[k]; if (k < K && e == K + k) arg = pi_new[k]; }
+    t.lp[e] = log(arg);
   } else if (tid == 128 || tid == 129) {
     // d_truncnorm(x, x, sd, 0, Inf, log) evaluated at the *other* state (UpdateAlpha3.h:23-24)
     t.dt[tid - 128] = (tid == 128) ? dtruncnorm_lo_log(a3_ph, a3_ph, sd, 0.0) : dtruncnorm_lo_log(alpha3, alpha3, sd, 0.0);
@@ -183,8 +192,10 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
   double alpha3 = dyn->alpha3;
   double pi_old[KMAX], pi_new[KMAX];
   double gsum = 0.0;
-  for (int k = 0; k < K; ++k) gsum += g[k];
-  for (int k = 0; k < K; ++k) { pi_old[k] = dyn->pi[k]; pi_new[k] = g[k] / gsum; }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) if (k < K) gsum += g[k];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { pi_old[k] = (k < K) ? dyn->pi[k] : 0.0; pi_new[k] = (k < K) ? g[k] / gsum : 0.0; }
   const double a3_ph = ph_s[0];
   if (tid == 0) {
     auto lB = [&](int row) {   // calc_lB of (scale_row * pi_row), Distributions.h:51-60
@@ -193,31 +204,41 @@ __device__ inline void job_pi_alpha(const Ctx& c) {
       return s - lg[6 * K + row];
     };
     double pi[KMAX];
-    for (int k = 0; k < K; ++k) pi[k] = pi_old[k];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pi[k] = pi_old[k];
     int pi_is_new = 0;
     if (mask & U_PI) {
       double lpdf_new = 0.0, lpdf_old = 0.0, pn = 0.0, po = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const double lo = lp[k], ln = lp[K + k];
-        lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
-        lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
-        pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
-        po += (c.h.a_pi_PM * pi_new[k] - 1) * lo;
-      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          const double lo = lp[k], ln = lp[K + k];
+          lpdf_new += (c.h.c[k] - 1) * ln + ((alpha3 * pi_new[k]) - 1) * S[k];
+          lpdf_old += (c.h.c[k] - 1) * lo + ((alpha3 * pi_old[k]) - 1) * S[k];
+          pn += (c.h.a_pi_PM * pi_old[k] - 1) * ln;
+          po += (c.h.a_pi_PM * pi_new[k] - 1) * lo;
+        }
       lpdf_new -= n * lB(3);
       lpdf_old -= n * lB(2);
       const double lpn = pn - lB(0);
       const double lpo = po - lB(1);
       const double acc = lpdf_new - lpdf_old + lpo - lpn;
-      if (lu[0] < acc) { pi_is_new = 1; for (int k = 0; k < K; ++k) pi[k] = pi_new[k]; }
-      for (int k = 0; k < K; ++k) dyn->pi[k] = pi[k];
+      if (lu[0] < acc) {
+        pi_is_new = 1;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) pi[k] = pi_new[k];
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K) dyn->pi[k] = pi[k];
     }
     if (mask & U_ALPHA3) {
       double l_old = (-c.h.b) * alpha3, l_new = (-c.h.b) * a3_ph;
-      for (int k = 0; k < K; ++k) {
-        l_old += ((alpha3 * pi[k]) - 1) * S[k];
-        l_new += ((a3_ph * pi[k]) - 1) * S[k];
-      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          l_old += ((alpha3 * pi[k]) - 1) * S[k];
+          l_new += ((a3_ph * pi[k]) - 1) * S[k];
+        }
       l_old -= n * lB(2 + pi_is_new);
       l_new -= n * lB(4 + pi_is_new);
       l_old += dt[0];
