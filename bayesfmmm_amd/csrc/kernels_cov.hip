@@ -11,8 +11,7 @@
 // steps over the per-curve fitted coefficient c_i and g_i = G_i c_i kept in HBM:
 //     rhs_a = (1/sigma^2) [ sum_i w_i (s_i - g_i) + (sum_i w_i^2 G_i) theta_a ],   theta_a ~ N(C_a rhs_a, C_a),
 //     c_i += w_i (theta_a_new - theta_a_old),   g_i += w_i G_i (theta_a_new - theta_a_old)
-// (the c_i / g_i update of step s is applied lazily at the start of step s+1).
-// This round's implementation favours simplicity over speed: two small launches per direction.
+// (the c_i / g_i update of step s is applied lazily at the start of step s+1): one launch per direction, k_cov_step.
 #include "model.hpp"
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
@@ -57,12 +56,20 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
   const int CH = (d.n + c.NB2 - 1) / c.NB2;
   const int i0 = cb * CH, i1 = min(d.n, i0 + CH);
   double acc0 = 0.0, acc1 = 0.0;
-  for (int i = i0; i < i1; ++i) {
-    const double w = w_of(c, i, a);
-    const double w2 = w * w;
-    const double* r = c.rec + (size_t)i * d.LREC;
-    if (tid < d.LG) acc0 += w2 * r[tid];
-    if (tid + 256 < d.LG) acc1 += w2 * r[tid + 256];
+  // (batches of 16 curves: the loads of a batch are in flight together instead of one L2 round trip per curve)
+  for (int ib = i0; ib < i1; ib += 16) {
+    double w2[16], r0[16], r1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = min(ib + u, i1 - 1);
+      const double w = w_of(c, i, a);
+      w2[u] = (ib + u < i1) ? w * w : 0.0;
+      const double* r = c.rec + (size_t)i * d.LREC;
+      r0[u] = (tid < d.LG) ? r[tid] : 0.0;
+      r1[u] = (tid + 256 < d.LG) ? r[tid + 256] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { acc0 += w2[u] * r0[u]; acc1 += w2[u] * r1[u]; }
   }
   double* out = c.w2_part + ((size_t)a2 * c.NB2 + cb) * d.LG;
   if (tid < d.LG) out[tid] = acc0;
@@ -84,7 +91,13 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
   double* hb = zv + PP;            // LG
   for (int e = tid; e < d.LG; e += 256) {
     double s = 0.0;
-    for (int cb = 0; cb < c.NB2; ++cb) s += c.w2_part[((size_t)a2 * c.NB2 + cb) * d.LG + e];
+    for (int cb0 = 0; cb0 < c.NB2; cb0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (cb0 + u < c.NB2) ? c.w2_part[((size_t)a2 * c.NB2 + cb0 + u) * d.LG + e] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     hb[e] = s;
     c.H2aa[(size_t)a2 * d.LG + e] = s;
   }
@@ -123,7 +136,17 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 
-// ---- per-curve part of one step: apply the pending update, accumulate w (s - g) ------------------
+// ---- one step of the eta / Xi sweep: ONE launch per direction -----------------------------------------
+// k_cov_step(a_prev, a_next) is the whole dependent chain between two directions:
+//   1. (a_prev >= 0) every workgroup sums the partial sums the previous launch left (fixed order), forms
+//      rhs = (beta/sigma^2) [ sum_i w_i (s_i - g_i) + H_aa theta_old ] and draws theta_new = C rhs + L z  -- redundantly
+//      and bit-identically in all workgroups, so that the launch boundary is the only grid-wide synchronisation of
+//      the step (a second launch for the draw costs as much as the step itself); workgroup 0 records theta_new,
+//   2. applies c_i += w_i delta, g_i += w_i G_i delta to its curves,
+//   3. (a_next >= 0) accumulates sum_i w_i (s_i - g_i) of the next direction into the other parity of step_part;
+//      (a_next < 0) leaves the residual sums of squares of the final state for the log-likelihood / sigma^2.
+// State-independent operands (C_a, L_a z_a, H_aa, the curve records) are requested before the partial sums so
+// that one memory round trip covers all of them.
 template <int LPC>
 __device__ inline double gsum_l(double v) {
 #pragma unroll
@@ -131,111 +154,162 @@ __device__ inline double gsum_l(double v) {
   return v;
 }
 
-// a2 >= 0: step for direction a2 (partials -> step_part); a2 == -1: final pass (residual sums -> rss_part)
+constexpr int COV_CPG = 4;     // curves per lane group and launch
+
 template <int BW, int LPC>
-__global__ __launch_bounds__(256) void k_cov_accum(Ctx c, int a2) {
+__global__ __launch_bounds__(256) void k_cov_step(Ctx c, int a_prev, int a_next, int par_prev) {
+  constexpr int GPB = 256 / LPC;          // lane groups per workgroup
+  constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR)
+  constexpr int QPL = LPC / LR;           // columns per lane
   __shared__ double sDl[PMAX + 2 * BWMAX + 2];
-  __shared__ double sAcc[8][PMAX];
-  constexpr int GPB = 256 / LPC;
+  __shared__ double sTh[PMAX + 2 * BWMAX + 2];
+  __shared__ double sRhs[PMAX];
+  __shared__ double sAcc[GPB][PMAX];
   const Dims& d = c.d;
   const int n = d.n, P = d.P, tid = threadIdx.x;
   const int grp = tid / LPC, lp = tid % LPC;
   const Dyn* dyn = c.dyn;
-  const int pd = dyn->pend_dir;
-  for (int e = tid; e < PMAX + 2 * BWMAX + 2; e += 256) {
-    const int p = e - BW;
-    sDl[e] = (pd >= 0 && p >= 0 && p < P) ? c.delta_cur[p] : 0.0;
+  const bool act = lp < P;
+  const int pc = min(lp, P - 1);
+
+  // ---- requests that do not depend on the previous step ----
+  const int row = tid / LR, rl = tid % LR;
+  double cr[QPL];
+  double lz = 0.0;
+  int ax_prev = 0;
+  if (a_prev >= 0) {
+    const Dir2 ap = dir2_of(d, a_prev);
+    ax_prev = (ap.j * (d.M + 1) + ap.mt) * d.D + ap.dd;
+    const double* Cg = c.C2 + (size_t)a_prev * P * P;
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+      const int q = rl + u * LR;
+      cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
+    }
+    if (row < P) lz = c.Lz2[(size_t)a_prev * P + row];
+    for (int e = tid; e < PMAX + 2 * BWMAX + 2; e += 256) {
+      const int p = e - BW;
+      sTh[e] = (p >= 0 && p < P) ? c.thetaX[(size_t)ax_prev * P + p] : 0.0;
+    }
   }
-  __syncthreads();
-  const int i = blockIdx.x * GPB + grp;
-  const bool valid = i < n, act = lp < P;
-  double acc = 0.0;
-  if (valid) {
-    // band of G_i in registers (same access pattern as the per-curve kernels)
-    const double* rec = c.rec + (size_t)i * d.LREC;
-    const int pc = min(lp, P - 1);
-    double g[BW + 1], gl[BW + 1];
+  double g[COV_CPG][BW + 1], gl[COV_CPG][BW + 1], sv[COV_CPG], cf[COV_CPG], gv[COV_CPG], wp[COV_CPG], wn[COV_CPG], yy[COV_CPG];
+  const int ibase = (blockIdx.x * GPB + grp) * COV_CPG;
+#pragma unroll
+  for (int u = 0; u < COV_CPG; ++u) {
+    const int i = ibase + u;
+    const bool valid = i < n;
+    const int ic = valid ? i : 0;
+    const double* rec = c.rec + (size_t)ic * d.LREC;
 #pragma unroll
     for (int dd = 0; dd <= BW; ++dd) {
       const double vg = rec[dd * P + pc], vl = rec[dd * P + max(pc - dd, 0)];
-      g[dd] = act ? vg : 0.0;
-      gl[dd] = (act && dd > 0 && lp - dd >= 0) ? vl : 0.0;
+      g[u][dd] = (act && valid) ? vg : 0.0;
+      gl[u][dd] = (act && valid && dd > 0 && lp - dd >= 0) ? vl : 0.0;
     }
-    const double sv = act ? rec[d.LG + pc] : 0.0;
-    double cf = act ? c.cfull[(size_t)i * P + pc] : 0.0;
-    double gv = act ? c.gfull[(size_t)i * P + pc] : 0.0;
-    if (pd >= 0) {
-      const Dir2 ap = dir2_of(d, pd);
-      const double wp = w_of(c, i, ap);
-      const double* dl = sDl + BW + lp;
-      double Gd = g[0] * dl[0];
+    const double s0 = rec[d.LG + pc], c0 = c.cfull[(size_t)ic * P + pc], g0 = c.gfull[(size_t)ic * P + pc];
+    sv[u] = (act && valid) ? s0 : 0.0;
+    cf[u] = (act && valid) ? c0 : 0.0;
+    gv[u] = (act && valid) ? g0 : 0.0;
+    yy[u] = valid ? rec[d.LG + P] : 0.0;
+    wp[u] = (valid && a_prev >= 0) ? w_of(c, ic, dir2_of(d, a_prev)) : 0.0;
+    wn[u] = (valid && a_next >= 0) ? w_of(c, ic, dir2_of(d, a_next)) : 0.0;
+  }
+
+  // ---- the draw of direction a_prev ----
+  if (a_prev >= 0) {
+    const double* sp = c.step_part + (size_t)par_prev * c.NBS * P;
+    // (the partial sums were written by other XCDs: every load is a trip to memory, so they go out in batches)
+    if (lp < P) {
+      double s = 0.0;
+      for (int b0 = grp; b0 < c.NBS; b0 += GPB * 16) {
+        double v[16];
 #pragma unroll
-      for (int dd = 1; dd <= BW; ++dd) Gd += g[dd] * dl[dd] + gl[dd] * dl[-dd];
-      cf += wp * dl[0];
-      gv += wp * Gd;
-      if (act) { c.cfull[(size_t)i * P + lp] = cf; c.gfull[(size_t)i * P + lp] = gv; }
+        for (int u = 0; u < 16; ++u) {
+          const int b = b0 + u * GPB;
+          v[u] = (b < c.NBS) ? sp[(size_t)b * P + lp] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
+      sAcc[grp][lp] = s;
     }
-    if (a2 >= 0) {
-      const Dir2 a = dir2_of(d, a2);
-      acc = w_of(c, i, a) * (sv - gv);
-    } else {
-      const double yy = rec[d.LG + P];
-      const double cs = gsum_l<LPC>(cf * sv), cg = gsum_l<LPC>(cf * gv);
-      acc = yy - 2.0 * cs + cg;          // identical on every lane of the group
+    __syncthreads();
+    const double f = dyn->beta / dyn->sigma2;
+    if (tid < P) {
+      const double* Hb = c.H2aa + (size_t)a_prev * d.LG;
+      const double* th = sTh + BW + tid;
+      double hv = Hb[tid] * th[0];
+#pragma unroll
+      for (int dd = 1; dd <= BW; ++dd) hv += Hb[dd * P + tid] * th[dd] + Hb[dd * P + max(tid - dd, 0)] * th[-dd];
+      double ps = 0.0;
+#pragma unroll
+      for (int gq = 0; gq < GPB; ++gq) ps += sAcc[gq][tid];
+      sRhs[tid] = f * (ps + hv);
+    }
+    __syncthreads();
+    double mean = 0.0;
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+      const int q = rl + u * LR;
+      mean += cr[u] * sRhs[min(q, P - 1)];
+    }
+    mean = gsum_l<LR>(mean);
+    if (tid < BW || (tid >= 64 && tid < 64 + BWMAX + 2)) {     // zero pads of the delta row
+      if (tid < BW) sDl[tid] = 0.0;
+      else if (BW + P + (tid - 64) < PMAX + 2 * BWMAX + 2) sDl[BW + P + (tid - 64)] = 0.0;
+    }
+    if (rl == 0 && row < P) {
+      const double nw = mean + lz;
+      sDl[BW + row] = nw - sTh[BW + row];
+      if (blockIdx.x == 0) c.thetaN[(size_t)ax_prev * P + row] = nw;
+    }
+    __syncthreads();
+    // ---- apply it to this workgroup's curves ----
+    const double* dl = sDl + BW + pc;
+#pragma unroll
+    for (int u = 0; u < COV_CPG; ++u) {
+      double Gd = g[u][0] * dl[0];
+#pragma unroll
+      for (int dd = 1; dd <= BW; ++dd) Gd += g[u][dd] * dl[dd] + gl[u][dd] * dl[-dd];
+      cf[u] += wp[u] * dl[0];
+      gv[u] += wp[u] * Gd;
+      const int i = ibase + u;
+      if (act && i < n) { c.cfull[(size_t)i * P + lp] = cf[u]; c.gfull[(size_t)i * P + lp] = gv[u]; }
+    }
+  }
+
+  // ---- partial sums for the next direction, or the residual sums of the final state ----
+  double acc = 0.0;
+  if (a_next >= 0) {
+#pragma unroll
+    for (int u = 0; u < COV_CPG; ++u) acc += wn[u] * (sv[u] - gv[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < COV_CPG; ++u) {
+      const double cs = gsum_l<LPC>(cf[u] * sv[u]), cg = gsum_l<LPC>(cf[u] * gv[u]);
+      acc += yy[u] - 2.0 * cs + cg;          // identical on every lane of the group
     }
   }
   if (lp < PMAX) sAcc[grp][lp] = acc;
   __syncthreads();
-  if (a2 >= 0) {
+  if (a_next >= 0) {
     if (tid < P) {
       double s = 0.0;
+#pragma unroll
       for (int gq = 0; gq < GPB; ++gq) s += sAcc[gq][tid];
-      c.step_part[(size_t)blockIdx.x * P + tid] = s;
+      c.step_part[((size_t)(par_prev ^ 1) * c.NBS + blockIdx.x) * P + tid] = s;
     }
-  } else if (tid == 0) {
-    double s = 0.0;
-    for (int gq = 0; gq < GPB; ++gq) s += sAcc[gq][0];
-    c.rss_part[blockIdx.x] = s;
+  } else {
+    if (tid == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int gq = 0; gq < GPB; ++gq) s += sAcc[gq][0];
+      c.rss_part[blockIdx.x] = s;
+    }
+    // rss_part is read over nblk_curve entries by the log-likelihood / sigma^2 jobs
+    if (blockIdx.x == 0)
+      for (int b = c.NBS + tid; b < c.nblk_curve; b += 256) c.rss_part[b] = 0.0;
   }
-}
-
-// ---- the draw of one step: one workgroup -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cov_draw(Ctx c, int a2) {
-  __shared__ double part[4][PMAX], rhs[PMAX], thold[PMAX + 2 * BWMAX + 2];
-  const Dims& d = c.d;
-  const int P = d.P, D = d.D, M = d.M, tid = threadIdx.x;
-  Dyn* dyn = c.dyn;
-  const Dir2 a = dir2_of(d, a2);
-  const int ax = (a.j * (M + 1) + a.mt) * D + a.dd;
-  const int p0 = tid & 63, seg = tid >> 6;
-  if (p0 < P) {
-    double s = 0.0;
-    for (int b = seg; b < c.nblk_curve; b += 4) s += c.step_part[(size_t)b * P + p0];
-    part[seg][p0] = s;
-  }
-  for (int e = tid; e < PMAX + 2 * BWMAX + 2; e += 256) {
-    const int p = e - d.BW;
-    thold[e] = (p >= 0 && p < P) ? c.thetaX[(size_t)ax * P + p] : 0.0;
-  }
-  __syncthreads();
-  const double f = dyn->beta / dyn->sigma2;
-  if (tid < P) {
-    const double* Hb = c.H2aa + (size_t)a2 * d.LG;
-    const double* th = thold + d.BW + tid;
-    double hv = Hb[tid] * th[0];
-    for (int dd = 1; dd <= d.BW; ++dd) hv += Hb[dd * P + tid] * th[dd] + Hb[dd * P + tid - dd] * th[-dd];
-    rhs[tid] = f * (((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + hv);
-  }
-  __syncthreads();
-  if (tid < P) {
-    const double* Cg = c.C2 + (size_t)a2 * P * P;
-    double mean = 0.0;
-    for (int q = 0; q < P; ++q) mean += Cg[tid + (size_t)P * q] * rhs[q];
-    const double nw = mean + c.Lz2[(size_t)a2 * P + tid];
-    c.delta_cur[tid] = nw - thold[d.BW + tid];
-    c.thetaX[(size_t)ax * P + tid] = nw;
-  }
-  if (tid == 0) dyn->pend_dir = a2;
 }
 
 // ---- tau_eta, delta_xi, A_xi, gamma_xi and the chain slots of the covariate blocks: one workgroup ----
@@ -248,6 +322,15 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
   const uint32_t mask = c.mask, slot = dyn->slot;
   const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
   if (tid == 0) dyn->pend_dir = -1;
+  // ---- commit this iteration's eta / Xi draws (k_cov_step leaves them in thetaN) ----
+  for (int e = tid; e < c.A2 * P; e += 256) {
+    const int a2 = e / P, p = e - a2 * P;
+    const Dir2 a = dir2_of(d, a2);
+    if (!dir2_updated(c, a)) continue;
+    const size_t ax = (size_t)((a.j * (M + 1) + a.mt) * D + a.dd);
+    c.thetaX[ax * P + p] = c.thetaN[ax * P + p];
+  }
+  __syncthreads();
   // ---- tau_eta (UpdateTau.h:75-95; MV :106-124) ----
   if (mask & U_TAU_ETA) {
     for (int j = 0; j < K; ++j)
@@ -376,27 +459,31 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
 
 // ---- host launchers -------------------------------------------------------------------------
 template <int BW>
-static void launch_accum_bw(const Ctx& c, int a2, hipStream_t st) {
-  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_accum<BW, 32>), dim3(c.nblk_curve), dim3(256), 0, st, c, a2);
-  else hipLaunchKernelGGL((k_cov_accum<BW, 64>), dim3(c.nblk_curve), dim3(256), 0, st, c, a2);
+static void launch_step_bw(const Ctx& c, int a_prev, int a_next, int par_prev, hipStream_t st) {
+  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_step<BW, 32>), dim3(c.NBS), dim3(256), 0, st, c, a_prev, a_next, par_prev);
+  else hipLaunchKernelGGL((k_cov_step<BW, 64>), dim3(c.NBS), dim3(256), 0, st, c, a_prev, a_next, par_prev);
 }
 
-static void launch_accum(const Ctx& c, int a2, hipStream_t st) {
+static void launch_step(const Ctx& c, int a_prev, int a_next, int par_prev, hipStream_t st) {
   switch (c.d.BW) {
-    case 0: launch_accum_bw<0>(c, a2, st); break;
-    case 1: launch_accum_bw<1>(c, a2, st); break;
-    case 2: launch_accum_bw<2>(c, a2, st); break;
-    case 3: launch_accum_bw<3>(c, a2, st); break;
-    case 4: launch_accum_bw<4>(c, a2, st); break;
-    default: launch_accum_bw<5>(c, a2, st); break;
+    case 0: launch_step_bw<0>(c, a_prev, a_next, par_prev, st); break;
+    case 1: launch_step_bw<1>(c, a_prev, a_next, par_prev, st); break;
+    case 2: launch_step_bw<2>(c, a_prev, a_next, par_prev, st); break;
+    case 3: launch_step_bw<3>(c, a_prev, a_next, par_prev, st); break;
+    case 4: launch_step_bw<4>(c, a_prev, a_next, par_prev, st); break;
+    default: launch_step_bw<5>(c, a_prev, a_next, par_prev, st); break;
   }
 }
+
+// curve blocks of k_cov_step for nblk_curve blocks of the per-curve kernels
+int cov_step_blocks(int nblk_curve) { return (nblk_curve + COV_CPG - 1) / COV_CPG; }
 
 // the eta / Xi part of one iteration (after k_curve_chi has stored c_i, g_i)
 void launch_cov_block(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   const bool do_eta = (c.mask & U_ETA) != 0;
   const bool do_xi = (c.mask & U_XI) != 0 && c.covariance_adj && d.MD > 1;
+  int a_prev = -1, par = 0;
   if (do_eta || do_xi) {
     hipLaunchKernelGGL(k_cov_w2, dim3(c.A2, c.NB2), dim3(256), 0, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
@@ -406,11 +493,12 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     const int n_eta = d.K * d.D;
     for (int a2 = 0; a2 < c.A2; ++a2) {
       if (a2 < n_eta ? !do_eta : !do_xi) continue;
-      launch_accum(c, a2, st);
-      hipLaunchKernelGGL(k_cov_draw, dim3(1), dim3(256), 0, st, c, a2);
+      launch_step(c, a_prev, a2, par, st);      // partial sums of a2 go to parity par ^ 1
+      a_prev = a2;
+      par ^= 1;
     }
   }
-  launch_accum(c, -1, st);      // applies the last pending update and leaves the residual sums for the log-likelihood
+  launch_step(c, a_prev, -1, par, st);      // the last draw, and the residual sums for the log-likelihood
   hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(256), 0, st, c);
 }
 

@@ -133,7 +133,8 @@ struct Ctx {
   double* H2aa;                 // A2 x LG         sum_i w^2 G_i
   double* C2;                   // A2 x P x P
   double* Lz2;                  // A2 x P
-  double* step_part;            // NBS x P         partial sums of w (s_i - g_i) of the current step
+  double* step_part;            // 2 x NBS x P     partial sums of w (s_i - g_i) of the current step (two parities)
+  double* thetaN;               // as thetaX: the values drawn in this iteration's eta / Xi steps (committed by k_cov_hyper)
   double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
   int defer_loglik;             // the iteration has no k_loglik: bookkeeping in job_hyper, reduction in the next k_pair_gram
   int ll_use_part;              // (deferred) log-likelihood from the per-curve residual partial sums
