@@ -32,6 +32,7 @@ void launch_loglik_flush(const Ctx& c, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 void launch_cov_block(const Ctx& c, hipStream_t st);
 int cov_step_blocks(int nblk_curve);
+int cov_w2_chunks(int n);
 void prepare_cov_kernels();
 #ifdef BFMMM_TIMELINE
 void fetch_wgtrace(unsigned long long* out);
@@ -313,8 +314,10 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   d.D = D;
   c.covariance_adj = covariance_adj ? 1 : 0;
   c.A2 = (int)(K * D + (covariance_adj ? K * M * D : 0));
-  c.NB2 = 32;
+  c.NB2 = cov_w2_chunks((int)n);
   c.NBS = cov_step_blocks(c.nblk_curve);
+  c.NPG = D * (D + 1) / 2;
+  c.NPAIR = (c.A2 / D) * c.NPG;
   double* Xd;
   if (dalloc(h, &Xd, n * D)) return 1;
   HIPCHK(copy_sync(h, Xd, X, sizeof(double) * n * D, hipMemcpyHostToDevice));
@@ -322,9 +325,10 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   if (dalloc(h, &c.thetaX, K * (M + 1) * D * P) || dalloc(h, &c.tau_eta, K * D) || dalloc(h, &c.gamma_xi, K * P * D * M) ||
       dalloc(h, &c.delta_xi, K * M * D) || dalloc(h, &c.A_xi, K * 2 * D) || dalloc(h, &c.stil, n * P) ||
       dalloc(h, &c.yyp_part, (size_t)c.nblk_curve) || dalloc(h, &c.cfull, n * P) || dalloc(h, &c.gfull, n * P) ||
-      dalloc(h, &c.w2_part, (size_t)c.A2 * c.NB2 * d.LG) || dalloc(h, &c.H2aa, (size_t)c.A2 * d.LG) ||
+      dalloc(h, &c.w2_part, (size_t)c.NPAIR * c.NB2 * d.LG) || dalloc(h, &c.H2aa, (size_t)c.NPAIR * d.LG) ||
+      dalloc(h, &c.Wdir, n * (size_t)c.A2) || dalloc(h, &c.gstd2, K * D + K * M * D + K * D * P * M) ||
       dalloc(h, &c.C2, (size_t)c.A2 * P * P) || dalloc(h, &c.Lz2, (size_t)c.A2 * P) ||
-      dalloc(h, &c.step_part, 2 * (size_t)c.nblk_curve * P) || dalloc(h, &c.thetaN, K * (M + 1) * D * P) || dalloc(h, &c.delta_cur, P + 2) ||
+      dalloc(h, &c.step_part, 2 * (size_t)c.NBS * D * P) || dalloc(h, &c.thetaN, K * (M + 1) * D * P) || dalloc(h, &c.delta_cur, P + 2) ||
       dalloc(h, &c.c_eta, T * P * D * K) || dalloc(h, &c.c_xi, T * K * P * D * M) || dalloc(h, &c.c_tau_eta, T * K * D) ||
       dalloc(h, &c.c_gamma_xi, T * K * P * D * M) || dalloc(h, &c.c_delta_xi, T * K * M * D) || dalloc(h, &c.c_A_xi, T * K * 2 * D))
     return 1;

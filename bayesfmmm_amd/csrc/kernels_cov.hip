@@ -47,42 +47,135 @@ __device__ inline bool dir2_updated(const Ctx& c, const Dir2& a) {
   return (c.mask & U_XI) != 0 && c.d.MD > 1;
 }
 
-// ---- sum_i w_i^2 G_i, partial over curve chunks: grid (A2, NB2) --------------------------------
-__global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
-  const Dims& d = c.d;
-  const int a2 = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
-  const Dir2 a = dir2_of(d, a2);
-  if (!dir2_updated(c, a)) return;
-  const int CH = (d.n + c.NB2 - 1) / c.NB2;
-  const int i0 = cb * CH, i1 = min(d.n, i0 + CH);
-  double acc0 = 0.0, acc1 = 0.0;
-  // (batches of 16 curves: the loads of a batch are in flight together instead of one L2 round trip per curve)
-  for (int ib = i0; ib < i1; ib += 16) {
-    double w2[16], r0[16], r1[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = min(ib + u, i1 - 1);
-      const double w = w_of(c, i, a);
-      w2[u] = (ib + u < i1) ? w * w : 0.0;
-      const double* r = c.rec + (size_t)i * d.LREC;
-      r0[u] = (tid < d.LG) ? r[tid] : 0.0;
-      r1[u] = (tid + 256 < d.LG) ? r[tid + 256] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { acc0 += w2[u] * r0[u]; acc1 += w2[u] * r1[u]; }
-  }
-  double* out = c.w2_part + ((size_t)a2 * c.NB2 + cb) * d.LG;
-  if (tid < d.LG) out[tid] = acc0;
-  if (tid + 256 < d.LG) out[tid + 256] = acc1;
+constexpr int DMAX_COV = 8;     // covariates (bfmmm_set_covariates)
+
+// in-group pair q = v(v+1)/2 + u  (u <= v < D)
+__host__ __device__ inline void pair_uv(int q, int& u, int& v) {
+  v = 0;
+  while ((v + 1) * (v + 2) / 2 <= q) ++v;
+  u = q - v * (v + 1) / 2;
 }
 
-// ---- C_a, L_a z_a for every eta / Xi direction: grid A2 -----------------------------------------
+// ---- preparation, one launch: (a) w_{a,i} for every eta / Xi direction (Z, chi, X are fixed during the block):
+//      Wdir[i][a];  (b) the standard gamma variates of tau_eta, delta_xi, gamma_xi -- their shapes do not depend on
+//      anything this iteration samples (delta_xi's uses A_xi, which is updated after it), so k_cov_hyper only scales
+//      them: rgamma(shape, scale) == rgamma(shape, 1) * scale bit for bit (rng.hpp).  gstd2 = [K*D | K*M*D | K*D*P*M].
+__global__ __launch_bounds__(256) void k_cov_prep(Ctx c, int n_wblocks) {
+  const Dims& d = c.d;
+  if ((int)blockIdx.x < n_wblocks) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)d.n * c.A2;
+    if (e >= tot) return;
+    const int i = (int)(e / c.A2), a2 = (int)(e - (size_t)i * c.A2);
+    c.Wdir[e] = w_of(c, i, dir2_of(d, a2));
+    return;
+  }
+  const int P = d.P, K = d.K, M = d.M, D = d.D;
+  const int n_tau = K * D, n_del = K * M * D, n_gam = K * D * P * M;
+  const int e = ((int)blockIdx.x - n_wblocks) * 256 + threadIdx.x;
+  const RngKey key = make_key(c.seed, c.chain, c.dyn->iter, c.dyn->tt_step);
+  const bool xi_on = c.covariance_adj && d.MD > 1;
+  if (e < n_tau) {
+    if (c.mask & U_TAU_ETA) c.gstd2[e] = rgamma(key, UPD_TAU_ETA, (uint32_t)e, c.h.alpha_eta + (P / 2), 1.0);   // integer division, UpdateTau.h:87
+  } else if (e < n_tau + n_del) {
+    if ((c.mask & U_DELTA_XI) && xi_on) {
+      const int idx = e - n_tau;                    // (dd*K + k)*M + i
+      const int i = idx % M, k = (idx / M) % K, dd = idx / (M * K);
+      const double shape = (i == 0) ? c.A_xi[k + (size_t)K * (0 + 2 * (size_t)dd)] + ((P * M) * 0.5)
+                                    : c.A_xi[k + (size_t)K * (1 + 2 * (size_t)dd)] + ((P * (M - i)) * 0.5);
+      c.gstd2[e] = rgamma(key, UPD_DELTA_XI, (uint32_t)idx, shape, 1.0);
+    }
+  } else if (e < n_tau + n_del + n_gam) {
+    if ((c.mask & U_GAMMA_XI) && xi_on) c.gstd2[e] = rgamma(key, UPD_GAMMA_XI, (uint32_t)(e - n_tau - n_del), (c.h.nu_1 + 1) / 2, 1.0);
+  }
+}
+
+// ---- sum_i w_a w_b G_i over the in-group direction pairs, partial over curve chunks: grid (groups, NB2) ----
+// One workgroup = one group of D directions x one chunk of curves: a thread owns one record element e (two "halves"
+// of the chunk side by side when LG <= 128) and keeps the NPG pair accumulators of the group in registers, so a
+// record element is read once for all D(D+1)/2 pairs; the pair weights of the chunk are formed in LDS first.
+constexpr int NPG_MAX = DMAX_COV * (DMAX_COV + 1) / 2;
+constexpr int W2_CH = 128;       // curves per chunk (NB2 = ceil(n / W2_CH))
+
+__global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const Dims& d = c.d;
+  const int g = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
+  const int D = d.D, NPG = c.NPG, LG = d.LG;
+  if (!dir2_updated(c, dir2_of(d, g * D))) return;
+  const int i0 = cb * W2_CH, nc = min(d.n - i0, W2_CH);
+  double* sW = sm;                       // W2_CH x D
+  double* sPW = sW + W2_CH * DMAX_COV;   // W2_CH x NPG
+  double* sRed = sPW + W2_CH * NPG_MAX;  // NPG x LGR (second half's sums)
+  for (int e = tid; e < nc * D; e += 256) {
+    const int cl = e / D, s = e - cl * D;
+    sW[cl * D + s] = c.Wdir[(size_t)(i0 + cl) * c.A2 + g * D + s];
+  }
+  __syncthreads();
+  for (int e = tid; e < W2_CH * NPG; e += 256) {
+    const int cl = e / NPG, q = e - cl * NPG;
+    int u, v;
+    pair_uv(q, u, v);
+    sPW[cl * NPG + q] = (cl < nc) ? sW[cl * D + u] * sW[cl * D + v] : 0.0;
+  }
+  __syncthreads();
+  const int LGR = (LG + 63) & ~63;
+  const int NH = (LGR <= 128) ? 2 : 1;
+  const int half = (NH == 2) ? tid / 128 : 0;
+  const int e0 = (NH == 2) ? tid % 128 : tid;
+  const int per = W2_CH / NH;                      // curves per half
+  const int cl0 = half * per;
+  for (int ep = 0; ep < LG; ep += 256) {
+    const int e = ep + e0;
+    const bool on = e < LG;
+    double acc[NPG_MAX];
+#pragma unroll
+    for (int q = 0; q < NPG_MAX; ++q) acc[q] = 0.0;
+    for (int cb0 = 0; cb0 < per; cb0 += 16) {
+      double r[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int cl = min(cl0 + cb0 + t, nc - 1);
+        r[t] = on ? c.rec[(size_t)(i0 + max(cl, 0)) * d.LREC + e] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double* pw = sPW + (cl0 + cb0 + t) * NPG;       // zero rows beyond the chunk's curves
+#pragma unroll
+        for (int q = 0; q < NPG_MAX; ++q)
+          if (q < NPG) acc[q] += pw[q] * r[t];
+      }
+    }
+    if (NH == 2) {
+      __syncthreads();
+      if (half == 1)
+#pragma unroll
+        for (int q = 0; q < NPG_MAX; ++q)
+          if (q < NPG) sRed[q * 128 + e0] = acc[q];
+      __syncthreads();
+      if (half == 0 && on)
+#pragma unroll
+        for (int q = 0; q < NPG_MAX; ++q)
+          if (q < NPG) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q] + sRed[q * 128 + e0];
+    } else if (on) {
+#pragma unroll
+      for (int q = 0; q < NPG_MAX; ++q)
+        if (q < NPG) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q];
+    }
+  }
+}
+
+// ---- H_ab for every in-group pair; C_a, L_a z_a for every eta / Xi direction: grid NPAIR -----------------
 template <int PP>
 __global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, D = d.D, tid = threadIdx.x;
-  const int a2 = blockIdx.x;
+  const int pid = blockIdx.x;
+  const int g = pid / c.NPG;
+  int pu, pv;
+  pair_uv(pid - g * c.NPG, pu, pv);
+  const int a2 = g * D + pu;
   const Dir2 a = dir2_of(d, a2);
   if (!dir2_updated(c, a)) return;
   double* S = smem;
@@ -94,13 +187,14 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
     for (int cb0 = 0; cb0 < c.NB2; cb0 += 16) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (cb0 + u < c.NB2) ? c.w2_part[((size_t)a2 * c.NB2 + cb0 + u) * d.LG + e] : 0.0;
+      for (int u = 0; u < 16; ++u) v[u] = (cb0 + u < c.NB2) ? c.w2_part[((size_t)pid * c.NB2 + cb0 + u) * d.LG + e] : 0.0;
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += v[u];
     }
     hb[e] = s;
-    c.H2aa[(size_t)a2 * d.LG + e] = s;
+    c.H2aa[(size_t)pid * d.LG + e] = s;
   }
+  if (pu != pv) return;      // off-diagonal pair: only the reduction
   __syncthreads();
   const Dyn* dyn = c.dyn;
   const double f = dyn->beta / dyn->sigma2;
@@ -136,17 +230,20 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 
-// ---- one step of the eta / Xi sweep: ONE launch per direction -----------------------------------------
-// k_cov_step(a_prev, a_next) is the whole dependent chain between two directions:
-//   1. (a_prev >= 0) every workgroup sums the partial sums the previous launch left (fixed order), forms
-//      rhs = (beta/sigma^2) [ sum_i w_i (s_i - g_i) + H_aa theta_old ] and draws theta_new = C rhs + L z  -- redundantly
-//      and bit-identically in all workgroups, so that the launch boundary is the only grid-wide synchronisation of
-//      the step (a second launch for the draw costs as much as the step itself); workgroup 0 records theta_new,
-//   2. applies c_i += w_i delta, g_i += w_i G_i delta to its curves,
-//   3. (a_next >= 0) accumulates sum_i w_i (s_i - g_i) of the next direction into the other parity of step_part;
-//      (a_next < 0) leaves the residual sums of squares of the final state for the log-likelihood / sigma^2.
-// State-independent operands (C_a, L_a z_a, H_aa, the curve records) are requested before the partial sums so
-// that one memory round trip covers all of them.
+// ---- one GROUP of the eta / Xi sweep per launch ---------------------------------------------------------
+// The K*D + K*M*D directions are visited in the reference's order, D consecutive directions ("group") per launch.
+// k_cov_group(g_prev, g_next):
+//   1. (g_prev >= 0) every workgroup sums the partial sums r_s = sum_i w_{s,i} (s_i - g_i) the previous launch left
+//      for the D directions of g_prev (fixed order) and runs the D sequential draws itself -- redundantly and
+//      bit-identically in all workgroups, so that the launch boundary is the only grid-wide synchronisation of a
+//      group: inside the group, direction s sees the earlier draws through the pair blocks H_su = sum_i w_s w_u G_i,
+//        r_s <- r_s - sum_{u<s} H_su delta_u,   rhs = (beta/sigma^2) (r_s + H_ss theta_old),   theta_new = C_s rhs + L_s z_s;
+//      workgroup 0 records theta_new,
+//   2. applies c_i += v_i, g_i += G_i v_i with v_i = sum_s w_{s,i} delta_s to its curves,
+//   3. (g_next >= 0) accumulates the D partial sums of the next group into the other parity of step_part;
+//      (g_next < 0) leaves the residual sums of squares of the final state for the log-likelihood / sigma^2.
+// State-independent operands (the curve records, weights, pair blocks, C_s, L_s z_s) are requested before the partial
+// sums so that they share one memory round trip.
 template <int LPC>
 __device__ inline double gsum_l(double v) {
 #pragma unroll
@@ -155,55 +252,70 @@ __device__ inline double gsum_l(double v) {
 }
 
 constexpr int COV_CPG = 4;     // curves per lane group and launch
+constexpr int DMAX = DMAX_COV;
+constexpr int PADW = PMAX + 2 * BWMAX + 2;
 
 template <int BW, int LPC>
-__global__ __launch_bounds__(256) void k_cov_step(Ctx c, int a_prev, int a_next, int par_prev) {
+__global__ __launch_bounds__(256) void k_cov_group(Ctx c, int g_prev, int g_next, int par_prev) {
   constexpr int GPB = 256 / LPC;          // lane groups per workgroup
+  constexpr int CPB = GPB * COV_CPG;      // curves per workgroup
   constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR)
   constexpr int QPL = LPC / LR;           // columns per lane
-  __shared__ double sDl[PMAX + 2 * BWMAX + 2];
-  __shared__ double sTh[PMAX + 2 * BWMAX + 2];
+  extern __shared__ __attribute__((aligned(16))) double sHp[];     // NPG x LG pair blocks of g_prev
+  __shared__ double sDl[DMAX][PADW];
+  __shared__ double sTh[DMAX][PADW];
+  __shared__ double sR[DMAX * PMAX];
+  __shared__ double sLz[DMAX][PMAX];
   __shared__ double sRhs[PMAX];
-  __shared__ double sAcc[GPB][PMAX];
+  __shared__ double sAcc[GPB][DMAX][LPC];
+  __shared__ double sWp[CPB][DMAX], sWn[CPB][DMAX];
   const Dims& d = c.d;
-  const int n = d.n, P = d.P, tid = threadIdx.x;
+  const int n = d.n, P = d.P, D = d.D, DP = D * P, tid = threadIdx.x;
   const int grp = tid / LPC, lp = tid % LPC;
   const Dyn* dyn = c.dyn;
   const bool act = lp < P;
   const int pc = min(lp, P - 1);
-
-  // ---- requests that do not depend on the previous step ----
   const int row = tid / LR, rl = tid % LR;
+  const int cbase = blockIdx.x * CPB;
+
+  // ---- requests that do not depend on the previous group ----
   double cr[QPL];
-  double lz = 0.0;
-  int ax_prev = 0;
-  if (a_prev >= 0) {
-    const Dir2 ap = dir2_of(d, a_prev);
-    ax_prev = (ap.j * (d.M + 1) + ap.mt) * d.D + ap.dd;
-    const double* Cg = c.C2 + (size_t)a_prev * P * P;
+  if (g_prev >= 0) {
+    const int a0 = g_prev * D;
+    const double* Cg = c.C2 + (size_t)a0 * P * P;
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {
       const int q = rl + u * LR;
       cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
     }
-    if (row < P) lz = c.Lz2[(size_t)a_prev * P + row];
-    for (int e = tid; e < PMAX + 2 * BWMAX + 2; e += 256) {
-      const int p = e - BW;
-      sTh[e] = (p >= 0 && p < P) ? c.thetaX[(size_t)ax_prev * P + p] : 0.0;
+    const double* Hg = c.H2aa + (size_t)g_prev * c.NPG * d.LG;
+    for (int e = tid; e < c.NPG * d.LG; e += 256) sHp[e] = Hg[e];
+    for (int e = tid; e < D * PADW; e += 256) {
+      const int s = e / PADW, p = e - s * PADW - BW;
+      const Dir2 as = dir2_of(d, a0 + s);
+      const int ax = (as.j * (d.M + 1) + as.mt) * D + as.dd;
+      sTh[s][e - s * PADW] = (p >= 0 && p < P) ? c.thetaX[(size_t)ax * P + p] : 0.0;
+      sDl[s][e - s * PADW] = 0.0;
     }
+    for (int e = tid; e < DP; e += 256) sLz[e / P][e % P] = c.Lz2[(size_t)a0 * P + e];
   }
-  double g[COV_CPG][BW + 1], gl[COV_CPG][BW + 1], sv[COV_CPG], cf[COV_CPG], gv[COV_CPG], wp[COV_CPG], wn[COV_CPG], yy[COV_CPG];
-  const int ibase = (blockIdx.x * GPB + grp) * COV_CPG;
+  for (int e = tid; e < CPB * D; e += 256) {
+    const int cl = e / D, s = e - cl * D;
+    const int i = cbase + cl;
+    sWp[cl][s] = (i < n && g_prev >= 0) ? c.Wdir[(size_t)i * c.A2 + g_prev * D + s] : 0.0;
+    sWn[cl][s] = (i < n && g_next >= 0) ? c.Wdir[(size_t)i * c.A2 + g_next * D + s] : 0.0;
+  }
+  double g[COV_CPG][BW + 1], gl[COV_CPG][BW + 1], sv[COV_CPG], cf[COV_CPG], gv[COV_CPG], yy[COV_CPG];
 #pragma unroll
   for (int u = 0; u < COV_CPG; ++u) {
-    const int i = ibase + u;
+    const int i = cbase + grp * COV_CPG + u;
     const bool valid = i < n;
     const int ic = valid ? i : 0;
     const double* rec = c.rec + (size_t)ic * d.LREC;
 #pragma unroll
     for (int dd = 0; dd <= BW; ++dd) {
       const double vg = rec[dd * P + pc], vl = rec[dd * P + max(pc - dd, 0)];
-      g[u][dd] = (act && valid) ? vg : 0.0;
+      g[u][dd] = (act && valid && lp + dd < P) ? vg : 0.0;
       gl[u][dd] = (act && valid && dd > 0 && lp - dd >= 0) ? vl : 0.0;
     }
     const double s0 = rec[d.LG + pc], c0 = c.cfull[(size_t)ic * P + pc], g0 = c.gfull[(size_t)ic * P + pc];
@@ -211,100 +323,145 @@ __global__ __launch_bounds__(256) void k_cov_step(Ctx c, int a_prev, int a_next,
     cf[u] = (act && valid) ? c0 : 0.0;
     gv[u] = (act && valid) ? g0 : 0.0;
     yy[u] = valid ? rec[d.LG + P] : 0.0;
-    wp[u] = (valid && a_prev >= 0) ? w_of(c, ic, dir2_of(d, a_prev)) : 0.0;
-    wn[u] = (valid && a_next >= 0) ? w_of(c, ic, dir2_of(d, a_next)) : 0.0;
   }
 
-  // ---- the draw of direction a_prev ----
-  if (a_prev >= 0) {
-    const double* sp = c.step_part + (size_t)par_prev * c.NBS * P;
-    // (the partial sums were written by other XCDs: every load is a trip to memory, so they go out in batches)
-    if (lp < P) {
-      double s = 0.0;
-      for (int b0 = grp; b0 < c.NBS; b0 += GPB * 16) {
-        double v[16];
+  if (g_prev >= 0) {
+    // ---- r_s of the D directions: fixed-order sum of the previous launch's partial sums.  They were written by
+    //      other XCDs (every load is a trip to memory), so they go out in batches of 80 ----
+    const double* sp = c.step_part + (size_t)par_prev * c.NBS * DP;
+    const int seg = tid >> 5, l32 = tid & 31;
+    for (int v0 = 0; v0 < DP; v0 += 160) {
+      double accv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int b0 = seg; b0 < c.NBS; b0 += 8 * 16) {
+        double t[5][16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int b = b0 + u * GPB;
-          v[u] = (b < c.NBS) ? sp[(size_t)b * P + lp] : 0.0;
-        }
+        for (int w = 0; w < 5; ++w)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+          for (int u = 0; u < 16; ++u) {
+            const int v = v0 + w * 32 + l32, b = b0 + u * 8;
+            t[w][u] = (v < DP && b < c.NBS) ? sp[(size_t)b * DP + v] : 0.0;
+          }
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+#pragma unroll
+          for (int u = 0; u < 16; ++u) accv[w] += t[w][u];
       }
-      sAcc[grp][lp] = s;
+      // the 8 segments of a value meet in LDS (sAcc is free until the accumulation phase)
+      double* red = &sAcc[0][0][0];          // >= 8 x 160 doubles
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < 5; ++w) red[seg * 160 + w * 32 + l32] = accv[w];
+      __syncthreads();
+      if (tid < 160 && v0 + tid < DP) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q * 160 + tid];
+        sR[v0 + tid] = s;
+      }
     }
     __syncthreads();
+    // ---- the D sequential draws ----
     const double f = dyn->beta / dyn->sigma2;
-    if (tid < P) {
-      const double* Hb = c.H2aa + (size_t)a_prev * d.LG;
-      const double* th = sTh + BW + tid;
-      double hv = Hb[tid] * th[0];
+    for (int s = 0; s < D; ++s) {
+      const int a2 = g_prev * D + s;
+      // rhs_s: lanes of a row share the pairs (u, s), u <= s
+      double part = 0.0;
+      if (row < P) {
+        for (int u = rl; u <= s; u += LR) {
+          const double* Hb = sHp + (size_t)(s * (s + 1) / 2 + u) * d.LG;
+          const double* vec = (u < s) ? &sDl[u][BW + row] : &sTh[s][BW + row];
+          double hv = Hb[row] * vec[0];
 #pragma unroll
-      for (int dd = 1; dd <= BW; ++dd) hv += Hb[dd * P + tid] * th[dd] + Hb[dd * P + max(tid - dd, 0)] * th[-dd];
-      double ps = 0.0;
+          for (int dd = 1; dd <= BW; ++dd) hv += Hb[dd * P + row] * vec[dd] + Hb[dd * P + max(row - dd, 0)] * vec[-dd];
+          part += (u < s) ? -hv : hv;
+        }
+      }
+      part = gsum_l<LR>(part);
+      if (rl == 0 && row < P) sRhs[row] = f * (sR[s * P + row] + part);
+      __syncthreads();
+      double mean = 0.0;
 #pragma unroll
-      for (int gq = 0; gq < GPB; ++gq) ps += sAcc[gq][tid];
-      sRhs[tid] = f * (ps + hv);
-    }
-    __syncthreads();
-    double mean = 0.0;
+      for (int u = 0; u < QPL; ++u) mean += cr[u] * sRhs[min(rl + u * LR, P - 1)];
+      mean = gsum_l<LR>(mean);
+      if (s + 1 < D) {       // C of the next direction is on its way while this one is finished
+        const double* Cg = c.C2 + (size_t)(a2 + 1) * P * P;
 #pragma unroll
-    for (int u = 0; u < QPL; ++u) {
-      const int q = rl + u * LR;
-      mean += cr[u] * sRhs[min(q, P - 1)];
+        for (int u = 0; u < QPL; ++u) {
+          const int q = rl + u * LR;
+          cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
+        }
+      }
+      if (rl == 0 && row < P) {
+        const double nw = mean + sLz[s][row];
+        sDl[s][BW + row] = nw - sTh[s][BW + row];
+        if (blockIdx.x == 0) {
+          const Dir2 as = dir2_of(d, a2);
+          const int ax = (as.j * (d.M + 1) + as.mt) * D + as.dd;
+          c.thetaN[(size_t)ax * P + row] = nw;
+        }
+      }
+      __syncthreads();
     }
-    mean = gsum_l<LR>(mean);
-    if (tid < BW || (tid >= 64 && tid < 64 + BWMAX + 2)) {     // zero pads of the delta row
-      if (tid < BW) sDl[tid] = 0.0;
-      else if (BW + P + (tid - 64) < PMAX + 2 * BWMAX + 2) sDl[BW + P + (tid - 64)] = 0.0;
-    }
-    if (rl == 0 && row < P) {
-      const double nw = mean + lz;
-      sDl[BW + row] = nw - sTh[BW + row];
-      if (blockIdx.x == 0) c.thetaN[(size_t)ax_prev * P + row] = nw;
-    }
-    __syncthreads();
-    // ---- apply it to this workgroup's curves ----
-    const double* dl = sDl + BW + pc;
+    // ---- apply the group to this workgroup's curves ----
 #pragma unroll
     for (int u = 0; u < COV_CPG; ++u) {
-      double Gd = g[u][0] * dl[0];
+      const int cl = grp * COV_CPG + u;
+      double v = 0.0;
+      for (int s = 0; s < D; ++s) v += sWp[cl][s] * sDl[s][BW + pc];
+      if (!act) v = 0.0;
+      double Gd = g[u][0] * v;
 #pragma unroll
-      for (int dd = 1; dd <= BW; ++dd) Gd += g[u][dd] * dl[dd] + gl[u][dd] * dl[-dd];
-      cf[u] += wp[u] * dl[0];
-      gv[u] += wp[u] * Gd;
-      const int i = ibase + u;
+      for (int dd = 1; dd <= BW; ++dd) {
+        const double vu = __shfl_down(v, dd, LPC), vd = __shfl_up(v, dd, LPC);
+        Gd += g[u][dd] * ((lp + dd < P) ? vu : 0.0) + gl[u][dd] * ((lp - dd >= 0) ? vd : 0.0);
+      }
+      cf[u] += v;
+      gv[u] += Gd;
+      const int i = cbase + cl;
       if (act && i < n) { c.cfull[(size_t)i * P + lp] = cf[u]; c.gfull[(size_t)i * P + lp] = gv[u]; }
     }
   }
 
-  // ---- partial sums for the next direction, or the residual sums of the final state ----
-  double acc = 0.0;
-  if (a_next >= 0) {
+  // ---- partial sums for the next group, or the residual sums of the final state ----
+  if (g_next >= 0) {
+    double acc[DMAX];
 #pragma unroll
-    for (int u = 0; u < COV_CPG; ++u) acc += wn[u] * (sv[u] - gv[u]);
+    for (int s = 0; s < DMAX; ++s) acc[s] = 0.0;
+#pragma unroll
+    for (int u = 0; u < COV_CPG; ++u) {
+      const double rsd = sv[u] - gv[u];
+      const int cl = grp * COV_CPG + u;
+#pragma unroll
+      for (int s = 0; s < DMAX; ++s)
+        if (s < D) acc[s] += sWn[cl][s] * rsd;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DMAX; ++s)
+      if (s < D) sAcc[grp][s][lp] = acc[s];
+    __syncthreads();
+    for (int e = tid; e < DP; e += 256) {
+      const int s = e / P, p = e - s * P;
+      double t = 0.0;
+#pragma unroll
+      for (int gq = 0; gq < GPB; ++gq) t += sAcc[gq][s][p];
+      c.step_part[((size_t)(par_prev ^ 1) * c.NBS + blockIdx.x) * DP + e] = t;
+    }
   } else {
+    double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < COV_CPG; ++u) {
       const double cs = gsum_l<LPC>(cf[u] * sv[u]), cg = gsum_l<LPC>(cf[u] * gv[u]);
       acc += yy[u] - 2.0 * cs + cg;          // identical on every lane of the group
     }
-  }
-  if (lp < PMAX) sAcc[grp][lp] = acc;
-  __syncthreads();
-  if (a_next >= 0) {
-    if (tid < P) {
-      double s = 0.0;
-#pragma unroll
-      for (int gq = 0; gq < GPB; ++gq) s += sAcc[gq][tid];
-      c.step_part[((size_t)(par_prev ^ 1) * c.NBS + blockIdx.x) * P + tid] = s;
-    }
-  } else {
+    __syncthreads();
+    if (lp == 0) sAcc[grp][0][0] = acc;
+    __syncthreads();
     if (tid == 0) {
-      double s = 0.0;
+      double t = 0.0;
 #pragma unroll
-      for (int gq = 0; gq < GPB; ++gq) s += sAcc[gq][0];
-      c.rss_part[blockIdx.x] = s;
+      for (int gq = 0; gq < GPB; ++gq) t += sAcc[gq][0][0];
+      c.rss_part[blockIdx.x] = t;
     }
     // rss_part is read over nblk_curve entries by the log-likelihood / sigma^2 jobs
     if (blockIdx.x == 0)
@@ -313,16 +470,21 @@ __global__ __launch_bounds__(256) void k_cov_step(Ctx c, int a_prev, int a_next,
 }
 
 // ---- tau_eta, delta_xi, A_xi, gamma_xi and the chain slots of the covariate blocks: one workgroup ----
+// (the gamma variates arrive as standard draws from k_cov_prep; what is left is sums, products and the A_xi step)
 __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
-  __shared__ double red[256];
-  __shared__ double Sk[KMAX * 16];
+  extern __shared__ __attribute__((aligned(16))) double hsm[];
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, D = d.D, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
   const uint32_t mask = c.mask, slot = dyn->slot;
   const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
+  const int n_tau = K * D, n_del = K * M * D;
+  double* sE = hsm;                 // K*D x P    eta rows
+  double* sPm = sE + K * D * P;     // P x P      penalty
+  double* sSk = sPm + P * P;        // D x K*M
+  double* sDX = sSk + D * K * M;    // (k*D + dd)*M + m    delta_xi
   if (tid == 0) dyn->pend_dir = -1;
-  // ---- commit this iteration's eta / Xi draws (k_cov_step leaves them in thetaN) ----
+  // ---- commit this iteration's eta / Xi draws (k_cov_group leaves them in thetaN) ----
   for (int e = tid; e < c.A2 * P; e += 256) {
     const int a2 = e / P, p = e - a2 * P;
     const Dir2 a = dir2_of(d, a2);
@@ -330,68 +492,82 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
     const size_t ax = (size_t)((a.j * (M + 1) + a.mt) * D + a.dd);
     c.thetaX[ax * P + p] = c.thetaN[ax * P + p];
   }
+  for (int e = tid; e < K * M * D; e += 256) {
+    const int m = e % M, dd = (e / M) % D, k = e / (M * D);
+    sDX[e] = c.delta_xi[k + (size_t)K * (m + (size_t)M * dd)];
+  }
+  if (!d.mv)
+    for (int e = tid; e < P * P; e += 256) sPm[e] = c.Pmat[e];
   __syncthreads();
-  // ---- tau_eta (UpdateTau.h:75-95; MV :106-124) ----
+  // ---- tau_eta (UpdateTau.h:75-95; MV :106-124): the K*D quadratic forms side by side, 32 lanes each ----
   if (mask & U_TAU_ETA) {
-    for (int j = 0; j < K; ++j)
-      for (int i = 0; i < D; ++i) {
-        const double* e = c.thetaX + (size_t)((j * (M + 1)) * D + i) * P;
-        double acc = 0.0;
-        if (tid < P) {
-          double s = 0.0;
-          if (d.mv) s = e[tid];
-          else
-            for (int q = 0; q < P; ++q) s += c.Pmat[tid + (size_t)P * q] * e[q];
-          acc = e[tid] * s;
-        }
-        const double qf = block_sum256(acc, red);
-        if (tid == 0) {
-          const double aa = c.h.alpha_eta + (P / 2);                         // integer division, UpdateTau.h:87
-          const double bb = c.h.beta_eta + (0.5 * qf);
-          const double g = rgamma(key, UPD_TAU_ETA, (uint32_t)(j * D + i), aa, 1.0 / bb);
-          c.tau_eta[j + (size_t)K * i] = d.mv ? (1.0 / g) : g;
-        }
-      }
+    for (int e = tid; e < K * D * P; e += 256) {
+      const int p = e % P, pr = e / P, j = pr / D, i = pr - j * D;
+      sE[e] = c.thetaX[(size_t)((j * (M + 1)) * D + i) * P + p];
+    }
     __syncthreads();
+    const int grp = tid >> 5, l = tid & 31;
+    for (int pr = grp; pr < K * D; pr += 8) {
+      const double* ev = sE + pr * P;
+      double acc = 0.0;
+      for (int p = l; p < P; p += 32) {
+        double sv = 0.0;
+        if (d.mv) sv = ev[p];
+        else
+          for (int q = 0; q < P; ++q) sv += sPm[p + P * q] * ev[q];
+        acc += ev[p] * sv;
+      }
+      const double qf = gsum_l<32>(acc);
+      if (l == 0) {
+        const int j = pr / D, i = pr - j * D;
+        const double bb = c.h.beta_eta + (0.5 * qf);
+        const double gv = c.gstd2[j * D + i] * (1.0 / bb);
+        c.tau_eta[j + (size_t)K * i] = d.mv ? (1.0 / gv) : gv;
+      }
+    }
   }
   const bool xi_on = c.covariance_adj && d.MD > 1;
-  // ---- delta_xi (UpdateDelta.h:76-124), order (d, k, i) ----
+  // ---- delta_xi (UpdateDelta.h:76-124), order (d, k, i): the (d, k) cells are independent of each other ----
   if ((mask & U_DELTA_XI) && xi_on) {
-    for (int dd = 0; dd < D; ++dd) {
-      if (tid < K * M) {
-        const int k = tid / M, m = tid - k * M;
-        const double* xk = c.thetaX + (size_t)((k * (M + 1) + m + 1) * D + dd) * P;
-        const double* gx = c.gamma_xi + (size_t)k * P * D * M;
-        double acc = 0.0;
-        for (int p = 0; p < P; ++p) acc += gx[p + (size_t)P * (dd + (size_t)D * m)] * (xk[p] * xk[p]);
-        Sk[tid] = acc;
+    for (int e = tid; e < D * K * M; e += 256) {
+      const int dd = e / (K * M), km = e - dd * K * M, k = km / M, m = km - k * M;
+      const double* xk = c.thetaX + (size_t)((k * (M + 1) + m + 1) * D + dd) * P;
+      const double* gx = c.gamma_xi + (size_t)k * P * D * M + (size_t)P * (dd + (size_t)D * m);
+      double acc = 0.0;
+      for (int p0 = 0; p0 < P; p0 += 16) {
+        double gq[16], xq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int p = min(p0 + t, P - 1); gq[t] = gx[p]; xq[t] = xk[p]; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) if (p0 + t < P) acc += gq[t] * (xq[t] * xq[t]);
       }
-      __syncthreads();
-      if (tid < K) {
-        const int k = tid;
-        for (int i = 0; i < M; ++i) {
-          double param1, param2 = 1.0;
-          auto DX = [&](int nn) { return c.delta_xi[k + (size_t)K * (nn + (size_t)M * dd)]; };
-          if (i == 0) {
-            param1 = c.A_xi[k + (size_t)K * (0 + 2 * (size_t)dd)] + ((P * M) * 0.5);
-            param2 += 0.5 * Sk[k * M + 0];
-            double tt = 1.0;
-            for (int m = 1; m < M; ++m) { tt *= DX(m); param2 += 0.5 * tt * Sk[k * M + m]; }
-          } else {
-            param1 = c.A_xi[k + (size_t)K * (1 + 2 * (size_t)dd)] + ((P * (M - i)) * 0.5);
-            for (int m = i; m < M; ++m) {
-              double tt = 1.0;
-              for (int nn = 0; nn <= m; ++nn)
-                if (nn != i) tt *= DX(nn);
-              param2 += 0.5 * tt * Sk[k * M + m];
-            }
-          }
-          c.delta_xi[k + (size_t)K * (i + (size_t)M * dd)] =
-              rgamma(key, UPD_DELTA_XI, (uint32_t)((dd * K + k) * M + i), param1, 1.0 / param2);
-        }
-      }
-      __syncthreads();
+      sSk[e] = acc;
     }
+    __syncthreads();
+    if (tid < K * D) {
+      const int dd = tid / K, k = tid - dd * K;
+      const double* Sk = sSk + dd * K * M;
+      double* DX = sDX + (k * D + dd) * M;
+      for (int i = 0; i < M; ++i) {
+        double param2 = 1.0;
+        if (i == 0) {
+          param2 += 0.5 * Sk[k * M + 0];
+          double tt = 1.0;
+          for (int m = 1; m < M; ++m) { tt *= DX[m]; param2 += 0.5 * tt * Sk[k * M + m]; }
+        } else {
+          for (int m = i; m < M; ++m) {
+            double tt = 1.0;
+            for (int nn = 0; nn <= m; ++nn)
+              if (nn != i) tt *= DX[nn];
+            param2 += 0.5 * tt * Sk[k * M + m];
+          }
+        }
+        const double nv = c.gstd2[n_tau + (dd * K + k) * M + i] * (1.0 / param2);
+        DX[i] = nv;
+        c.delta_xi[k + (size_t)K * (i + (size_t)M * dd)] = nv;
+      }
+    }
+    __syncthreads();
   }
   // ---- A_xi (UpdateA.h:137-205), cells (j, i, d) ----
   if ((mask & U_A_XI) && xi_on) {
@@ -403,7 +579,7 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
       const double cur = *cell;
       const uint32_t idx = (uint32_t)((j * 2 + i) * D + dd);
       const double na = rtruncnorm_lo(key, UPD_AXI_PROP, idx, cur, sd, 0.0);
-      const double* drow = c.delta_xi + j + (size_t)K * M * dd;     // delta_xi.slice(d).row(j), stride K
+      const double* drow = sDX + (j * D + dd) * M;     // delta_xi.slice(d).row(j)
       double l0, l1;
       if (first) {
         l0 = -logGamma_ref(cur) + (cur - 1) * log(drow[0]) + (c.h.alpha1l - 1) * log(cur) - (cur * c.h.beta1l);
@@ -413,7 +589,7 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
         l0 = -x * logGamma_ref(cur) + (c.h.alpha2l - 1) * log(cur) - (cur * c.h.beta2l);
         l1 = -x * logGamma_ref(na) + (c.h.alpha2l - 1) * log(na) - (na * c.h.beta2l);
         for (int q = 1; q < M; ++q) {
-          const double lg = log(drow[(size_t)q * K]);
+          const double lg = log(drow[q]);
           l0 = l0 + (cur - 1) * lg;
           l1 = l1 + (na - 1) * lg;
         }
@@ -422,7 +598,6 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
       const double u = runif(key, UPD_AXI_ACC, idx);
       if (log(u) < acc) *cell = na;
     }
-    __syncthreads();
   }
   // ---- gamma_xi (UpdateGamma.h:48-72), order (k, i = d, l = p, j = m) ----
   if ((mask & U_GAMMA_XI) && xi_on) {
@@ -430,10 +605,10 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
     for (int e = tid; e < tot; e += 256) {
       const int jm = e % M, r1 = e / M, l = r1 % P, r2 = r1 / P, i = r2 % D, k = r2 / D;
       double ph = 1.0;
-      for (int j2 = 0; j2 <= jm; ++j2) ph *= c.delta_xi[k + (size_t)K * (j2 + (size_t)M * i)];
+      for (int j2 = 0; j2 <= jm; ++j2) ph *= sDX[(k * D + i) * M + j2];
       const double x = c.thetaX[(size_t)((k * (M + 1) + jm + 1) * D + i) * P + l];
       c.gamma_xi[(size_t)k * P * D * M + l + (size_t)P * (i + (size_t)D * jm)] =
-          rgamma(key, UPD_GAMMA_XI, (uint32_t)e, (c.h.nu_1 + 1) / 2, 2 / (c.h.nu_1 + ph * (x * x)));
+          c.gstd2[n_tau + n_del + e] * (2 / (c.h.nu_1 + ph * (x * x)));
     }
   }
   __syncthreads();
@@ -459,52 +634,72 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
 
 // ---- host launchers -------------------------------------------------------------------------
 template <int BW>
-static void launch_step_bw(const Ctx& c, int a_prev, int a_next, int par_prev, hipStream_t st) {
-  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_step<BW, 32>), dim3(c.NBS), dim3(256), 0, st, c, a_prev, a_next, par_prev);
-  else hipLaunchKernelGGL((k_cov_step<BW, 64>), dim3(c.NBS), dim3(256), 0, st, c, a_prev, a_next, par_prev);
+static void launch_group_bw(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
+  const size_t lds = (size_t)c.NPG * c.d.LG * sizeof(double);
+  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS), dim3(256), lds, st, c, g_prev, g_next, par_prev);
+  else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS), dim3(256), lds, st, c, g_prev, g_next, par_prev);
 }
 
-static void launch_step(const Ctx& c, int a_prev, int a_next, int par_prev, hipStream_t st) {
+static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
   switch (c.d.BW) {
-    case 0: launch_step_bw<0>(c, a_prev, a_next, par_prev, st); break;
-    case 1: launch_step_bw<1>(c, a_prev, a_next, par_prev, st); break;
-    case 2: launch_step_bw<2>(c, a_prev, a_next, par_prev, st); break;
-    case 3: launch_step_bw<3>(c, a_prev, a_next, par_prev, st); break;
-    case 4: launch_step_bw<4>(c, a_prev, a_next, par_prev, st); break;
-    default: launch_step_bw<5>(c, a_prev, a_next, par_prev, st); break;
+    case 0: launch_group_bw<0>(c, g_prev, g_next, par_prev, st); break;
+    case 1: launch_group_bw<1>(c, g_prev, g_next, par_prev, st); break;
+    case 2: launch_group_bw<2>(c, g_prev, g_next, par_prev, st); break;
+    case 3: launch_group_bw<3>(c, g_prev, g_next, par_prev, st); break;
+    case 4: launch_group_bw<4>(c, g_prev, g_next, par_prev, st); break;
+    default: launch_group_bw<5>(c, g_prev, g_next, par_prev, st); break;
   }
 }
 
-// curve blocks of k_cov_step for nblk_curve blocks of the per-curve kernels
+// curve blocks of k_cov_group for nblk_curve blocks of the per-curve kernels
 int cov_step_blocks(int nblk_curve) { return (nblk_curve + COV_CPG - 1) / COV_CPG; }
+int cov_w2_chunks(int n) { return (n + W2_CH - 1) / W2_CH; }
 
 // the eta / Xi part of one iteration (after k_curve_chi has stored c_i, g_i)
 void launch_cov_block(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   const bool do_eta = (c.mask & U_ETA) != 0;
   const bool do_xi = (c.mask & U_XI) != 0 && c.covariance_adj && d.MD > 1;
-  int a_prev = -1, par = 0;
+  int g_prev = -1, par = 0;
+  {
+    const size_t tot = (size_t)d.n * c.A2;
+    const int n_wblocks = (do_eta || do_xi) ? (int)((tot + 255) / 256) : 0;
+    const int n_draws = d.K * d.D + d.K * d.M * d.D + d.K * d.D * d.P * d.M;
+    hipLaunchKernelGGL(k_cov_prep, dim3(n_wblocks + (n_draws + 255) / 256), dim3(256), 0, st, c, n_wblocks);
+  }
   if (do_eta || do_xi) {
-    hipLaunchKernelGGL(k_cov_w2, dim3(c.A2, c.NB2), dim3(256), 0, st, c);
+    const size_t lds_w2 = ((size_t)W2_CH * DMAX_COV + (size_t)W2_CH * NPG_MAX + (size_t)NPG_MAX * 128) * sizeof(double);
+    hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2), dim3(256), lds_w2, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
     const size_t lds = (2 * (size_t)PP * PP + PP + d.LG) * sizeof(double);
-    if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.A2), dim3(256), lds, st, c);
-    else hipLaunchKernelGGL(k_cov_factor<64>, dim3(c.A2), dim3(256), lds, st, c);
-    const int n_eta = d.K * d.D;
-    for (int a2 = 0; a2 < c.A2; ++a2) {
-      if (a2 < n_eta ? !do_eta : !do_xi) continue;
-      launch_step(c, a_prev, a2, par, st);      // partial sums of a2 go to parity par ^ 1
-      a_prev = a2;
+    if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.NPAIR), dim3(256), lds, st, c);
+    else hipLaunchKernelGGL(k_cov_factor<64>, dim3(c.NPAIR), dim3(256), lds, st, c);
+    const int n_eta_groups = d.K, n_groups = c.A2 / d.D;
+    for (int g = 0; g < n_groups; ++g) {
+      if (g < n_eta_groups ? !do_eta : !do_xi) continue;
+      launch_group(c, g_prev, g, par, st);      // partial sums of g go to parity par ^ 1
+      g_prev = g;
       par ^= 1;
     }
   }
-  launch_step(c, a_prev, -1, par, st);      // the last draw, and the residual sums for the log-likelihood
-  hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(256), 0, st, c);
+  launch_group(c, g_prev, -1, par, st);      // the last group's draws, and the residual sums for the log-likelihood
+  const size_t lds_h = ((size_t)d.K * d.D * d.P + (size_t)d.P * d.P + 2 * (size_t)d.D * d.K * d.M) * sizeof(double);
+  hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(256), lds_h, st, c);
+}
+
+template <int BW>
+static void prepare_group_bw() {
+  set_max_lds((const void*)k_cov_group<BW, 32>);
+  set_max_lds((const void*)k_cov_group<BW, 64>);
 }
 
 void prepare_cov_kernels() {
+  set_max_lds((const void*)k_cov_w2);
+  set_max_lds((const void*)k_cov_hyper);
   set_max_lds((const void*)k_cov_factor<32>);
   set_max_lds((const void*)k_cov_factor<64>);
+  prepare_group_bw<0>(); prepare_group_bw<1>(); prepare_group_bw<2>();
+  prepare_group_bw<3>(); prepare_group_bw<4>(); prepare_group_bw<5>();
 }
 
 }  // namespace bfmmm

@@ -129,11 +129,13 @@ struct Ctx {
   double* yyp_part;             // nblk_curve  partial sums of yy_i - 2 o_i's_i + o_i'G_i o_i
   double* cfull;                // n x P   c_i (full fitted coefficient), maintained during the eta / Xi steps
   double* gfull;                // n x P   G_i c_i
-  double* w2_part;              // A2 x NB2 x LG   partial sums of w^2 G_i
-  double* H2aa;                 // A2 x LG         sum_i w^2 G_i
+  double* w2_part;              // NPAIR x NB2 x LG   partial sums of w_a w_b G_i over the in-group direction pairs
+  double* H2aa;                 // NPAIR x LG         sum_i w_a w_b G_i (band-packed); pair (u <= v) of group g at g*NPG + v(v+1)/2 + u
+  double* gstd2;                // K*D + K*M*D + K*D*P*M  standard gamma variates of tau_eta, delta_xi, gamma_xi (k_cov_prep)
+  double* Wdir;                 // n x A2             w_{a,i} = Z_ij chit_{i,mt} X_id of this iteration's eta / Xi block
   double* C2;                   // A2 x P x P
   double* Lz2;                  // A2 x P
-  double* step_part;            // 2 x NBS x P     partial sums of w (s_i - g_i) of the current step (two parities)
+  double* step_part;            // 2 x NBS x D x P partial sums of w (s_i - g_i) of the current group of directions (two parities)
   double* thetaN;               // as thetaX: the values drawn in this iteration's eta / Xi steps (committed by k_cov_hyper)
   double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
   int defer_loglik;             // the iteration has no k_loglik: bookkeeping in job_hyper, reduction in the next k_pair_gram
@@ -141,6 +143,7 @@ struct Ctx {
   int covariance_adj;           // Xi block on (BFMMM.h:4602 vs :4067)
   int A2;                       // eta / xi directions: K*D (+ K*M*D)
   int NB2, NBS;
+  int NPG, NPAIR;               // in-group direction pairs: D(D+1)/2 per group of D consecutive directions, (A2/D)*NPG in all
   double *c_eta, *c_xi, *c_tau_eta, *c_gamma_xi, *c_delta_xi, *c_A_xi;
   double YY;                    // sum_i yy_i
   // chain storage (slot-major, each slot laid out exactly as the reference returns it)
