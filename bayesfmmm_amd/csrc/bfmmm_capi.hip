@@ -327,8 +327,8 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
       dalloc(h, &c.yyp_part, (size_t)c.nblk_curve) || dalloc(h, &c.cfull, n * P) || dalloc(h, &c.gfull, n * P) ||
       dalloc(h, &c.w2_part, (size_t)c.NPAIR * c.NB2 * d.LG) || dalloc(h, &c.H2aa, (size_t)c.NPAIR * d.LG) ||
       dalloc(h, &c.Wdir, n * (size_t)c.A2) || dalloc(h, &c.gstd2, K * D + K * M * D + K * D * P * M) ||
-      dalloc(h, &c.C2, (size_t)c.A2 * P * P) || dalloc(h, &c.Lz2, (size_t)c.A2 * P) ||
-      dalloc(h, &c.step_part, 2 * (size_t)c.NBS * D * P) || dalloc(h, &c.thetaN, K * (M + 1) * D * P) || dalloc(h, &c.delta_cur, P + 2) ||
+      dalloc(h, &c.C2, (size_t)c.A2 * P * P + 2) || dalloc(h, &c.Lz2, (size_t)c.A2 * P) ||
+      dalloc(h, &c.step_part, 2 * (size_t)c.NBS * (D * P + 1)) || dalloc(h, &c.thetaN, K * (M + 1) * D * P) || dalloc(h, &c.delta_cur, P + 2) ||
       dalloc(h, &c.c_eta, T * P * D * K) || dalloc(h, &c.c_xi, T * K * P * D * M) || dalloc(h, &c.c_tau_eta, T * K * D) ||
       dalloc(h, &c.c_gamma_xi, T * K * P * D * M) || dalloc(h, &c.c_delta_xi, T * K * M * D) || dalloc(h, &c.c_A_xi, T * K * 2 * D))
     return 1;

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
   if (!dir2_updated(c, dir2_of(d, g * D))) return;
   const int i0 = cb * W2_CH, nc = min(d.n - i0, W2_CH);
   double* sW = sm;                       // W2_CH x D
-  double* sPW = sW + W2_CH * DMAX_COV;   // W2_CH x NPG
-  double* sRed = sPW + W2_CH * NPG_MAX;  // NPG x LGR (second half's sums)
+  double* sPW = sW + W2_CH * D;          // W2_CH x NPG
+  double* sRed = sPW + W2_CH * NPG;      // NPG x 128 (second half's sums)
   for (int e = tid; e < nc * D; e += 256) {
     const int cl = e / D, s = e - cl * D;
     sW[cl * D + s] = c.Wdir[(size_t)(i0 + cl) * c.A2 + g * D + s];
@@ -251,23 +251,40 @@ __device__ inline double gsum_l(double v) {
   return v;
 }
 
-constexpr int COV_CPG = 4;     // curves per lane group and launch
+// sum over the LR (8 or 4) adjacent lanes of a row, on the DPP path (an LDS-pipe shuffle costs ~100 clk on the chain)
+template <int LR>
+__device__ inline double rsum_dpp(double v) {
+  v = dpp_add<0xB1>(v);                   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                   // quad_perm [2,3,0,1]
+  if (LR == 8) v = dpp_add<0x141>(v);     // row_half_mirror
+  return v;
+}
+
+constexpr int COV_CPG = 2;     // curves per lane group of k_cov_group
+constexpr int COV_CPB32 = 32;  // curves per workgroup of k_cov_group (P <= 32: 32 lane groups of 32; P > 32: 16 groups of 64)
 constexpr int DMAX = DMAX_COV;
 constexpr int PADW = PMAX + 2 * BWMAX + 2;
+constexpr int GT = 1024;       // threads of k_cov_group
+
+// 1024 threads = four waves per SIMD: every phase of this kernel is bound by instruction issue and latency, not by
+// bytes, and a wave alone on a SIMD issues only every ~5 clk.  One curve per lane group; the D sequential draws are
+// done by the first 256 threads.
+typedef double dbl2 __attribute__((ext_vector_type(2)));     // one 16-byte memory instruction
 
 template <int BW, int LPC>
-__global__ __launch_bounds__(256) void k_cov_group(Ctx c, int g_prev, int g_next, int par_prev) {
-  constexpr int GPB = 256 / LPC;          // lane groups per workgroup
+__global__ __launch_bounds__(GT) void k_cov_group(Ctx c, int g_prev, int g_next, int par_prev) {
+  constexpr int GPB = GT / LPC;           // lane groups
   constexpr int CPB = GPB * COV_CPG;      // curves per workgroup
-  constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR)
+  constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR, tid < 256)
   constexpr int QPL = LPC / LR;           // columns per lane
+  constexpr int NSEG = GT / 32;           // segments of the partial-sum reduction
   extern __shared__ __attribute__((aligned(16))) double sHp[];     // NPG x LG pair blocks of g_prev
   __shared__ double sDl[DMAX][PADW];
   __shared__ double sTh[DMAX][PADW];
   __shared__ double sR[DMAX * PMAX];
-  __shared__ double sLz[DMAX][PMAX];
+  __shared__ double sLz[DMAX * PMAX];
   __shared__ double sRhs[PMAX];
-  __shared__ double sAcc[GPB][DMAX][LPC];
+  __shared__ __attribute__((aligned(16))) double sAcc[GPB * DMAX * LPC];     // [grp][s][lp]; also the 32 x 160 scratch of the partial-sum reduction
   __shared__ double sWp[CPB][DMAX], sWn[CPB][DMAX];
   const Dims& d = c.d;
   const int n = d.n, P = d.P, D = d.D, DP = D * P, tid = threadIdx.x;
@@ -275,134 +292,222 @@ __global__ __launch_bounds__(256) void k_cov_group(Ctx c, int g_prev, int g_next
   const Dyn* dyn = c.dyn;
   const bool act = lp < P;
   const int pc = min(lp, P - 1);
-  const int row = tid / LR, rl = tid % LR;
+  const bool chain = tid < 256;                      // wave-uniform
+  const int row = (tid & 255) / LR, rl = tid % LR;
   const int cbase = blockIdx.x * CPB;
+#ifdef COV_STAMPS
+#define CST(k) do { if (blockIdx.x == 1 && tid == 0 && g_prev == 5) c.dyn->stamps[40 + (k)] = clock64(); } while (0)
+#else
+#define CST(k) do { } while (0)
+#endif
+  CST(0);
 
-  // ---- requests that do not depend on the previous group ----
+  // ---- requests that do not depend on the previous group: into registers first, so that everything this launch
+  //      reads shares one memory round trip (addresses are clamped instead of predicated: no branches) ----
+  // C_s: P <= 32: all D matrices are staged in LDS (after the pair blocks); P > 32: rows in registers, one direction ahead
+  constexpr bool ALLC = (LPC == 32);
+  constexpr int NCV = ALLC ? (DMAX * 32 * 32) / GT : 1;
+  constexpr int NHR = 2;
   double cr[QPL];
+  dbl2 cv2[(NCV + 1) / 2];
+  double hpv[NHR], thv = 0.0, lzv = 0.0, wpv = 0.0, wnv = 0.0;
+  const int totH = c.NPG * d.LG, totC = D * P * P;
+  double* sC = sHp + ((totH + 1) & ~1);
+  const int a0 = max(g_prev, 0) * D;
+  const bool c_al = ((((size_t)a0 * P * P) & 1) == 0);       // C_a0 starts on a 16-byte boundary (uniform)
   if (g_prev >= 0) {
-    const int a0 = g_prev * D;
-    const double* Cg = c.C2 + (size_t)a0 * P * P;
+    if (ALLC) {
+      const double* Cg = c.C2 + (size_t)a0 * P * P;
+      if (c_al) {       // 16-byte loads: the kernel is bound by the number of memory instructions per CU
+        const dbl2* Cg2 = (const dbl2*)Cg;
 #pragma unroll
-    for (int u = 0; u < QPL; ++u) {
-      const int q = rl + u * LR;
-      cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
+        for (int t = 0; t < NCV / 2; ++t) cv2[t] = Cg2[min(tid + GT * t, (totC + 1) / 2 - 1)];
+      }
+    } else if (chain) {
+      const double* Cg = c.C2 + (size_t)a0 * P * P;
+#pragma unroll
+      for (int u = 0; u < QPL; ++u) {
+        const int q = rl + u * LR;
+        const double v = Cg[min(row, P - 1) + P * min(q, P - 1)];
+        cr[u] = (row < P && q < P) ? v : 0.0;
+      }
     }
-    const double* Hg = c.H2aa + (size_t)g_prev * c.NPG * d.LG;
-    for (int e = tid; e < c.NPG * d.LG; e += 256) sHp[e] = Hg[e];
-    for (int e = tid; e < D * PADW; e += 256) {
+    const double* Hg = c.H2aa + (size_t)g_prev * totH;
+#pragma unroll
+    for (int t = 0; t < NHR; ++t) hpv[t] = Hg[min(tid + GT * t, totH - 1)];
+    {
+      const int e = min(tid, D * PADW - 1);
       const int s = e / PADW, p = e - s * PADW - BW;
       const Dir2 as = dir2_of(d, a0 + s);
       const int ax = (as.j * (d.M + 1) + as.mt) * D + as.dd;
-      sTh[s][e - s * PADW] = (p >= 0 && p < P) ? c.thetaX[(size_t)ax * P + p] : 0.0;
-      sDl[s][e - s * PADW] = 0.0;
+      const double v = c.thetaX[(size_t)ax * P + min(max(p, 0), P - 1)];
+      thv = (p >= 0 && p < P) ? v : 0.0;
     }
-    for (int e = tid; e < DP; e += 256) sLz[e / P][e % P] = c.Lz2[(size_t)a0 * P + e];
+    lzv = c.Lz2[(size_t)a0 * P + min(tid, DP - 1)];
   }
-  for (int e = tid; e < CPB * D; e += 256) {
+  {
+    const int e = min(tid, CPB * D - 1);
     const int cl = e / D, s = e - cl * D;
-    const int i = cbase + cl;
-    sWp[cl][s] = (i < n && g_prev >= 0) ? c.Wdir[(size_t)i * c.A2 + g_prev * D + s] : 0.0;
-    sWn[cl][s] = (i < n && g_next >= 0) ? c.Wdir[(size_t)i * c.A2 + g_next * D + s] : 0.0;
+    const int i = min(cbase + cl, n - 1);
+    const double vp = c.Wdir[(size_t)i * c.A2 + a0 + s], vn = c.Wdir[(size_t)i * c.A2 + max(g_next, 0) * D + s];
+    wpv = (cbase + cl < n && g_prev >= 0) ? vp : 0.0;
+    wnv = (cbase + cl < n && g_next >= 0) ? vn : 0.0;
   }
-  double g[COV_CPG][BW + 1], gl[COV_CPG][BW + 1], sv[COV_CPG], cf[COV_CPG], gv[COV_CPG], yy[COV_CPG];
+  auto stage_to_lds = [&]() {
+    if (g_prev >= 0) {
 #pragma unroll
-  for (int u = 0; u < COV_CPG; ++u) {
-    const int i = cbase + grp * COV_CPG + u;
-    const bool valid = i < n;
-    const int ic = valid ? i : 0;
-    const double* rec = c.rec + (size_t)ic * d.LREC;
+      for (int t = 0; t < NHR; ++t) { const int e = tid + GT * t; if (e < totH) sHp[e] = hpv[t]; }
+      const double* Hg = c.H2aa + (size_t)g_prev * totH;
+      for (int e = tid + GT * NHR; e < totH; e += GT) sHp[e] = Hg[e];
+      if (ALLC) {
+        if (c_al) {
 #pragma unroll
-    for (int dd = 0; dd <= BW; ++dd) {
-      const double vg = rec[dd * P + pc], vl = rec[dd * P + max(pc - dd, 0)];
-      g[u][dd] = (act && valid && lp + dd < P) ? vg : 0.0;
-      gl[u][dd] = (act && valid && dd > 0 && lp - dd >= 0) ? vl : 0.0;
+          for (int t = 0; t < NCV / 2; ++t) { const int e = tid + GT * t; if (2 * e < totC) ((dbl2*)sC)[e] = cv2[t]; }
+        } else {
+          const double* Cg = c.C2 + (size_t)a0 * P * P;
+          for (int e = tid; e < totC; e += GT) sC[e] = Cg[e];
+        }
+      }
+      if (tid < D * PADW) { (&sTh[0][0])[tid] = thv; (&sDl[0][0])[tid] = 0.0; }
+      if (tid < DP) sLz[tid] = lzv;
     }
-    const double s0 = rec[d.LG + pc], c0 = c.cfull[(size_t)ic * P + pc], g0 = c.gfull[(size_t)ic * P + pc];
-    sv[u] = (act && valid) ? s0 : 0.0;
-    cf[u] = (act && valid) ? c0 : 0.0;
-    gv[u] = (act && valid) ? g0 : 0.0;
-    yy[u] = valid ? rec[d.LG + P] : 0.0;
-  }
+    if (tid < CPB * D) { (&sWp[0][0])[(tid / D) * DMAX + tid % D] = wpv; (&sWn[0][0])[(tid / D) * DMAX + tid % D] = wnv; }
+  };
+  // this lane group's curve (requested after the partial sums: it is not needed before the draws are done, and the
+  // registers are scarce while the partial sums are in flight)
+  double g[COV_CPG][BW + 1], gl[COV_CPG][BW + 1], sv[COV_CPG], cf[COV_CPG], gv[COV_CPG], yy[COV_CPG];
+  auto load_curve = [&]() {
+#pragma unroll
+    for (int u = 0; u < COV_CPG; ++u) {
+      const int icv = cbase + grp * COV_CPG + u;
+      const bool valid = icv < n;
+      const int ic = valid ? icv : 0;
+      const double* rec = c.rec + (size_t)ic * d.LREC;
+#pragma unroll
+      for (int dd = 0; dd <= BW; ++dd) {
+        const double vg = rec[dd * P + pc];
+        g[u][dd] = (act && valid && lp + dd < P) ? vg : 0.0;
+      }
+#pragma unroll
+      for (int dd = 0; dd <= BW; ++dd) {       // G(p, p-dd) = G(p-dd, p): the band entry lane p-dd has just loaded
+        const double vl = (dd > 0) ? __shfl_up(g[u][dd], dd, LPC) : 0.0;
+        gl[u][dd] = (dd > 0 && lp - dd >= 0) ? vl : 0.0;
+      }
+      const double s0 = rec[d.LG + pc], c0 = c.cfull[(size_t)ic * P + pc], g0 = c.gfull[(size_t)ic * P + pc];
+      const double y0 = (g_next < 0) ? rec[d.LG + P] : 0.0;      // (only the final pass needs yy_i)
+      sv[u] = (act && valid) ? s0 : 0.0;
+      cf[u] = (act && valid) ? c0 : 0.0;
+      gv[u] = (act && valid) ? g0 : 0.0;
+      yy[u] = valid ? y0 : 0.0;
+    }
+  };
 
+  if (g_prev < 0) { stage_to_lds(); load_curve(); }
   if (g_prev >= 0) {
     // ---- r_s of the D directions: fixed-order sum of the previous launch's partial sums.  They were written by
-    //      other XCDs (every load is a trip to memory), so they go out in batches of 80 ----
-    const double* sp = c.step_part + (size_t)par_prev * c.NBS * DP;
+    //      other XCDs (every load is a trip to memory), so a thread's 20 go out together ----
+    CST(1);
+    const int DPS = (DP + 1) & ~1;                                   // row stride of step_part (even: 16-byte loads)
+    const dbl2* sp2 = (const dbl2*)(c.step_part + (size_t)par_prev * c.NBS * DPS);
     const int seg = tid >> 5, l32 = tid & 31;
-    for (int v0 = 0; v0 < DP; v0 += 160) {
-      double accv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-      for (int b0 = seg; b0 < c.NBS; b0 += 8 * 16) {
-        double t[5][16];
+    bool staged = false;
+    for (int v0 = 0; v0 < DPS; v0 += 192) {         // 96 pairs of values per round
+      dbl2 accv[3];
 #pragma unroll
-        for (int w = 0; w < 5; ++w)
+      for (int w = 0; w < 3; ++w) accv[w] = dbl2{0.0, 0.0};
+      for (int b0 = seg; b0 < c.NBS; b0 += NSEG * 4) {
+        dbl2 t[3][4];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int v = v0 + w * 32 + l32, b = b0 + u * 8;
-            t[w][u] = (v < DP && b < c.NBS) ? sp[(size_t)b * DP + v] : 0.0;
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int v2 = v0 / 2 + w * 32 + l32, b = b0 + u * NSEG;
+            const dbl2 x = sp2[(size_t)min(b, c.NBS - 1) * (DPS / 2) + min(v2, DPS / 2 - 1)];
+            const bool on = (2 * v2 < DPS && b < c.NBS);
+            t[w][u] = dbl2{on ? x.x : 0.0, on ? x.y : 0.0};
           }
+        if (!staged) { stage_to_lds(); staged = true; }
 #pragma unroll
-        for (int w = 0; w < 5; ++w)
+        for (int w = 0; w < 3; ++w)
 #pragma unroll
-          for (int u = 0; u < 16; ++u) accv[w] += t[w][u];
+          for (int u = 0; u < 4; ++u) { accv[w].x += t[w][u].x; accv[w].y += t[w][u].y; }
       }
-      // the 8 segments of a value meet in LDS (sAcc is free until the accumulation phase)
-      double* red = &sAcc[0][0][0];          // >= 8 x 160 doubles
+      if (!staged) { stage_to_lds(); staged = true; }       // (workgroups with fewer partial blocks than segments)
+      // the segments of a value meet in LDS (sAcc is free until the accumulation phase)
       __syncthreads();
 #pragma unroll
-      for (int w = 0; w < 5; ++w) red[seg * 160 + w * 32 + l32] = accv[w];
+      for (int w = 0; w < 3; ++w) ((dbl2*)sAcc)[seg * 96 + w * 32 + l32] = accv[w];
       __syncthreads();
-      if (tid < 160 && v0 + tid < DP) {
+      if (tid < 192 && v0 + tid < DP) {
         double s = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += red[q * 160 + tid];
+        for (int q = 0; q < NSEG; ++q) s += sAcc[q * 192 + tid];
         sR[v0 + tid] = s;
       }
     }
+    load_curve();
     __syncthreads();
-    // ---- the D sequential draws ----
+    CST(2);
+    // ---- the D sequential draws (first 256 threads; the others wait at the barriers) ----
     const double f = dyn->beta / dyn->sigma2;
-    for (int s = 0; s < D; ++s) {
-      const int a2 = g_prev * D + s;
-      // rhs_s: lanes of a row share the pairs (u, s), u <= s
-      double part = 0.0;
-      if (row < P) {
-        for (int u = rl; u <= s; u += LR) {
-          const double* Hb = sHp + (size_t)(s * (s + 1) / 2 + u) * d.LG;
-          const double* vec = (u < s) ? &sDl[u][BW + row] : &sTh[s][BW + row];
-          double hv = Hb[row] * vec[0];
 #pragma unroll
-          for (int dd = 1; dd <= BW; ++dd) hv += Hb[dd * P + row] * vec[dd] + Hb[dd * P + max(row - dd, 0)] * vec[-dd];
-          part += (u < s) ? -hv : hv;
-        }
-      }
-      part = gsum_l<LR>(part);
-      if (rl == 0 && row < P) sRhs[row] = f * (sR[s * P + row] + part);
-      __syncthreads();
-      double mean = 0.0;
+    for (int s = 0; s < DMAX; ++s) {
+      if (s < D) {
+        const int a2 = g_prev * D + s;
+        if (chain) {
+          // rhs_s: lanes of a row share the pairs (u, s), u <= s
+          double part = 0.0;
+          if (row < P) {
+            for (int u = rl; u <= s; u += LR) {
+              const double* Hb = sHp + (size_t)(s * (s + 1) / 2 + u) * d.LG;
+              const double* vec = (u < s) ? &sDl[u][BW + row] : &sTh[s][BW + row];
+              double hv = Hb[row] * vec[0];
 #pragma unroll
-      for (int u = 0; u < QPL; ++u) mean += cr[u] * sRhs[min(rl + u * LR, P - 1)];
-      mean = gsum_l<LR>(mean);
-      if (s + 1 < D) {       // C of the next direction is on its way while this one is finished
-        const double* Cg = c.C2 + (size_t)(a2 + 1) * P * P;
+              for (int dd = 1; dd <= BW; ++dd) hv += Hb[dd * P + row] * vec[dd] + Hb[dd * P + max(row - dd, 0)] * vec[-dd];
+              part += (u < s) ? -hv : hv;
+            }
+          }
+          part = rsum_dpp<LR>(part);
+          if (rl == 0 && row < P) sRhs[row] = f * (sR[s * P + row] + part);
+        }
+        __syncthreads();
+        if (chain) {
+          double mean = 0.0;
+          if (ALLC) {
+            const double* Cs = sC + s * P * P + min(row, P - 1);
 #pragma unroll
-        for (int u = 0; u < QPL; ++u) {
-          const int q = rl + u * LR;
-          cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
+            for (int u = 0; u < QPL; ++u) {
+              const int q = rl + u * LR;
+              mean += ((row < P && q < P) ? Cs[P * min(q, P - 1)] : 0.0) * sRhs[min(q, P - 1)];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) mean += cr[u] * sRhs[min(rl + u * LR, P - 1)];
+          }
+          mean = rsum_dpp<LR>(mean);
+          if (!ALLC && s + 1 < D) {       // C of the next direction is on its way while this one is finished
+            const double* Cg = c.C2 + (size_t)(a2 + 1) * P * P;
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) {
+              const int q = rl + u * LR;
+              cr[u] = (row < P && q < P) ? Cg[row + (size_t)P * q] : 0.0;
+            }
+          }
+          if (rl == 0 && row < P) {
+            const double nw = mean + sLz[s * P + row];
+            sDl[s][BW + row] = nw - sTh[s][BW + row];
+            if (blockIdx.x == 0) {
+              const Dir2 as = dir2_of(d, a2);
+              const int ax = (as.j * (d.M + 1) + as.mt) * D + as.dd;
+              c.thetaN[(size_t)ax * P + row] = nw;
+            }
+          }
         }
+        __syncthreads();
       }
-      if (rl == 0 && row < P) {
-        const double nw = mean + sLz[s][row];
-        sDl[s][BW + row] = nw - sTh[s][BW + row];
-        if (blockIdx.x == 0) {
-          const Dir2 as = dir2_of(d, a2);
-          const int ax = (as.j * (d.M + 1) + as.mt) * D + as.dd;
-          c.thetaN[(size_t)ax * P + row] = nw;
-        }
-      }
-      __syncthreads();
     }
-    // ---- apply the group to this workgroup's curves ----
+    CST(3);
+    // ---- apply the group to this lane group's curves ----
 #pragma unroll
     for (int u = 0; u < COV_CPG; ++u) {
       const int cl = grp * COV_CPG + u;
@@ -417,36 +522,32 @@ __global__ __launch_bounds__(256) void k_cov_group(Ctx c, int g_prev, int g_next
       }
       cf[u] += v;
       gv[u] += Gd;
-      const int i = cbase + cl;
-      if (act && i < n) { c.cfull[(size_t)i * P + lp] = cf[u]; c.gfull[(size_t)i * P + lp] = gv[u]; }
+      const int icv = cbase + cl;
+      if (act && icv < n) { c.cfull[(size_t)icv * P + lp] = cf[u]; c.gfull[(size_t)icv * P + lp] = gv[u]; }
     }
   }
 
+  CST(4);
   // ---- partial sums for the next group, or the residual sums of the final state ----
   if (g_next >= 0) {
-    double acc[DMAX];
-#pragma unroll
-    for (int s = 0; s < DMAX; ++s) acc[s] = 0.0;
-#pragma unroll
-    for (int u = 0; u < COV_CPG; ++u) {
-      const double rsd = sv[u] - gv[u];
-      const int cl = grp * COV_CPG + u;
-#pragma unroll
-      for (int s = 0; s < DMAX; ++s)
-        if (s < D) acc[s] += sWn[cl][s] * rsd;
-    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < DMAX; ++s)
-      if (s < D) sAcc[grp][s][lp] = acc[s];
+      if (s < D) {
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < COV_CPG; ++u) a += sWn[grp * COV_CPG + u][s] * (sv[u] - gv[u]);
+        sAcc[(grp * DMAX + s) * LPC + lp] = a;
+      }
     __syncthreads();
-    for (int e = tid; e < DP; e += 256) {
+    for (int e = tid; e < DP; e += GT) {
       const int s = e / P, p = e - s * P;
       double t = 0.0;
-#pragma unroll
-      for (int gq = 0; gq < GPB; ++gq) t += sAcc[gq][s][p];
-      c.step_part[((size_t)(par_prev ^ 1) * c.NBS + blockIdx.x) * DP + e] = t;
+#pragma unroll 8
+      for (int gq = 0; gq < GPB; ++gq) t += sAcc[(gq * DMAX + s) * LPC + p];
+      c.step_part[((size_t)(par_prev ^ 1) * c.NBS + blockIdx.x) * ((DP + 1) & ~1) + e] = t;
     }
+    CST(5);
   } else {
     double acc = 0.0;
 #pragma unroll
@@ -455,17 +556,16 @@ __global__ __launch_bounds__(256) void k_cov_group(Ctx c, int g_prev, int g_next
       acc += yy[u] - 2.0 * cs + cg;          // identical on every lane of the group
     }
     __syncthreads();
-    if (lp == 0) sAcc[grp][0][0] = acc;
+    if (lp == 0) sAcc[grp] = acc;
     __syncthreads();
     if (tid == 0) {
       double t = 0.0;
-#pragma unroll
-      for (int gq = 0; gq < GPB; ++gq) t += sAcc[gq][0][0];
+      for (int gq = 0; gq < GPB; ++gq) t += sAcc[gq];
       c.rss_part[blockIdx.x] = t;
     }
     // rss_part is read over nblk_curve entries by the log-likelihood / sigma^2 jobs
     if (blockIdx.x == 0)
-      for (int b = c.NBS + tid; b < c.nblk_curve; b += 256) c.rss_part[b] = 0.0;
+      for (int b = c.NBS + tid; b < c.nblk_curve; b += GT) c.rss_part[b] = 0.0;
   }
 }
 
@@ -635,9 +735,9 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
 // ---- host launchers -------------------------------------------------------------------------
 template <int BW>
 static void launch_group_bw(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
-  const size_t lds = (size_t)c.NPG * c.d.LG * sizeof(double);
-  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS), dim3(256), lds, st, c, g_prev, g_next, par_prev);
-  else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS), dim3(256), lds, st, c, g_prev, g_next, par_prev);
+  const size_t lds = ((size_t)c.NPG * c.d.LG + 2 + (c.d.P <= 32 ? (size_t)c.d.D * c.d.P * c.d.P + 2 : 0)) * sizeof(double);
+  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
+  else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
 }
 
 static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
@@ -652,7 +752,8 @@ static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hip
 }
 
 // curve blocks of k_cov_group for nblk_curve blocks of the per-curve kernels
-int cov_step_blocks(int nblk_curve) { return (nblk_curve + COV_CPG - 1) / COV_CPG; }
+// (the per-curve kernels take 256 / LPC curves per block, k_cov_group 1024 / LPC)
+int cov_step_blocks(int nblk_curve) { return (nblk_curve + 4 * COV_CPG - 1) / (4 * COV_CPG); }
 int cov_w2_chunks(int n) { return (n + W2_CH - 1) / W2_CH; }
 
 // the eta / Xi part of one iteration (after k_curve_chi has stored c_i, g_i)
@@ -668,7 +769,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     hipLaunchKernelGGL(k_cov_prep, dim3(n_wblocks + (n_draws + 255) / 256), dim3(256), 0, st, c, n_wblocks);
   }
   if (do_eta || do_xi) {
-    const size_t lds_w2 = ((size_t)W2_CH * DMAX_COV + (size_t)W2_CH * NPG_MAX + (size_t)NPG_MAX * 128) * sizeof(double);
+    const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)W2_CH * c.NPG + (size_t)c.NPG * 128) * sizeof(double);
     hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2), dim3(256), lds_w2, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
     const size_t lds = (2 * (size_t)PP * PP + PP + d.LG) * sizeof(double);

@@ -63,6 +63,11 @@ def main():
     t0 = time.perf_counter()
     smp.run(mask, a.steps, first_iter=a.warmup, seed=2)
     dt = (time.perf_counter() - t0) / a.steps
+    if os.environ.get("COV_STAMPS"):
+        st = smp.get_state("stamps")[40:46]
+        print("k_cov_group phase clocks:", [int(st[i + 1] - st[i]) for i in range(5)], file=sys.stderr)
+        s2 = smp.get_state("stamps")
+        print("  partial phase: issue", int(s2[50] - s2[41]), "stage", int(s2[51] - s2[50]), "adds(wait)", int(s2[52] - s2[51]), "reduce", int(s2[42] - s2[52]), file=sys.stderr)
     n, P, M, K, D = w["n"], w["P"], w["M"], w["K"], w["D"]
     b_alg = 7 * n * 8 * (P * P + P + 1) + 8 * n * (2 * M + 2 * K) + 8 * n * D     # 7 blocks + X
     print(json.dumps({"workload": "config 3: n_funct=4096, D=5, K=3, P=30, M=6, Mean_CovAdj sweep (19 updates)",
