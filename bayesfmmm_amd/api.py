@@ -34,7 +34,7 @@ class EntryArgs(C.Structure):
                 ("N_t", C.c_int32), ("n_temp_trans", C.c_int32), ("r_stored_iters", C.c_int32),
                 ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
                 ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32),
-                ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32)]
+                ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32), ("dir", C.c_char_p)]
 
 
 ENTRY_SYMBOLS = {
@@ -52,6 +52,10 @@ ENTRY_SYMBOLS = {
     "bfmmm_BMVMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_BMVMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
     "bfmmm_BMVMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_arma_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_arma_read_field": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_arma_write_ascii": (C.c_int, [C.c_char_p, c_double_p, c_int64_p, C.c_int]),
+    "bfmmm_arma_write_field": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
     "bfmmm_entry_last_error": (C.c_char_p, []),
 }
 
@@ -109,7 +113,7 @@ def _result_to_dict(lib, res, offsets, P):
         data, cnt, dims, nd = c_double_p(), C.c_int64(), c_int64_p(), C.c_int()
         _check(lib.bfmmm_result_get(res, name, C.byref(data), C.byref(cnt), C.byref(dims), C.byref(nd)))
         shape = tuple(dims[k] for k in range(nd.value))
-        arr = np.ctypeslib.as_array(data, shape=(cnt.value,)).copy()
+        arr = np.ctypeslib.as_array(data, shape=(cnt.value,)).copy() if cnt.value > 0 else np.zeros(0)
         key = name.decode()
         if key in ("B", "B_obs") and offsets is not None:
             rows = arr.reshape(-1, P)
@@ -220,11 +224,12 @@ def BFMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_
 def BFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
                      multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
     """src/UserFunctions.cpp:1341.  Full sampler started at the posterior medians of stages 1 and 2."""
-    if dir is not None:
-        raise NotImplementedError("on-disk chain batches ('dir') are not implemented in this round")
     lib = _lib_entry()
     args = _Args(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.burnin_prop = burnin_prop
+    if dir is not None:      # <dir>Nu<q>.txt, ... are written as the reference does (string concatenation: end it with "/")
+        args.dir = str(dir).encode()
+        args.a.dir = args.dir
     mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau") + (("eta", "tau_eta") if X is not None else ())}
     te_names = ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")
     if X is not None and args.a.covariance_adj:
@@ -258,11 +263,94 @@ def BMVMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, n_eigen, multiple_try, X=None,
 
 def BMVMMM_warm_start(tot_mcmc_iters, K, Y, n_eigen, multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
     """src/UserFunctions.cpp:5540."""
-    if dir is not None:
-        raise NotImplementedError("on-disk chain batches ('dir') are not implemented in this round")
     lib = _lib_entry()
     args = _ArgsMV(5, tot_mcmc_iters, K, Y, n_eigen, X, kw)
     args.a.burnin_prop = burnin_prop
+    if dir is not None:
+        args.dir = str(dir).encode()
+        args.a.dir = args.dir
     mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
     te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
     return _call1(lib.bfmmm_BMVMMM_warm_start, args, mt, te)
+
+
+# ---- readers / writers of the on-disk chain batches (src/UserFunctions.cpp:2157-2357) ---------------------------
+def _read(fn, file):
+    lib = _lib_entry()
+    res = C.c_void_p()
+    try:
+        _check(fn(str(file).encode(), C.byref(res)))
+        return _result_to_dict(lib, res, None, 0)
+    finally:
+        if res:
+            lib.bfmmm_result_free(res)
+
+
+def ReadVec(file):
+    """src/UserFunctions.cpp:2158 (arma::vec::load): 1-d array."""
+    return _read(_lib_entry().bfmmm_arma_read, file)["value"].reshape(-1, order="F")
+
+
+def ReadMat(file):
+    """src/UserFunctions.cpp:2205."""
+    return _read(_lib_entry().bfmmm_arma_read, file)["value"]
+
+
+def ReadCube(file):
+    """src/UserFunctions.cpp:2253."""
+    return _read(_lib_entry().bfmmm_arma_read, file)["value"]
+
+
+def _read_field(file):
+    d = _read(_lib_entry().bfmmm_arma_read_field, file)
+    nr, nc = (int(x) for x in d["field_dims"])
+    out = np.empty((nr, nc), dtype=object)
+    for e in range(nr * nc):
+        out[e % nr, e // nr] = d[str(e)]
+    return out
+
+
+def ReadFieldCube(file):
+    """src/UserFunctions.cpp:2303: object array (n_rows, n_cols) of cubes."""
+    return _read_field(file)
+
+
+def ReadFieldMat(file):
+    """src/UserFunctions.cpp:2351."""
+    return _read_field(file)
+
+
+def ReadFieldVec(file):
+    """src/UserFunctions.cpp:2399: object array of 1-d arrays."""
+    f = _read_field(file)
+    for idx in np.ndindex(f.shape):
+        f[idx] = f[idx].reshape(-1, order="F")
+    return f
+
+
+def write_arma_ascii(file, x):
+    """`x.save(file, arma::arma_ascii)` for a vector (saved as an n x 1 matrix), matrix or cube."""
+    a = np.asfortranarray(np.asarray(x, dtype=np.float64))
+    if a.ndim == 1:
+        a = a.reshape(-1, 1, order="F")
+    flat = np.ascontiguousarray(a.reshape(-1, order="F"))
+    dims = (C.c_int64 * a.ndim)(*a.shape)
+    _check(_lib_entry().bfmmm_arma_write_ascii(str(file).encode(), flat.ctypes.data_as(c_double_p), dims, a.ndim))
+
+
+def write_arma_field(file, field):
+    """`field.save(file)` (arma_binary) for an object array (n_rows, n_cols) of matrices / cubes."""
+    lib = _lib_entry()
+    field = np.asarray(field, dtype=object)
+    if field.ndim == 1:
+        field = field.reshape(-1, 1)
+    nr, nc = field.shape
+    items = {}
+    for e in range(nr * nc):
+        v = np.asarray(field[e % nr, e // nr], dtype=np.float64)
+        items[str(e)] = v.reshape(-1, 1) if v.ndim == 1 else v
+    res = _dict_to_result(lib, items)
+    try:
+        _check(lib.bfmmm_arma_write_field(str(file).encode(), res, nr, nc))
+    finally:
+        lib.bfmmm_result_free(res)

@@ -80,6 +80,7 @@ struct bfmmm_handle {
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
+  int slot_base = 0;                   // chain slot of iteration i is i - slot_base (bfmmm_set_slot_base)
   double* tt_save = nullptr;            // state saved across a tempered-transition block
   bool state_dirty = true;             // the state was changed from the host: proposals prepared on the device are stale
   int profile = 0;
@@ -622,7 +623,8 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
 static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
                     int phi_chi_zero, double beta, uint32_t tt_step) {
   if (!h) return fail("bfmmm_run: null handle");
-  if (n_iters < 0 || first_iter < 0 || first_iter + n_iters > h->T) return fail("bfmmm_run: iterations exceed the allocated chain");
+  if (n_iters < 0 || first_iter < h->slot_base || first_iter - h->slot_base + n_iters > h->T)
+    return fail("bfmmm_run: iterations exceed the allocated chain");
   HIPCHK(hipSetDevice(h->device));
   Ctx c = h->c;
   const int MD = phi_chi_zero ? 1 : (c.d.M + 1);
@@ -640,7 +642,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->last_md = MD;
   Dyn dyn;
   if (dyn_get(h, dyn)) return 1;
-  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)first_iter; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
+  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
   dyn.pend_dir = -1;
   dyn.ll_pending = 0;
   if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; h->state_dirty = false; }
@@ -687,8 +689,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   }
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
-  if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter, first_iter + n_iters, h->st);
-  if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter, first_iter + n_iters, h->st);
+  if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
+  if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS (5 A P doubles + A^2 ints must fit 160 KB)"); }
@@ -701,6 +703,12 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if (dyn.status & 1u)
     return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
                 "eigen-decomposition fallback here; not supported on the device)");
+  return 0;
+}
+
+extern "C" int bfmmm_set_slot_base(bfmmm_handle* h, int base) {
+  if (!h || base < 0) return fail("bfmmm_set_slot_base: bad arguments");
+  h->slot_base = base;
   return 0;
 }
 
@@ -720,7 +728,7 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
                                          uint64_t seed, uint32_t chain, double* logA_out, int* accepted_out) {
   if (!h) return fail("bfmmm_tempered_transition: null handle");
   if (h->c.d.D > 0) return fail("bfmmm_tempered_transition: covariate-adjusted models are not supported");
-  if (N_t < 1 || iter < 0 || iter >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
+  if (N_t < 1 || iter < h->slot_base || iter - h->slot_base >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const Ctx& c = h->c;
   const Dims& d = c.d;
@@ -777,7 +785,7 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
   }
   Dyn dn;
   if (dyn_get(h, dn)) return 1;
-  dn.iter = (uint32_t)(iter + 1); dn.slot = (uint32_t)(iter + 1); dn.tt_step = 0; dn.beta = 1.0;
+  dn.iter = (uint32_t)(iter + 1); dn.slot = (uint32_t)(iter + 1 - h->slot_base); dn.tt_step = 0; dn.beta = 1.0;
   if (dyn_put(h, dn)) return 1;
   if (logA_out) *logA_out = logA;
   if (accepted_out) *accepted_out = accepted;

@@ -30,6 +30,10 @@ extern "C" const char* bfmmm_last_error(void);
 extern "C" const char* bfmmm_entry_last_error(void) { return g_entry_err.c_str(); }
 static int efail(const std::string& m) { g_entry_err = m; return 1; }
 static int efail_lib() { g_entry_err = bfmmm_last_error(); return 1; }
+int bfmmm_io_fail(const std::string& m) { return efail(m); }      // arma_io.cpp reports through the same channel
+int arma_save_ascii(const std::string& path, const double* d, int64_t r, int64_t c, int64_t s, bool cube);
+int arma_save_field_cubes(const std::string& path, const std::vector<std::vector<double>>& cubes, int64_t n_rows, int64_t n_cols,
+                          int64_t r, int64_t c, int64_t s);
 
 extern "C" bfmmm_result* bfmmm_result_create(void) { return new bfmmm_result(); }
 extern "C" void bfmmm_result_free(bfmmm_result* r) { delete r; }
@@ -407,6 +411,72 @@ extern "C" int bfmmm_BFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_resu
   return 0;
 }
 
+// ---- one on-disk batch of BFMMM_MTT_warm_start (BFMMM.h:1680-1730; covariate-adjusted drivers :4455-4545, :5086-5165) ----
+// The batch's r_stored_iters slots are thinned to cnt = r_stored_iters / thinning_num draws: draw 0 is slot 0, draw p > 0
+// is slot thinning_num * p - 1.  Two quirks of the reference are kept: alpha_31(0) is never assigned (the file starts
+// with 0), and the covariate blocks are saved in containers of r_stored_iters (not cnt) entries whose tail stays
+// unassigned (empty cubes in the fields, ones in Tau_Eta).
+static int save_batch(bfmmm_handle* h, const bfmmm_entry_args* a, const std::string& dir, int q, int rs) {
+  const int64_t K = a->K, M = a->n_eigen, n = a->n_funct, P = dimP(a), D = a->D;
+  const int cnt = (int)(rs / a->thinning_num);
+  auto slot_of = [&](int p) { return p == 0 ? 0 : (int)(a->thinning_num * p - 1); };
+  auto get = [&](const char* name, int64_t len, std::vector<double>& v) {
+    v.assign((size_t)len * rs, 0.0);
+    return bfmmm_get_chain(h, name, rs, v.data(), (int64_t)v.size()) ? efail_lib() : 0;
+  };
+  auto thin = [&](const std::vector<double>& v, int64_t len) {
+    std::vector<double> o((size_t)len * cnt);
+    for (int p = 0; p < cnt; ++p) std::copy(v.begin() + len * slot_of(p), v.begin() + len * (slot_of(p) + 1), o.begin() + len * p);
+    return o;
+  };
+  const std::string sq = std::to_string(q) + ".txt";
+  std::vector<double> v;
+  auto cube_txt = [&](const char* chain, const char* file, int64_t r, int64_t c) {
+    if (get(chain, r * c, v)) return 1;
+    return arma_save_ascii(dir + file + sq, thin(v, r * c).data(), r, c, cnt, true);
+  };
+  auto field_bin = [&](const char* chain, const char* file, int64_t r, int64_t c, int64_t s3, int64_t cols, int rows) {
+    // chain slot = `cols` consecutive cubes r x c x s3; field(rows, cols), object (p, k) at p + rows * k
+    if (get(chain, r * c * s3 * cols, v)) return 1;
+    std::vector<std::vector<double>> cubes((size_t)rows * cols);
+    const int64_t len = r * c * s3;
+    for (int p = 0; p < cnt; ++p)
+      for (int64_t k = 0; k < cols; ++k) {
+        const double* src = v.data() + (size_t)(len * cols) * slot_of(p) + len * k;
+        cubes[(size_t)p + (size_t)rows * k].assign(src, src + len);
+      }
+    return arma_save_field_cubes(dir + file + sq, cubes, rows, cols, r, c, s3);
+  };
+  if (cube_txt("nu", "Nu", K, P) || cube_txt("chi", "Chi", n, M)) return 1;
+  if (get("pi", K, v) || arma_save_ascii(dir + "Pi" + sq, thin(v, K).data(), K, cnt, 1, false)) return 1;
+  if (get("alpha_3", 1, v)) return 1;
+  { std::vector<double> t = thin(v, 1); if (cnt > 0) t[0] = 0.0; if (arma_save_ascii(dir + "alpha_3" + sq, t.data(), cnt, 1, 1, false)) return 1; }
+  if (cube_txt("A", "A", K, 2) || cube_txt("delta", "Delta", K, M)) return 1;
+  if (get("sigma_sq", 1, v) || arma_save_ascii(dir + "Sigma" + sq, thin(v, 1).data(), cnt, 1, 1, false)) return 1;
+  {
+    if (get("tau", K, v)) return 1;           // rs x K column-major
+    std::vector<double> t((size_t)cnt * K);
+    for (int64_t k = 0; k < K; ++k)
+      for (int p = 0; p < cnt; ++p) t[(size_t)p + (size_t)cnt * k] = v[(size_t)slot_of(p) + (size_t)rs * k];
+    if (arma_save_ascii(dir + "Tau" + sq, t.data(), cnt, K, 1, false)) return 1;
+  }
+  if (field_bin("gamma", "Gamma", K, P, M, 1, cnt) || field_bin("Phi", "Phi", K, P, M, 1, cnt)) return 1;
+  if (cube_txt("Z", "Z", n, K)) return 1;
+  if (a->X) {
+    if (a->covariance_adj) {
+      if (field_bin("xi", "Xi", P, D, M, K, rs) || field_bin("gamma_xi", "Gamma_Xi", P, D, M, K, rs) ||
+          field_bin("delta_xi", "Delta_Xi", K, M, D, 1, rs) || field_bin("A_xi", "A_Xi", K, 2, D, 1, rs))
+        return 1;
+    }
+    if (field_bin("eta", "Eta", P, D, K, 1, rs)) return 1;
+    if (get("tau_eta", K * D, v)) return 1;
+    std::vector<double> t((size_t)K * D * rs, 1.0);
+    for (int p = 0; p < cnt; ++p) std::copy(v.begin() + K * D * slot_of(p), v.begin() + K * D * (slot_of(p) + 1), t.begin() + K * D * p);
+    if (arma_save_ascii(dir + "Tau_Eta" + sq, t.data(), K, D, rs, true)) return 1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* mt, const bfmmm_result* te,
                                       bfmmm_result** out) {
@@ -418,11 +488,18 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   if (a->n_temp_trans < 0) return efail("'n_temp_trans' must be a non-negative integer");
   if (a->n_temp_trans > 0 && a->X)
     return efail("tempered transitions are implemented for the models without covariates only");
-  if (a->r_stored_iters != 0)
-    return efail("batched on-disk chains (r_stored_iters > 0 with 'dir') are not implemented in this build");
-  if (a->thinning_num != 1) return efail("thinning_num != 1 only applies to on-disk batches, which are not implemented in this build");
+  if (a->thinning_num <= 0) return efail("'thinning_num' must be a positive integer");            // UserFunctions.cpp:1472-1474
+  if (a->r_stored_iters < 0) return efail("'r_stored_iters' must be a non-negative integer");      // :1484-1486
   const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;
   const int P = dimP(a);
+  // UserFunctions.cpp:1508-1541: r_stored_iters = 0 keeps everything in memory (tot_mcmc_iters + 1 slots)
+  const bool have_dir = a->dir && a->dir[0];
+  int rs = a->r_stored_iters == 0 ? T + 1 : a->r_stored_iters;
+  if (!have_dir && rs <= T)
+    return efail("'r_stored_iters' <= 'tot_mcmc_iters' with no 'dir' specified. Either specify 'dir' or increase 'r_stored_iters'");
+  if (rs > T + 1) rs = T + 1;
+  const bool batched = rs <= T;          // otherwise (i + 1) % r_stored_iters is never 0 inside the loop: nothing is saved
+  if (batched && a->thinning_num != std::floor(a->thinning_num)) return efail("'thinning_num' must be a positive integer");
   // ---- posterior medians of every block (UserFunctions.cpp:1557-1647) ----
   std::vector<double> Z_est, nu_est, buf;
   int64_t n_nu = 0;
@@ -497,7 +574,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   // ---- one chain of the full sweep from the medians (BFMMM.h:1486-1498, 1500-1554) ----
   int tt_blocks = 0, tt_accepted = 0;
   bfmmm_config cfg;
-  make_cfg(a, T, &cfg);
+  make_cfg(a, batched ? rs : T, &cfg);          // chain slots in HBM
   bfmmm_handle* h = nullptr;
   if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &h)) return efail_lib();
   const uint32_t mask_ws = BFMMM_SWEEP_WARM | (a->X ? (BFMMM_COV_MEAN | (a->covariance_adj ? BFMMM_COV_XI : 0)) : 0);   // BFMMM.h:4248-4312 / 4809-4894
@@ -515,35 +592,75 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
            bfmmm_set_state(h, "Phi", Phi_est.data(), (int64_t)K * P * M) || bfmmm_set_state(h, "A", A_est.data(), (int64_t)K * 2) ||
            bfmmm_set_state(h, "nu", nu_est.data(), (int64_t)K * P) || bfmmm_set_state(h, "tau", tau_est.data(), K) ||
            bfmmm_set_state(h, "sigma_sq", &sigma_est, 1) || bfmmm_set_state(h, "chi", chi_est.data(), (int64_t)n * M);
+  // iterations [i_begin, i_end) of BFMMM.h:1500-1672: the sweep of iteration i, then -- every n_temp_trans iterations --
+  // the tempered-transition block
+  auto run_range = [&](int i_begin, int i_end) -> int {
+    if (a->n_temp_trans == 0) return bfmmm_run(h, mask_ws, i_begin, i_end - i_begin, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+    int i0 = i_begin, r2 = 0;
+    for (int i = i_begin; i < i_end && !r2; ++i)
+      if (i > 0 && (i % a->n_temp_trans) == 0) {
+        double logA; int acc;
+        r2 = bfmmm_run(h, mask_ws, i0, i + 1 - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0) ||
+             bfmmm_tempered_transition(h, mask_ws, i, a->N_t, a->beta_N_t, a->seed, (uint32_t)a->chain_offset, &logA, &acc);
+        i0 = i + 1; tt_blocks += 1; tt_accepted += acc;
+      }
+    if (!r2 && i0 < i_end) r2 = bfmmm_run(h, mask_ws, i0, i_end - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+    return r2;
+  };
+  bool io_failed = false;
   if (!rc) {
-    if (a->n_temp_trans == 0) {
-      rc = bfmmm_run(h, mask_ws, 0, T, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
+    if (!batched) {
+      rc = run_range(0, T);
     } else {
-      // BFMMM.h:1500-1672: the sweep of iteration i, then -- every n_temp_trans iterations -- the tempered-transition block
-      int i0 = 0, n_blocks = 0, n_acc = 0;
-      for (int i = 0; i < T && !rc; ++i)
-        if (i > 0 && (i % a->n_temp_trans) == 0) {
-          double logA; int acc;
-          rc = bfmmm_run(h, mask_ws, i0, i + 1 - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0) ||
-               bfmmm_tempered_transition(h, mask_ws, i, a->N_t, a->beta_N_t, a->seed, (uint32_t)a->chain_offset, &logA, &acc);
-          i0 = i + 1; n_blocks += 1; n_acc += acc;
+      // BFMMM.h:1680-1746: iteration i lives in slot i % r_stored_iters; whenever a batch is full (and i > 1) it is
+      // thinned and saved, and the next batch reuses the slots
+      const std::string dir(a->dir);
+      int q = 0;
+      for (int b0 = 0; b0 < T && !rc; b0 += rs) {
+        const int b1 = std::min(b0 + rs, T);
+        rc = bfmmm_set_slot_base(h, b0) || run_range(b0, b1);
+        if (!rc && b1 - b0 == rs && b1 - 1 > 1) {
+          if (save_batch(h, a, dir, q, rs)) { io_failed = true; rc = 1; }
+          q += 1;
         }
-      if (!rc && i0 < T) rc = bfmmm_run(h, mask_ws, i0, T - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
-      tt_blocks = n_blocks; tt_accepted = n_acc;
+      }
     }
   }
+  if (rc && io_failed) { bfmmm_destroy(h); return 1; }
   if (rc) { efail_lib(); bfmmm_destroy(h); return 1; }
-  // r_stored_iters defaults to tot_mcmc_iters + 1 slots (UserFunctions.cpp:1510-1541): slot T repeats slot T-1
-  const int TT = T + 1;
   bfmmm_result* r = bfmmm_result_create();
-  rc = fetch_basis(h, r, a, "B_obs") || fetch(h, r, "Z", "Z", T, (int64_t)n * K, {n, K, TT}, 1) ||
-       fetch(h, r, "nu", "nu", T, (int64_t)K * P, {K, P, TT}, 1) || fetch(h, r, "chi", "chi", T, (int64_t)n * M, {n, M, TT}, 1) ||
-       fetch(h, r, "pi", "pi", T, K, {K, TT}, 1) || fetch(h, r, "alpha_3", "alpha_3", T, 1, {TT}, 1) ||
-       fetch(h, r, "A", "A", T, (int64_t)K * 2, {K, 2, TT}, 1) || fetch(h, r, "delta", "delta", T, (int64_t)K * M, {K, M, TT}, 1) ||
-       fetch(h, r, "sigma_sq", "sigma_sq", T, 1, {TT}, 1) || fetch_tau(h, r, T, K, 1) ||
-       fetch(h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, TT}, 1) ||
-       fetch(h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, TT}, 1) || fetch(h, r, "loglik", "loglik", T, 1, {TT}, 1) ||
-       fetch_cov(h, r, a, T, a->covariance_adj != 0, 1);
+  if (!batched) {
+    // r_stored_iters defaults to tot_mcmc_iters + 1 slots (UserFunctions.cpp:1510-1541): slot T repeats slot T-1
+    const int TT = T + 1;
+    rc = fetch_basis(h, r, a, "B_obs") || fetch(h, r, "Z", "Z", T, (int64_t)n * K, {n, K, TT}, 1) ||
+         fetch(h, r, "nu", "nu", T, (int64_t)K * P, {K, P, TT}, 1) || fetch(h, r, "chi", "chi", T, (int64_t)n * M, {n, M, TT}, 1) ||
+         fetch(h, r, "pi", "pi", T, K, {K, TT}, 1) || fetch(h, r, "alpha_3", "alpha_3", T, 1, {TT}, 1) ||
+         fetch(h, r, "A", "A", T, (int64_t)K * 2, {K, 2, TT}, 1) || fetch(h, r, "delta", "delta", T, (int64_t)K * M, {K, M, TT}, 1) ||
+         fetch(h, r, "sigma_sq", "sigma_sq", T, 1, {TT}, 1) || fetch_tau(h, r, T, K, 1) ||
+         fetch(h, r, "gamma", "gamma", T, (int64_t)K * P * M, {K, P, M, TT}, 1) ||
+         fetch(h, r, "Phi", "Phi", T, (int64_t)K * P * M, {K, P, M, TT}, 1) || fetch(h, r, "loglik", "loglik", T, 1, {TT}, 1) ||
+         fetch_cov(h, r, a, T, a->covariance_adj != 0, 1);
+  } else {
+    // the r_stored_iters slots of the last batch in memory; when the run ended on a full batch the reference has
+    // already copied the final state into slot 0 for the iteration that never comes ("reset all parameters",
+    // BFMMM.h:1732-1743; loglik is not part of that reset)
+    rc = fetch_basis(h, r, a, "B_obs") || fetch(h, r, "Z", "Z", rs, (int64_t)n * K, {n, K, rs}) ||
+         fetch(h, r, "nu", "nu", rs, (int64_t)K * P, {K, P, rs}) || fetch(h, r, "chi", "chi", rs, (int64_t)n * M, {n, M, rs}) ||
+         fetch(h, r, "pi", "pi", rs, K, {K, rs}) || fetch(h, r, "alpha_3", "alpha_3", rs, 1, {rs}) ||
+         fetch(h, r, "A", "A", rs, (int64_t)K * 2, {K, 2, rs}) || fetch(h, r, "delta", "delta", rs, (int64_t)K * M, {K, M, rs}) ||
+         fetch(h, r, "sigma_sq", "sigma_sq", rs, 1, {rs}) || fetch_tau(h, r, rs, K) ||
+         fetch(h, r, "gamma", "gamma", rs, (int64_t)K * P * M, {K, P, M, rs}) ||
+         fetch(h, r, "Phi", "Phi", rs, (int64_t)K * P * M, {K, P, M, rs}) || fetch(h, r, "loglik", "loglik", rs, 1, {rs}) ||
+         fetch_cov(h, r, a, rs, a->covariance_adj != 0);
+    if (!rc && T % rs == 0 && T - 1 > 1)
+      for (const std::string& nm : r->names) {
+        if (nm == "loglik" || nm == "B_obs") continue;
+        ResArr& arr = r->arrs[nm];
+        if (nm == "tau") { for (int k = 0; k < K; ++k) arr.data[(size_t)rs * k] = arr.data[(size_t)rs * k + rs - 1]; continue; }
+        const size_t len = arr.data.size() / (size_t)rs;
+        std::copy(arr.data.begin() + len * (rs - 1), arr.data.begin() + len * rs, arr.data.begin());
+      }
+  }
   bfmmm_destroy(h);
   if (rc) { bfmmm_result_free(r); return 1; }
   if (a->n_temp_trans > 0) {     // (the reference only prints its running acceptance rate, BFMMM.h:1675; exposed here)

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_s
     dyn->loglik = ll;
     if (c.mask & U_LOGLIK) c.c_loglik[dyn->slot] = ll;
     dyn->iter += 1;
-    dyn->slot = (r_stored > 0) ? (dyn->iter % (uint32_t)r_stored) : dyn->iter;
+    dyn->slot = (r_stored > 0) ? ((dyn->iter - dyn->slot_base) % (uint32_t)r_stored) : dyn->iter - dyn->slot_base;
   }
 }
 

@@ -39,7 +39,7 @@ struct Hyper {
 // can be replayed without re-recording kernel arguments.
 struct Dyn {
   uint32_t iter;        // chain iteration index (RNG counter word) of the sweep being executed
-  uint32_t slot;        // chain slot that sweep writes (iter % r_stored_iters)
+  uint32_t slot;        // chain slot that sweep writes (iter - slot_base)
   uint32_t tt_step;     // tempered-transition sub-step (0 outside)
   uint32_t status;      // sticky error bits (1: precision matrix not positive definite)
   uint32_t iter_hyper;  // snapshot of iter / slot taken by the sweep kernel for k_curve_chi, whose scalar-job workgroup
@@ -50,7 +50,8 @@ struct Dyn {
   uint32_t ll_use_part;
   uint32_t zprep_valid, zprep_iter, zprep_tt, zprep_chain;   // tag of the Z proposals prepared ahead (z_proposal.hpp)
   uint32_t znorm_valid, znorm_iter, znorm_tt;    // tag of the chi normals drawn ahead by spare k_factor workgroups
-  uint32_t piprep_valid, piprep_iter, pad2_;     // tag of the pi / alpha_3 tables prepared ahead
+  uint32_t piprep_valid, piprep_iter;            // tag of the pi / alpha_3 tables prepared ahead
+  uint32_t slot_base;   // slot = iter - slot_base: on-disk batches of r_stored_iters draws reuse the same slots (BFMMM.h:1680-1746)
   unsigned long long zprep_seed;
   double beta;          // temperature (1 = untempered)
   double sigma2;        // current sigma^2 (variance, as everywhere in the reference)

@@ -469,7 +469,7 @@ __device__ inline void job_hyper(const Ctx& c) {
     dyn->ll_use_part = (uint32_t)c.ll_use_part;
     dyn->ll_pending = 1u;
     dyn->iter = dyn->iter_hyper + 1u;
-    dyn->slot = dyn->iter_hyper + 1u;
+    dyn->slot = dyn->iter_hyper + 1u - dyn->slot_base;
   }
 }
 

@@ -109,6 +109,10 @@ class Sampler:
     def run(self, mask, n_iters, first_iter=0, seed=1, chain=0, phi_chi_zero=False, beta=1.0):
         _lib.check(self.lib.bfmmm_run(self.h, mask, first_iter, n_iters, seed, chain, int(phi_chi_zero), beta))
 
+    def set_slot_base(self, base):
+        """Chain iteration i is written to slot i - base (on-disk batches reuse the slots, include/bfmmm.h)."""
+        _lib.check(self.lib.bfmmm_set_slot_base(self.h, int(base)))
+
     def tempered_transition(self, mask, iteration, N_t, beta_N_t, seed=1, chain=0):
         """Tempered-transition block of BFMMM_warm_start (BFMMM.h:1556-1657) for the chain iteration that `run` has just
         produced; returns (log acceptance probability, accepted)."""

@@ -115,6 +115,12 @@ int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain);
 int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
               int phi_chi_zero, double beta);
 
+/* Chain iteration i is written to slot i - base (default 0).  The reference keeps r_stored_iters draws in memory and
+ * reuses the slots for every on-disk batch (`i % r_stored_iters`, BFMMM.h:1500-1746): a driver that saves batches
+ * moves the base to the first iteration of the next batch; the RNG counter word stays the iteration index, so a
+ * batched run draws exactly what an unbatched one does. */
+int bfmmm_set_slot_base(bfmmm_handle* h, int base);
+
 /* Tempered-transition block of BFMMM_MTT_warm_start (inst/include/BayesFMMM/BFMMM.h:1556-1657, ladder :1452-1460,
  * acceptance CalculateTTAcceptance.h:22-97) for chain iteration `iter`, to be called right after bfmmm_run has
  * produced that iteration: 2 N_t tempered sweeps of the updates in `mask` (temperatures up and down the geometric

@@ -76,6 +76,13 @@ typedef struct {
   const double* X;
   int32_t D;
   int32_t covariance_adj;
+  /* warm_start only: the `dir` argument (UserFunctions.cpp:1354, :1515-1530), NULL = nothing is saved.  With a
+   * directory and 0 < r_stored_iters <= tot_mcmc_iters only r_stored_iters draws are kept in memory: after every
+   * r_stored_iters iterations the batch is thinned (every thinning_num-th draw) and saved as <dir>Nu<q>.txt, Chi, Pi,
+   * alpha_3, A, Delta, Sigma, Tau, Z (arma_ascii), Gamma, Phi (binary fields of cubes) -- plus Eta, Xi, Gamma_Xi,
+   * Delta_Xi, A_Xi, Tau_Eta with covariates -- exactly as BFMMM_MTT_warm_start does (BFMMM.h:1680-1746, :5086-5165);
+   * the returned arrays then have r_stored_iters slots (the last batch in memory). */
+  const char* dir;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:
@@ -103,6 +110,17 @@ int bfmmm_BMVMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out
 int bfmmm_BMVMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, bfmmm_result** out);
 int bfmmm_BMVMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, const bfmmm_result* theta_est,
                             bfmmm_result** out);
+
+/* Readers / writers of the on-disk batches (Armadillo arma_ascii and arma_binary field files), the counterparts of
+ * ReadVec / ReadMat / ReadCube (src/UserFunctions.cpp:2158, :2205, :2253: result element "value", with its dims) and
+ * ReadFieldCube / ReadFieldMat / ReadFieldVec (:2303, :2351, :2399: result elements "field_dims" = (n_rows, n_cols) and
+ * "0" .. "n-1", the field's objects in column-major order).  bfmmm_arma_write_ascii writes a vector / matrix / cube
+ * (n_dims = 1, 2, 3) as `.save(file, arma::arma_ascii)` does; bfmmm_arma_write_field writes the objects "0" .. of
+ * `items` as a binary field (`field.save(file)`). */
+int bfmmm_arma_read(const char* file, bfmmm_result** out);
+int bfmmm_arma_read_field(const char* file, bfmmm_result** out);
+int bfmmm_arma_write_ascii(const char* file, const double* data, const int64_t* dims, int n_dims);
+int bfmmm_arma_write_field(const char* file, const bfmmm_result* items, int64_t n_rows, int64_t n_cols);
 
 /* message of the last failing bfmmm_result_* / bfmmm_BFMMM_* call on this thread */
 const char* bfmmm_entry_last_error(void);
