@@ -77,9 +77,13 @@ struct bfmmm_handle {
   // graph cache for the last (mask, md, seed, chain)
   hipGraphExec_t gexec = nullptr;      // one iteration
   hipGraphExec_t gexecN = nullptr;     // GRAPH_UNROLL iterations (amortises the fixed cost of a graph launch)
+  // fused runs (k_curve_chi of iteration i also does the Z update of iteration i + 1): k_curve_z once, then bodies
+  // [pair_gram .. chi + Z] (gexecF one, gexecFN GRAPH_UNROLL of them), then the last iteration without Z (gexecL)
+  hipGraphExec_t gexecF = nullptr, gexecFN = nullptr, gexecL = nullptr;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
+  bool g_valid = false;                // the captured graphs match (g_mask, g_md, g_seed, g_chain)
   int slot_base = 0;                   // chain slot of iteration i is i - slot_base (bfmmm_set_slot_base)
   double* tt_save = nullptr;            // state saved across a tempered-transition block
   bool state_dirty = true;             // the state was changed from the host: proposals prepared on the device are stale
@@ -339,8 +343,9 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   HIPCHK(copy_sync(h, c.gamma_xi, ones.data(), sizeof(double) * K * P * D * M, hipMemcpyHostToDevice));
   HIPCHK(copy_sync(h, c.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
   HIPCHK(copy_sync(h, c.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
-  if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-  if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
+  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL})
+    if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+  h->g_valid = false;
   return 0;
 }
 
@@ -348,8 +353,8 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-  if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
+  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL})
+    if (g) (void)hipGraphExecDestroy(g);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -599,13 +604,14 @@ static Plan make_plan(uint32_t mask, int MD) {
 //   -> k_curve_chi (+1 workgroup: delta/A/gamma/tau) -> k_loglik
 // The scalar updates ride inside the wide kernels, so the replayed graph is a single chain of
 // seven kernels with no cross-queue dependencies.
+// skip_z: the Z update of this iteration was already done by the previous iteration's k_curve_chi (fuse_z there).
 static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NKS, int KS, hipStream_t st,
-                             std::vector<hipEvent_t>* evs) {
+                             std::vector<hipEvent_t>* evs, bool skip_z = false, bool fuse_z = false) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
   mark();
-  if (p.z) launch_curve(c, 0, p.z_update, st);
+  if (p.z && !skip_z) launch_curve(c, 0, p.z_update, st);
   mark();
   launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
   mark();
@@ -613,7 +619,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
-  launch_curve(c, 1, p.chi ? (p.chi_update ? 2 : 1) : 0, st);
+  launch_curve(c, 1, (p.chi ? (p.chi_update ? 2 : 1) : 0) | (fuse_z ? 16 : 0), st);
   if (c.d.D > 0) launch_cov_block(c, st);      // eta, tau_eta, Xi, delta_xi, A_xi, gamma_xi (+ residual sums)
   mark();
   if (!c.defer_loglik) launch_loglik(c, p.use_rss_part, 0, st);      // otherwise: job_hyper + the next k_pair_gram (scalar_jobs.hpp)
@@ -665,27 +671,46 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
   } else if (n_iters > 0) {
-    const bool reuse = h->gexec && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
+    const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
     if (!reuse) {
-      if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-      if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
-      std::lock_guard<std::mutex> lock(g_capture_mutex);
-      for (int pass = 0; pass < 2; ++pass) {
-        const int reps = pass == 0 ? 1 : GRAPH_UNROLL;
-        if (pass == 1 && n_iters < 2 * GRAPH_UNROLL) break;
-        hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
-        for (int r = 0; r < reps; ++r) launch_iteration(h, c, plan, NKS, KS, h->st, nullptr);
-        HIPCHK(hipStreamEndCapture(h->st, &graph));
-        HIPCHK(hipGraphInstantiate(pass == 0 ? &h->gexec : &h->gexecN, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-      }
-      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain;
+      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL})
+        if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_valid = true;
     }
-    int it = 0;
-    if (h->gexecN)
-      for (; it + GRAPH_UNROLL <= n_iters; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
-    for (; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+    // graphs are captured on demand: kind 0 = full iterations, 1 = fused bodies (no Z in front, chi + next Z at the end),
+    // 2 = the closing iteration of a fused run (no Z in front, plain chi)
+    auto ensure = [&](hipGraphExec_t* g, int kind, int reps) -> int {
+      if (*g) return 0;
+      std::lock_guard<std::mutex> lock(g_capture_mutex);
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
+      for (int r = 0; r < reps; ++r) launch_iteration(h, c, plan, NKS, KS, h->st, nullptr, kind != 0, kind == 1);
+      HIPCHK(hipStreamEndCapture(h->st, &graph));
+      HIPCHK(hipGraphInstantiate(g, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      return 0;
+    };
+    const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
+    if (!fuse) {
+      if (ensure(&h->gexec, 0, 1)) return 1;
+      int it = 0;
+      if (n_iters >= 2 * GRAPH_UNROLL) {
+        if (ensure(&h->gexecN, 0, GRAPH_UNROLL)) return 1;
+        for (; it + GRAPH_UNROLL <= n_iters; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
+      }
+      for (; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+    } else {
+      if (ensure(&h->gexecF, 1, 1) || ensure(&h->gexecL, 2, 1)) return 1;
+      launch_curve(c, 0, plan.z_update, h->st);              // Z of the first iteration
+      int it = 0;
+      const int nb = n_iters - 1;                             // fused bodies
+      if (nb >= 2 * GRAPH_UNROLL) {
+        if (ensure(&h->gexecFN, 1, GRAPH_UNROLL)) return 1;
+        for (; it + GRAPH_UNROLL <= nb; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecFN, h->st));
+      }
+      for (; it < nb; ++it) HIPCHK(hipGraphLaunch(h->gexecF, h->st));
+      HIPCHK(hipGraphLaunch(h->gexecL, h->st));
+    }
   }
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
@@ -700,6 +725,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->fam_ms[FAM_TOTAL] = ms;
   h->fam_launches[FAM_TOTAL] = n_iters;
   if (dyn_get(h, dyn)) return 1;
+  if (dyn.status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
   if (dyn.status & 1u)
     return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
                 "eigen-decomposition fallback here; not supported on the device)");

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     TSTAMP(c, 58);
     return;
   }
+  // bit 4 of mode: after its chi update / residual pass a curve group also runs the Z update of the NEXT iteration
+  // (fused k_curve_z, D == 0 only): the record, theta and Z are already on chip, so the next iteration loses the
+  // load phase of k_curve_z (60 % of that kernel) and one launch boundary.
+  const bool fuse_z = (mode & 16) != 0;
+  mode &= 15;
   if (mode == 0) return;
   // Workgroups 1-7 are idle: they keep curve block b at grid index 8 + b, i.e. on the XCD that runs block b of
   // k_curve_z (workgroups go to the XCDs round-robin), so the Z / chi / record lines the two kernels hand each other
@@ -378,14 +383,16 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   double* sTh = smem;
   double* sThX = sTh + nth;
   double* sRss = sThX + (size_t)nth * D;            // GPB
+  double* sLog = sRss + GPB;                        // GPB*KMAX (fused Z: block partial of sum_i log Z_ik)
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int nres = M * (M + 1) / 2 + M + 2;
-  const int per_group = (2 * M + 3) * T::STR + 2 * M + nres + (D > 0 ? NR * T::STR : 0);
-  double* gbase = sRss + GPB + (size_t)grp * per_group;
-  T tU{gbase}, tG{gbase + M * T::STR}, tX{gbase + 2 * M * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
-  double* sChi = gbase + (2 * M + 3) * T::STR;
-  double* sZn = sChi + M;
-  double* sRes = sZn + M;
+  const int RT = max(M, K);                          // rows of the U / GU tiles (the fused Z update needs K of them)
+  const int nres = max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2);
+  const int per_group = (2 * RT + 3) * T::STR + 2 * M + 2 + nres + (D > 0 ? NR * T::STR : 0);
+  double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
+  T tU{gbase}, tG{gbase + RT * T::STR}, tX{gbase + 2 * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
+  double* sChi = gbase + (2 * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
+  double* sZn = sChi + M + 1;
+  double* sRes = sZn + M + 1;
   T tE{sRes + nres};
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
@@ -397,9 +404,9 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   Curve<BW, LPC> cv;
   if (valid) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
-    tU.zero_pads(2 * M + 3, lp);
+    tU.zero_pads(2 * RT + 3, lp);
     if (D > 0) tE.zero_pads(NR, lp);
-    if (lp < M) sChi[lp] = (MD > 1) ? c.chi[i + (size_t)n * lp] : 0.0;
+    if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;
     tX.row(2)[lp] = cv.s;
   }
   __syncthreads();
@@ -423,10 +430,20 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     ths = T::STR;
   }
   double rss = 0.0;
+  double logz_mine = 0.0;
   if (valid) {
     double Zi[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) Zi[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
+    // fused Z update: the proposal prepared by this iteration's k_factor is requested now, used at the end
+    ZProposal zp;
+    const uint32_t it_next = dyn->iter_hyper + 1u;
+    bool zpre = false;
+    if (fuse_z) {
+      zpre = dyn->zprep_valid && dyn->zprep_iter == it_next && dyn->zprep_tt == dyn->tt_step &&
+             dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed;
+      if (zpre) z_proposal_load(c, i, zp);
+    }
     // u_m = sum_k Z_k phi_km ;  c0 = sum_k Z_k nu_k + sum_m chi_m u_m
     double cf = 0.0;
     if (act) {
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
           const double W = 1.0 / (1.0 + ((W0 * beta) / sigma2));
           const double chi_new = W * w + sqrt(W) * sZn[m];
           dl[m] = chi_new - chi_old;
-          if (lp == m) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; }
+          if (lp == m) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; sChi[m] = chi_new; }
         }
       }
       // rss(c0 + sum_m dl_m u_m) = rss0 - 2 sum_m dl_m b_m + sum_{m,m2} dl_m dl_m2 A_{m,m2}
@@ -523,13 +540,93 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
       c.cfull[(size_t)i * P + lp] = tX.row(0)[lp];
       c.gfull[(size_t)i * P + lp] = cv.s - tX.row(1)[lp];
     }
+    if (fuse_z && !zpre && lp == 0) atomicOr(&c.dyn->status, 2u);      // cannot happen in a fused run (see below); reported by bfmmm_run
+    if (fuse_z && zpre) {
+      // ---- updateZ_PM of iteration it_next for this curve (UpdateMixedMembership.h:131-185), as in k_curve_z:
+      //      theta (sTh), the record (cv), s (tX row 2) and the new chi (sChi) are on chip; the U / GU tiles are free ----
+      // (the data-independent half of the update was prepared by this iteration's k_factor, job_z_prepare: it runs
+      //  under exactly the conditions the host fuses under -- U_Z, no covariates, untempered)
+      __builtin_amdgcn_wave_barrier();
+      double uk[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) uk[k] = (k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
+      if (MD > 1 && act)
+        for (int m = 0; m < M; m += 2) {
+          const double c0 = sChi[m], c1 = sChi[m + 1];
+          const int r0 = (m + 1), r1 = min(m + 2, M);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+              const double* th = sTh + (size_t)k * (M + 1) * P + lp;
+              uk[k] += c0 * th[r0 * P] + c1 * th[r1 * P];
+            }
+        }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) tU.row(k)[lp] = uk[k];
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
+      __builtin_amdgcn_wave_barrier();
+      const int nzt = K + K * (K + 1) / 2;       // q < K: a_q = u_q's ;  q >= K: pair (k, k2), k <= k2: u_k' G u_k2
+      if (lp < nzt) {
+        const double* ra = tU.row(min(lp, K - 1));
+        const double* rb = tX.row(2);
+        if (lp >= K) {
+          int a = 0, rem = lp - K;
+          while (rem >= K - a) { rem -= K - a; ++a; }
+          ra = tU.row(a); rb = tG.row(a + rem);
+        }
+        sRes[lp] = dotL<LPC>(ra, rb);
+      }
+      __builtin_amdgcn_wave_barrier();
+      double q_old = cv.yy, q_new = cv.yy;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const double avk = sRes[k];
+          q_old -= 2.0 * Zi[k] * avk;
+          q_new -= 2.0 * zp.Znew[k] * avk;
+#pragma unroll
+          for (int k2 = 0; k2 < KMAX; ++k2) {
+            if (k2 < K) {
+              const double qq = sRes[K + tri_index(K, min(k, k2), max(k, k2))];
+              q_old += Zi[k] * Zi[k2] * qq;
+              q_new += zp.Znew[k] * zp.Znew[k2] * qq;
+            }
+          }
+        }
+      }
+      const double z_lpdf = zp.pr_old - beta * (q_old / (2.0 * sigma2));
+      const double z_new_lpdf = zp.pr_new - beta * (q_new / (2.0 * sigma2));
+      double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && Zi[k] <= 0) acceptance = 1;                        // UpdateMixedMembership.h:170-174
+      const bool took_new = zp.log_uu < acceptance;
+      double* zslot = c.c_Z + (size_t)(dyn->slot_hyper + 1u) * n * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && lp == k) {
+          const double zf = took_new ? zp.Znew[k] : Zi[k];
+          c.Z[i + (size_t)n * k] = zf;
+          zslot[i + (size_t)n * k] = zf;
+          logz_mine = took_new ? zp.ln[k] : zp.lo[k];
+        }
+    }
   }
   if (lp == 0) sRss[grp] = rss;
+  if (fuse_z && lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
     double acc = 0.0;
     for (int g = 0; g < GPB; ++g) acc += sRss[g];
     c.rss_part[blk] = acc;
+  }
+  if (fuse_z && threadIdx.x >= 64 && threadIdx.x < 64 + K) {      // block partial of sum_i log Z_ik, as k_curve_z leaves it
+    const int k = threadIdx.x - 64;
+    double acc = 0.0;
+    for (int g = 0; g < GPB; ++g) acc += sLog[g * KMAX + k];
+    c.logz_part[(size_t)blk * K + k] = acc;
   }
 }
 
@@ -546,7 +643,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const size_t tileE = (D > 0) ? (size_t)K * (M + 1) * STR : 0;
   size_t lds;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
-  else lds = nth * (1 + D) + GPB + (size_t)GPB * ((2 * M + 3) * STR + 2 * M + (M * (M + 1) / 2 + M + 2) + tileE);
+  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((2 * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
   if (which == 1) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;
