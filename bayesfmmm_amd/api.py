@@ -83,8 +83,6 @@ class _ArgsMV:
     """bfmmm_entry_args of the multivariate entry points: Y is the n x P matrix."""
 
     def __init__(self, entry, tot_mcmc_iters, K, Y, n_eigen, X, kw):
-        if X is not None:
-            raise NotImplementedError("covariate-adjusted models (X) are not implemented in this round")
         lib = _lib_entry()
         self.a = EntryArgs()
         lib.bfmmm_entry_defaults(C.byref(self.a), entry)
@@ -94,6 +92,14 @@ class _ArgsMV:
         a.n_funct, a.P, a.tot_mcmc_iters, a.K, a.n_eigen = n, P, tot_mcmc_iters, K, n_eigen
         a.y = self.Y.ctypes.data_as(c_double_p)
         self.P, self.offsets = P, None
+        if X is not None:        # UserFunctions.cpp:4582 / :5000 / :5545 (`X`, `covariance_adj`)
+            self.X = np.asfortranarray(X, dtype=np.float64)
+            if self.X.shape[0] != n:
+                raise _lib.BfmmmError("'X' must be have 'n_funct' number of rows")
+            a.X, a.D = self.X.ctypes.data_as(c_double_p), self.X.shape[1]
+            a.covariance_adj = int(bool(kw.pop("covariance_adj", False)))
+        else:
+            kw.pop("covariance_adj", None)
         c = kw.pop("c", None)
         if c is not None:
             self.c = np.ascontiguousarray(c, dtype=np.float64)
@@ -254,7 +260,7 @@ def BMVMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, n_eigen, multiple_try, X=None,
     lib = _lib_entry()
     args = _ArgsMV(4, tot_mcmc_iters, K, Y, n_eigen, X, kw)
     args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
-    mt = {k: multiple_try[k] for k in ("Z", "nu")}
+    mt = {k: multiple_try[k] for k in ("Z", "nu") + (("eta",) if X is not None else ())}
     if group is not None:
         from . import parallel
         return parallel.multi_try(lambda: _call1(lib.bfmmm_BMVMMM_Theta_est, args, mt), args, group)
@@ -269,8 +275,11 @@ def BMVMMM_warm_start(tot_mcmc_iters, K, Y, n_eigen, multiple_try, theta_est, X=
     if dir is not None:
         args.dir = str(dir).encode()
         args.a.dir = args.dir
-    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
-    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau") + (("eta", "tau_eta") if X is not None else ())}
+    te_names = ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")
+    if X is not None and args.a.covariance_adj:
+        te_names += ("xi", "gamma_xi", "delta_xi", "A_xi")
+    te = {k: theta_est[k] for k in te_names}
     return _call1(lib.bfmmm_BMVMMM_warm_start, args, mt, te)
 
 
