@@ -657,12 +657,15 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
   HIPCHK(hipEventRecord(h->ev0, h->st));
   if (h->profile) {
+    // the same kernels as the graph path (including the fused chi + next-Z launches), bracketed by events
+    const bool pfuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
     for (int it = 0; it < n_iters; ++it) {
       std::vector<hipEvent_t> evs;
-      launch_iteration(h, c, plan, NKS, KS, h->st, &evs);
+      const bool skip_z = pfuse && it > 0, fuse_z = pfuse && it + 1 < n_iters;
+      launch_iteration(h, c, plan, NKS, KS, h->st, &evs, skip_z, fuse_z);
       HIPCHK(hipStreamSynchronize(h->st));
       const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
-      const bool ran[6] = {plan.z, true, plan.factor, true, true, c.defer_loglik == 0};
+      const bool ran[6] = {plan.z && !skip_z, true, plan.factor, true, true, c.defer_loglik == 0};
       for (int q = 0; q < 6; ++q) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, evs[q], evs[q + 1]);

@@ -125,18 +125,16 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
   const int D = COV ? d.D : 0;   // the covariate code is compiled only into the COV instantiation
   const int nth = K * (M + 1) * P;
-  const int NR = K * (M + 1);                        // rows of the effective-parameter tile (D > 0)
   double* sTh = smem;
   double* sThX = sTh + nth;                          // D > 0: thetaX, K*(M+1)*D*P
   double* sLog = sThX + (size_t)nth * D;             // GPB*KMAX
   double* sYp = sLog + GPB * KMAX;                   // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int per_group = (2 * K + 3) * T::STR + MMAX + 32 + (D > 0 ? NR * T::STR : 0);
+  const int per_group = (2 * K + 3) * T::STR + MMAX + 32;
   double* gbase = sYp + GPB + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
   double* sChi = gbase + (2 * K + 3) * T::STR;
   double* sRes = sChi + MMAX;
-  T tE{sRes + 32};                                   // D > 0: effective nu / phi of this curve
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
@@ -170,33 +168,18 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
     tU.zero_pads(2 * K + 3, lp);
-    if (D > 0) tE.zero_pads(NR, lp);
     if (lp <= M) sChi[lp] = chi_l;                   // [M] = 0: pad of the 2-unrolled loops
     tS.row(0)[lp] = cv.s;
   }
   ZT();
   __syncthreads();
   ZT();
-  // parameter rows seen by this curve: theta itself, or theta + sum_d x_id thetaX (covariate adjustment)
-  const double* thb = sTh + lp;
-  int ths = P;
-  if (valid && D > 0) {
-    double xv[8];
+  // covariate adjustment: the curve sees theta_r + sum_d x_id thetaX_{r,d}.  The combination is folded into the sums
+  // below (u_k = sum_r coef_r theta_r + sum_d x_d sum_r coef_r thetaX_{r,d}) instead of materialising the K(M+1)
+  // effective rows per curve in LDS: that tile cost 50 KB per workgroup and left one workgroup per CU.
+  double xv[8];
 #pragma unroll
-    for (int dd = 0; dd < 8; ++dd) xv[dd] = (dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
-    for (int r = 0; r < NR; ++r) {
-      double v = 0.0;
-      if (act) {
-        v = sTh[r * P + lp];
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd)
-          if (dd < D) v += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
-      }
-      tE.row(r)[lp] = v;
-    }
-    thb = tE.row(0) + lp;
-    ths = T::STR;
-  }
+  for (int dd = 0; dd < 8; ++dd) xv[dd] = (valid && dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
   double logz_mine = 0.0;
   if (valid) {
     double ucov[KMAX];                 // covariate part of u_k (D > 0)
@@ -204,11 +187,17 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
     {
       // u_k = nu_k + sum_m chi_im phi_km for all k at once: the m loop runs two eigenfunctions per trip with the
       // 2K + 2 LDS reads of a trip in flight together (sChi[M] = 0 pads an odd M; row indices stay inside direction k)
-      double vb[KMAX];
+      double vb[KMAX];                 // the part without covariates
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
-        uk[k] = (k < K && act) ? thb[(size_t)k * (M + 1) * ths] : 0.0;
-        vb[k] = (D > 0 && k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
+        vb[k] = (k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
+        ucov[k] = 0.0;
+        if (D > 0 && k < K && act) {
+          const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
+#pragma unroll
+          for (int dd = 0; dd < 8; ++dd)
+            if (dd < D) ucov[k] += xv[dd] * xb[dd * P];
+        }
       }
       if (MD > 1 && act)
         for (int m = 0; m < M; m += 2) {
@@ -217,19 +206,23 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
 #pragma unroll
           for (int k = 0; k < KMAX; ++k)
             if (k < K) {
-              const double* th = thb + (size_t)k * (M + 1) * ths;
-              uk[k] += c0 * th[r0 * ths] + c1 * th[r1 * ths];
+              const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
+              vb[k] += c0 * tb[r0 * P] + c1 * tb[r1 * P];
               if (D > 0) {
-                const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
-                vb[k] += c0 * tb[r0 * P] + c1 * tb[r1 * P];
+                const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
+                double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd)
+                  if (dd < D) { e0 += xv[dd] * xb[(r0 * D + dd) * P]; e1 += xv[dd] * xb[(r1 * D + dd) * P]; }
+                ucov[k] += c0 * e0 + c1 * e1;
               }
             }
         }
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+      for (int k = 0; k < KMAX; ++k) uk[k] = vb[k] + ucov[k];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
         if (k < K) tU.row(k)[lp] = uk[k];
-        ucov[k] = uk[k] - vb[k];
-      }
     }
     ZT();
     __builtin_amdgcn_wave_barrier();
@@ -377,7 +370,6 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
   const int D = COV ? d.D : 0;
   const int nth = K * (M + 1) * P;
-  const int NR = K * (M + 1);
   const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
   const int ntask = Mu * (Mu + 1) / 2 + Mu + 2;
   double* sTh = smem;
@@ -387,13 +379,12 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
   const int RT = max(M, K);                          // rows of the U / GU tiles (the fused Z update needs K of them)
   const int nres = max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2);
-  const int per_group = (2 * RT + 3) * T::STR + 2 * M + 2 + nres + (D > 0 ? NR * T::STR : 0);
+  const int per_group = (2 * RT + 3) * T::STR + 2 * M + 2 + nres;
   double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + RT * T::STR}, tX{gbase + 2 * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
   double* sChi = gbase + (2 * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
   double* sZn = sChi + M + 1;
   double* sRes = sZn + M + 1;
-  T tE{sRes + nres};
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blk * GPB + grp;
@@ -405,30 +396,14 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   if (valid) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
     tU.zero_pads(2 * RT + 3, lp);
-    if (D > 0) tE.zero_pads(NR, lp);
     if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;
     tX.row(2)[lp] = cv.s;
   }
   __syncthreads();
-  const double* thb = sTh + lp;
-  int ths = P;
-  if (valid && D > 0) {
-    double xv[8];
+  // covariate adjustment folded into the sums below (see k_curve_z): no per-curve tile of effective rows
+  double xv[8];
 #pragma unroll
-    for (int dd = 0; dd < 8; ++dd) xv[dd] = (dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
-    for (int r = 0; r < NR; ++r) {
-      double v = 0.0;
-      if (act) {
-        v = sTh[r * P + lp];
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd)
-          if (dd < D) v += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
-      }
-      tE.row(r)[lp] = v;
-    }
-    thb = tE.row(0) + lp;
-    ths = T::STR;
-  }
+  for (int dd = 0; dd < 8; ++dd) xv[dd] = (valid && dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
   double rss = 0.0;
   double logz_mine = 0.0;
   if (valid) {
@@ -445,20 +420,27 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
       if (zpre) z_proposal_load(c, i, zp);
     }
     // u_m = sum_k Z_k phi_km ;  c0 = sum_k Z_k nu_k + sum_m chi_m u_m
-    double cf = 0.0;
-    if (act) {
+    // row r = (k, mt) of the parameters as this curve sees it: theta_r + sum_d x_d thetaX_{r,d}
+    auto zrow = [&](int mt) {
+      double v = 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
-        if (k < K) cf += Zi[k] * thb[(size_t)k * (M + 1) * ths];
-    }
+        if (k < K) {
+          const int r = k * (M + 1) + mt;
+          double e = sTh[(size_t)r * P + lp];
+          if (D > 0) {
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd)
+              if (dd < D) e += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
+          }
+          v += Zi[k] * e;
+        }
+      return v;
+    };
+    double cf = act ? zrow(0) : 0.0;
     if (MD > 1) {
       for (int m = 0; m < M; ++m) {
-        double um = 0.0;
-        if (act) {
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k)
-            if (k < K) um += Zi[k] * thb[((size_t)k * (M + 1) + m + 1) * ths];
-        }
+        const double um = act ? zrow(m + 1) : 0.0;
         if (m < Mu) tU.row(m)[lp] = um;
         cf += sChi[m] * um;
       }
@@ -640,7 +622,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int STR = LPC + 2 * BW;
   const int D = c.d.D;
   const size_t nth = (size_t)K * (M + 1) * c.d.P;
-  const size_t tileE = (D > 0) ? (size_t)K * (M + 1) * STR : 0;
+  const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
   size_t lds;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
   else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((2 * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);

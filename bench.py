@@ -184,7 +184,9 @@ def main():
         b_alg = algorithmic_bytes_per_iteration(n, P, M, K)
         # dominant kernel = the family with the largest time per iteration; its algorithmic bytes are the
         # data-touching update blocks it implements (n*8*(P^2+P+1) per block)
-        blocks = {"curve_z": 1, "pair_gram": 2, "sweep": 1, "curve_chi": 1, "factor": 0, "loglik": 0}
+        # (k_curve_chi also carries the next iteration's Z update since the fusion: two blocks; "curve_z" is the single
+        #  stand-alone launch at the start of a run)
+        blocks = {"curve_z": 1, "pair_gram": 2, "sweep": 1, "curve_chi": 2, "factor": 0, "loglik": 0}
         roofline = None
         if fams:
             dom = max((k for k in fams if blocks[k] > 0), key=lambda k: fams[k]["ms_per_launch"])
