@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void k_cov_prep(Ctx c, int n_wblocks) {
 // ---- sum_i w_a w_b G_i over the in-group direction pairs, partial over curve chunks: grid (groups, NB2) ----
 // One workgroup = one group of D directions x one chunk of curves: a thread owns one record element e (two "halves"
 // of the chunk side by side when LG <= 128) and keeps the NPG pair accumulators of the group in registers, so a
-// record element is read once for all D(D+1)/2 pairs; the pair weights of the chunk are formed in LDS first.
+// record element is read once for all D(D+1)/2 pairs; the D weights of a curve are read from LDS, the pair weights
+// formed in registers.
 constexpr int NPG_MAX = DMAX_COV * (DMAX_COV + 1) / 2;
 constexpr int W2_CH = 128;       // curves per chunk (NB2 = ceil(n / W2_CH))
 
@@ -104,19 +105,11 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
   const int D = d.D, NPG = c.NPG, LG = d.LG;
   if (!dir2_updated(c, dir2_of(d, g * D))) return;
   const int i0 = cb * W2_CH, nc = min(d.n - i0, W2_CH);
-  double* sW = sm;                       // W2_CH x D
-  double* sPW = sW + W2_CH * D;          // W2_CH x NPG
-  double* sRed = sPW + W2_CH * NPG;      // NPG x 128 (second half's sums)
-  for (int e = tid; e < nc * D; e += 256) {
-    const int cl = e / D, s = e - cl * D;
-    sW[cl * D + s] = c.Wdir[(size_t)(i0 + cl) * c.A2 + g * D + s];
-  }
-  __syncthreads();
-  for (int e = tid; e < W2_CH * NPG; e += 256) {
-    const int cl = e / NPG, q = e - cl * NPG;
-    int u, v;
-    pair_uv(q, u, v);
-    sPW[cl * NPG + q] = (cl < nc) ? sW[cl * D + u] * sW[cl * D + v] : 0.0;
+  double* sW = sm;                       // W2_CH x D weights of the chunk (zero rows beyond its curves)
+  double* sRed = sW + W2_CH * D;         // NPG x 128 (second half's sums)
+  for (int e = tid; e < W2_CH * D; e += 256) {
+    const int cl = e / D, sdir_ = e - cl * D;
+    sW[e] = (cl < nc) ? c.Wdir[(size_t)(i0 + cl) * c.A2 + g * D + sdir_] : 0.0;
   }
   __syncthreads();
   const int LGR = (LG + 63) & ~63;
@@ -140,10 +133,19 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const double* pw = sPW + (cl0 + cb0 + t) * NPG;       // zero rows beyond the chunk's curves
+        // D broadcast LDS reads per curve; the D(D+1)/2 pair weights are formed in registers (one LDS read per FMA
+        // bound the first version of this kernel)
+        const double* wr = sW + (cl0 + cb0 + t) * D;
+        double w[DMAX_COV];
 #pragma unroll
-        for (int q = 0; q < NPG_MAX; ++q)
-          if (q < NPG) acc[q] += pw[q] * r[t];
+        for (int v = 0; v < DMAX_COV; ++v) w[v] = (v < D) ? wr[v] : 0.0;
+#pragma unroll
+        for (int v = 0; v < DMAX_COV; ++v)
+          if (v < D) {
+            const double wv = w[v] * r[t];
+#pragma unroll
+            for (int u = 0; u <= v; ++u) acc[v * (v + 1) / 2 + u] += w[u] * wv;
+          }
       }
     }
     if (NH == 2) {
@@ -769,7 +771,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     hipLaunchKernelGGL(k_cov_prep, dim3(n_wblocks + (n_draws + 255) / 256), dim3(256), 0, st, c, n_wblocks);
   }
   if (do_eta || do_xi) {
-    const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)W2_CH * c.NPG + (size_t)c.NPG * 128) * sizeof(double);
+    const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)c.NPG * 128) * sizeof(double);
     hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2), dim3(256), lds_w2, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
     const size_t lds = (2 * (size_t)PP * PP + PP + d.LG) * sizeof(double);
