@@ -573,7 +573,8 @@ __global__ __launch_bounds__(GT) void k_cov_group(Ctx c, int g_prev, int g_next,
 
 // ---- tau_eta, delta_xi, A_xi, gamma_xi and the chain slots of the covariate blocks: one workgroup ----
 // (the gamma variates arrive as standard draws from k_cov_prep; what is left is sums, products and the A_xi step)
-__global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
+constexpr int HT = 1024;       // threads of k_cov_hyper: its loops are chains of dependent global round trips, so more lanes = fewer trips
+__global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c) {
   extern __shared__ __attribute__((aligned(16))) double hsm[];
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, D = d.D, tid = threadIdx.x;
@@ -587,29 +588,29 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
   double* sDX = sSk + D * K * M;    // (k*D + dd)*M + m    delta_xi
   if (tid == 0) dyn->pend_dir = -1;
   // ---- commit this iteration's eta / Xi draws (k_cov_group leaves them in thetaN) ----
-  for (int e = tid; e < c.A2 * P; e += 256) {
+  for (int e = tid; e < c.A2 * P; e += HT) {
     const int a2 = e / P, p = e - a2 * P;
     const Dir2 a = dir2_of(d, a2);
     if (!dir2_updated(c, a)) continue;
     const size_t ax = (size_t)((a.j * (M + 1) + a.mt) * D + a.dd);
     c.thetaX[ax * P + p] = c.thetaN[ax * P + p];
   }
-  for (int e = tid; e < K * M * D; e += 256) {
+  for (int e = tid; e < K * M * D; e += HT) {
     const int m = e % M, dd = (e / M) % D, k = e / (M * D);
     sDX[e] = c.delta_xi[k + (size_t)K * (m + (size_t)M * dd)];
   }
   if (!d.mv)
-    for (int e = tid; e < P * P; e += 256) sPm[e] = c.Pmat[e];
+    for (int e = tid; e < P * P; e += HT) sPm[e] = c.Pmat[e];
   __syncthreads();
   // ---- tau_eta (UpdateTau.h:75-95; MV :106-124): the K*D quadratic forms side by side, 32 lanes each ----
   if (mask & U_TAU_ETA) {
-    for (int e = tid; e < K * D * P; e += 256) {
+    for (int e = tid; e < K * D * P; e += HT) {
       const int p = e % P, pr = e / P, j = pr / D, i = pr - j * D;
       sE[e] = c.thetaX[(size_t)((j * (M + 1)) * D + i) * P + p];
     }
     __syncthreads();
     const int grp = tid >> 5, l = tid & 31;
-    for (int pr = grp; pr < K * D; pr += 8) {
+    for (int pr = grp; pr < K * D; pr += HT / 32) {
       const double* ev = sE + pr * P;
       double acc = 0.0;
       for (int p = l; p < P; p += 32) {
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
   const bool xi_on = c.covariance_adj && d.MD > 1;
   // ---- delta_xi (UpdateDelta.h:76-124), order (d, k, i): the (d, k) cells are independent of each other ----
   if ((mask & U_DELTA_XI) && xi_on) {
-    for (int e = tid; e < D * K * M; e += 256) {
+    for (int e = tid; e < D * K * M; e += HT) {
       const int dd = e / (K * M), km = e - dd * K * M, k = km / M, m = km - k * M;
       const double* xk = c.thetaX + (size_t)((k * (M + 1) + m + 1) * D + dd) * P;
       const double* gx = c.gamma_xi + (size_t)k * P * D * M + (size_t)P * (dd + (size_t)D * m);
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
   // ---- gamma_xi (UpdateGamma.h:48-72), order (k, i = d, l = p, j = m) ----
   if ((mask & U_GAMMA_XI) && xi_on) {
     const int tot = K * D * P * M;
-    for (int e = tid; e < tot; e += 256) {
+    for (int e = tid; e < tot; e += HT) {
       const int jm = e % M, r1 = e / M, l = r1 % P, r2 = r1 / P, i = r2 % D, k = r2 / D;
       double ph = 1.0;
       for (int j2 = 0; j2 <= jm; ++j2) ph *= sDX[(k * D + i) * M + j2];
@@ -717,20 +718,20 @@ __global__ __launch_bounds__(256) void k_cov_hyper(Ctx c) {
   // ---- chain slots (reference layouts: eta P x D x K; xi / gamma_xi K cubes P x D x M; ...) ----
   {
     double* s_eta = c.c_eta + (size_t)slot * P * D * K;
-    for (int e = tid; e < P * D * K; e += 256) {
+    for (int e = tid; e < P * D * K; e += HT) {
       const int p = e % P, r = e / P, dd = r % D, k = r / D;
       s_eta[e] = c.thetaX[(size_t)((k * (M + 1)) * D + dd) * P + p];
     }
     double* s_xi = c.c_xi + (size_t)slot * K * P * D * M;
     double* s_gx = c.c_gamma_xi + (size_t)slot * K * P * D * M;
-    for (int e = tid; e < K * P * D * M; e += 256) {
+    for (int e = tid; e < K * P * D * M; e += HT) {
       const int p = e % P, r = e / P, dd = r % D, r2 = r / D, m = r2 % M, k = r2 / M;
       s_xi[e] = c.thetaX[(size_t)((k * (M + 1) + m + 1) * D + dd) * P + p];
       s_gx[e] = c.gamma_xi[e];
     }
-    for (int e = tid; e < K * D; e += 256) c.c_tau_eta[(size_t)slot * K * D + e] = c.tau_eta[e];
-    for (int e = tid; e < K * M * D; e += 256) c.c_delta_xi[(size_t)slot * K * M * D + e] = c.delta_xi[e];
-    for (int e = tid; e < K * 2 * D; e += 256) c.c_A_xi[(size_t)slot * K * 2 * D + e] = c.A_xi[e];
+    for (int e = tid; e < K * D; e += HT) c.c_tau_eta[(size_t)slot * K * D + e] = c.tau_eta[e];
+    for (int e = tid; e < K * M * D; e += HT) c.c_delta_xi[(size_t)slot * K * M * D + e] = c.delta_xi[e];
+    for (int e = tid; e < K * 2 * D; e += HT) c.c_A_xi[(size_t)slot * K * 2 * D + e] = c.A_xi[e];
   }
 }
 
@@ -787,7 +788,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
   }
   launch_group(c, g_prev, -1, par, st);      // the last group's draws, and the residual sums for the log-likelihood
   const size_t lds_h = ((size_t)d.K * d.D * d.P + (size_t)d.P * d.P + 2 * (size_t)d.D * d.K * d.M) * sizeof(double);
-  hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(256), lds_h, st, c);
+  hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(HT), lds_h, st, c);
 }
 
 template <int BW>
