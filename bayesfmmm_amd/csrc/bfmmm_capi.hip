@@ -756,20 +756,31 @@ extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_i
 extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int iter, int N_t, double beta_N_t,
                                          uint64_t seed, uint32_t chain, double* logA_out, int* accepted_out) {
   if (!h) return fail("bfmmm_tempered_transition: null handle");
-  if (h->c.d.D > 0) return fail("bfmmm_tempered_transition: covariate-adjusted models are not supported");
   if (N_t < 1 || iter < h->slot_base || iter - h->slot_base >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const Ctx& c = h->c;
   const Dims& d = c.d;
   const size_t n_th = (size_t)d.K * (d.M + 1) * d.P, n_chi = (size_t)d.n * d.M, n_Z = (size_t)d.n * d.K,
                n_dl = (size_t)d.K * d.M, n_A = (size_t)d.K * 2, n_g = (size_t)d.K * d.P * d.M;
-  if (!h->tt_save) { if (dalloc(h, &h->tt_save, n_th + n_chi + n_Z + n_dl + n_A + n_g)) return 1; }
+  // covariate blocks (BFMMM.h:4912-4940): eta / xi rows, tau_eta, gamma_xi, delta_xi, A_xi
+  const size_t Dc = (size_t)d.D;
+  const size_t n_tx = (size_t)d.K * (d.M + 1) * Dc * d.P, n_te = (size_t)d.K * Dc, n_gx = (size_t)d.K * d.P * Dc * d.M,
+               n_dx = (size_t)d.K * d.M * Dc, n_ax = (size_t)d.K * 2 * Dc;
+  if (!h->tt_save) { if (dalloc(h, &h->tt_save, n_th + n_chi + n_Z + n_dl + n_A + n_g + n_tx + n_te + n_gx + n_dx + n_ax + 8)) return 1; }
   double* sv = h->tt_save;
   double* sv_th = sv; double* sv_chi = sv_th + n_th; double* sv_Z = sv_chi + n_chi; double* sv_dl = sv_Z + n_Z;
   double* sv_A = sv_dl + n_dl; double* sv_g = sv_A + n_A;
-  auto d2d = [&](double* dst, const double* src, size_t cnt) { return hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->st); };
+  double* sv_tx = sv_g + n_g; double* sv_te = sv_tx + n_tx; double* sv_gx = sv_te + n_te; double* sv_dx = sv_gx + n_gx;
+  double* sv_ax = sv_dx + n_dx;
+  auto d2d = [&](double* dst, const double* src, size_t cnt) {
+    return cnt ? hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->st) : hipSuccess;
+  };
   HIPCHK(d2d(sv_th, c.theta, n_th)); HIPCHK(d2d(sv_chi, c.chi, n_chi)); HIPCHK(d2d(sv_Z, c.Z, n_Z));
   HIPCHK(d2d(sv_dl, c.delta, n_dl)); HIPCHK(d2d(sv_A, c.Aa, n_A)); HIPCHK(d2d(sv_g, c.gamma, n_g));
+  if (Dc > 0) {
+    HIPCHK(d2d(sv_tx, c.thetaX, n_tx)); HIPCHK(d2d(sv_te, c.tau_eta, n_te)); HIPCHK(d2d(sv_gx, c.gamma_xi, n_gx));
+    HIPCHK(d2d(sv_dx, c.delta_xi, n_dx)); HIPCHK(d2d(sv_ax, c.A_xi, n_ax));
+  }
   Dyn dyn0;
   if (dyn_get(h, dyn0)) return 1;
   // geometric ladder, BFMMM.h:1452-1460 (the loop overwrites the last rung: ladder[i] = geom_mult^i)
@@ -807,6 +818,10 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
   } else {
     HIPCHK(d2d(c.theta, sv_th, n_th)); HIPCHK(d2d(c.chi, sv_chi, n_chi)); HIPCHK(d2d(c.Z, sv_Z, n_Z));
     HIPCHK(d2d(c.delta, sv_dl, n_dl)); HIPCHK(d2d(c.Aa, sv_A, n_A)); HIPCHK(d2d(c.gamma, sv_g, n_g));
+    if (Dc > 0) {
+      HIPCHK(d2d(c.thetaX, sv_tx, n_tx)); HIPCHK(d2d(c.tau_eta, sv_te, n_te)); HIPCHK(d2d(c.gamma_xi, sv_gx, n_gx));
+      HIPCHK(d2d(c.delta_xi, sv_dx, n_dx)); HIPCHK(d2d(c.A_xi, sv_ax, n_ax));
+    }
     dyn0.zprep_valid = 0;        // the prepared Z proposals were overwritten by the tempered sweeps
     dyn0.piprep_valid = 0;
     if (dyn_put(h, dyn0)) return 1;

@@ -486,8 +486,6 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   if (a->beta_N_t <= 0 || a->beta_N_t > 1) return efail("'beta_N_t' must be between 0 and 1");
   if (a->N_t < 1) return efail("'N_t' must be a positive integer");
   if (a->n_temp_trans < 0) return efail("'n_temp_trans' must be a non-negative integer");
-  if (a->n_temp_trans > 0 && a->X)
-    return efail("tempered transitions are implemented for the models without covariates only");
   if (a->thinning_num <= 0) return efail("'thinning_num' must be a positive integer");            // UserFunctions.cpp:1472-1474
   if (a->r_stored_iters < 0) return efail("'r_stored_iters' must be a non-negative integer");      // :1484-1486
   const int T = a->tot_mcmc_iters, K = a->K, M = a->n_eigen, n = a->n_funct;

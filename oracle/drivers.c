@@ -167,6 +167,7 @@ void orc_beta_ladder(int N_t, double beta_N_t, double* ladder) {
 
 /* calculatePZeta, CalculateTTAcceptance.h:22-51 (state = slot `iter` of the TT arrays) */
 double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_chain* c) {
+  if (d->D > 0) return orc_calculatePZetaCov(d, beta_i, iter, c);     /* CalculateTTAcceptance.h:195, :296 */
   const int n = d->n, K = d->K, P = d->P, M = d->M;
   const double* nu = c->nu + (size_t)K * P * iter;
   const double* Phi = c->Phi + (size_t)K * P * M * iter;
@@ -237,7 +238,14 @@ static double* dalloc0(size_t n) { return (double*)calloc(n ? n : 1, sizeof(doub
  * Keyed RNG: (seed, chain, iteration i, tt_step l) for the tempered sweeps, (.., tt_step 0, UPD_TT_ACC) for the test. */
 void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int i, int N_t,
                   double beta_N_t, orc_chain* c, double* logA_out, int* accepted_out) {
-  const int n = d->n, K = d->K, P = d->P, M = d->M, T = c->T;
+  orc_tt_block_cov(d, h, seed, chain, i, N_t, beta_N_t, 0, c, logA_out, accepted_out);
+}
+
+/* covariate-adjusted drivers: BFMMM.h:4313-4440 (MeanAdj), :4897-5084 (Mean_CovAdj); MV :5880-6050, :6420-6590.  The
+ * tempered sweep adds eta, tau_eta (and, with covariance adjustment, Xi, delta_xi, A_xi, gamma_xi) after chi. */
+void orc_tt_block_cov(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int i, int N_t,
+                      double beta_N_t, int covariance_adj, orc_chain* c, double* logA_out, int* accepted_out) {
+  const int n = d->n, K = d->K, P = d->P, M = d->M, T = c->T, D = d->D;
   const int L = 2 * N_t + 1;
   double* ladder = dalloc0((size_t)N_t);
   orc_beta_ladder(N_t, beta_N_t, ladder);
@@ -249,6 +257,12 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
   tt.nu = dalloc0(s_nu * L); tt.chi = dalloc0(s_chi * L); tt.Z = dalloc0(s_Z * L); tt.pi = dalloc0(s_pi * L);
   tt.alpha3 = dalloc0(L); tt.delta = dalloc0(s_dl * L); tt.A = dalloc0(s_A * L); tt.sigma = dalloc0(L);
   tt.tau = dalloc0((size_t)L * K); tt.gamma = dalloc0(s_g * L); tt.Phi = dalloc0(s_g * L); tt.loglik = dalloc0(L);
+  const size_t s_eta = (size_t)P * D * K, s_te = (size_t)K * D, s_xi = (size_t)K * P * D * M, s_dx = (size_t)K * M * D,
+               s_ax = (size_t)K * 2 * D;
+  if (D > 0) {
+    tt.eta = dalloc0(s_eta * L); tt.tau_eta = dalloc0(s_te * L); tt.xi = dalloc0(s_xi * L); tt.gamma_xi = dalloc0(s_xi * L);
+    tt.delta_xi = dalloc0(s_dx * L); tt.A_xi = dalloc0(s_ax * L);
+  }
   /* initialize placeholders: slots 0 and 1 <- slot i (BFMMM.h:1557-1581) */
   for (int s = 0; s < 2; ++s) {
     memcpy(tt.nu + s_nu * s, c->nu + s_nu * i, sizeof(double) * s_nu);
@@ -262,8 +276,17 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
     memcpy(tt.A + s_A * s, c->A + s_A * i, sizeof(double) * s_A);
     for (int k = 0; k < K; ++k) tt.tau[s + (size_t)L * k] = c->tau[i + (size_t)T * k];
     tt.alpha3[s] = c->alpha3[i];
+    if (D > 0) {              /* BFMMM.h:4912-4940 */
+      memcpy(tt.eta + s_eta * s, c->eta + s_eta * i, sizeof(double) * s_eta);
+      memcpy(tt.tau_eta + s_te * s, c->tau_eta + s_te * i, sizeof(double) * s_te);
+      memcpy(tt.xi + s_xi * s, c->xi + s_xi * i, sizeof(double) * s_xi);
+      memcpy(tt.gamma_xi + s_xi * s, c->gamma_xi + s_xi * i, sizeof(double) * s_xi);
+      memcpy(tt.delta_xi + s_dx * s, c->delta_xi + s_dx * i, sizeof(double) * s_dx);
+      memcpy(tt.A_xi + s_ax * s, c->A_xi + s_ax * i, sizeof(double) * s_ax);
+    }
   }
   double* tilde_tau = dalloc0((size_t)K * M);
+  double* tilde_tau_xi = dalloc0((size_t)K * M * (D > 0 ? D : 1));
   int temp_ind = 0;
   for (int l = 1; l < L; ++l) {              /* BFMMM.h:1586-1634 */
     orc_rng r = {seed, chain, (uint32_t)i, (uint32_t)l};
@@ -280,6 +303,19 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
     orc_updateTau(d, &r, l, L, h->alpha_nu, h->beta_nu, &tt);
     orc_updateSigma(d, &r, bl, 1, l, L, h->alpha_0, h->beta_0, &tt);
     orc_updateChi(d, &r, bl, l, L, &tt);
+    if (D > 0) {              /* BFMMM.h:4991-5020 */
+      orc_updateEta(d, &r, bl, l, L, &tt);
+      orc_updateTauEta(d, &r, l, L, h->alpha_eta, h->beta_eta, &tt);
+      if (covariance_adj) {
+        orc_tilde_tau_xi(K, M, D, tt.delta_xi + s_dx * l, tilde_tau_xi);
+        orc_updateXi(d, &r, bl, l, L, tilde_tau_xi, &tt);
+        orc_updateDeltaXi(d, &r, l, L, &tt);
+        orc_updateAXi(d, &r, l, L, h, &tt);
+        orc_updateGammaXi(d, &r, l, L, h->nu_1, &tt);
+      } else if (l + 1 < L) {
+        memcpy(tt.xi + s_xi * (l + 1), tt.xi + s_xi * l, sizeof(double) * s_xi);
+      }
+    }
     if (l < N_t) temp_ind = temp_ind + 1;
     if (l > N_t) temp_ind = temp_ind - 1;
   }
@@ -301,6 +337,14 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
     memcpy(c->A + s_A * i, tt.A + s_A * f, sizeof(double) * s_A);
     for (int k = 0; k < K; ++k) c->tau[i + (size_t)T * k] = tt.tau[f + (size_t)L * k];
     c->alpha3[i] = tt.alpha3[f];
+    if (D > 0) {              /* BFMMM.h:5043-5052 */
+      memcpy(c->eta + s_eta * i, tt.eta + s_eta * f, sizeof(double) * s_eta);
+      memcpy(c->tau_eta + s_te * i, tt.tau_eta + s_te * f, sizeof(double) * s_te);
+      memcpy(c->delta_xi + s_dx * i, tt.delta_xi + s_dx * f, sizeof(double) * s_dx);
+      memcpy(c->A_xi + s_ax * i, tt.A_xi + s_ax * f, sizeof(double) * s_ax);
+      memcpy(c->xi + s_xi * i, tt.xi + s_xi * f, sizeof(double) * s_xi);
+      memcpy(c->gamma_xi + s_xi * i, tt.gamma_xi + s_xi * f, sizeof(double) * s_xi);
+    }
   }
   /* initialize next state (BFMMM.h:1660-1671): every block except gamma */
   if (i + 1 < T) {
@@ -314,10 +358,19 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
     for (int k = 0; k < K; ++k) c->tau[(i + 1) + (size_t)T * k] = c->tau[i + (size_t)T * k];
     memcpy(c->Phi + s_g * (i + 1), c->Phi + s_g * i, sizeof(double) * s_g);
     c->alpha3[i + 1] = c->alpha3[i];
+    if (D > 0) {              /* BFMMM.h:5070-5079: here gamma_xi IS carried (gamma is not) */
+      memcpy(c->eta + s_eta * (i + 1), c->eta + s_eta * i, sizeof(double) * s_eta);
+      memcpy(c->tau_eta + s_te * (i + 1), c->tau_eta + s_te * i, sizeof(double) * s_te);
+      memcpy(c->delta_xi + s_dx * (i + 1), c->delta_xi + s_dx * i, sizeof(double) * s_dx);
+      memcpy(c->A_xi + s_ax * (i + 1), c->A_xi + s_ax * i, sizeof(double) * s_ax);
+      memcpy(c->xi + s_xi * (i + 1), c->xi + s_xi * i, sizeof(double) * s_xi);
+      memcpy(c->gamma_xi + s_xi * (i + 1), c->gamma_xi + s_xi * i, sizeof(double) * s_xi);
+    }
   }
   if (logA_out) *logA_out = logA;
   if (accepted_out) *accepted_out = accepted;
-  free(tilde_tau); free(ladder);
+  free(tilde_tau); free(tilde_tau_xi); free(ladder);
+  free(tt.eta); free(tt.tau_eta); free(tt.xi); free(tt.gamma_xi); free(tt.delta_xi); free(tt.A_xi);
   free(tt.nu); free(tt.chi); free(tt.Z); free(tt.pi); free(tt.alpha3); free(tt.delta); free(tt.A); free(tt.sigma);
   free(tt.tau); free(tt.gamma); free(tt.Phi); free(tt.loglik);
 }
@@ -327,13 +380,19 @@ void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t
  * iteration (NaN / -1 where no block ran). */
 void orc_run_warm_tt(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int T, int first_iter,
                      int n_iter, int N_t, int n_temp_trans, double beta_N_t, orc_chain* c, double* logA, int* accepted) {
+  orc_run_warm_tt_cov(d, h, seed, chain, T, first_iter, n_iter, N_t, n_temp_trans, beta_N_t, 0, c, logA, accepted);
+}
+
+void orc_run_warm_tt_cov(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int T, int first_iter,
+                         int n_iter, int N_t, int n_temp_trans, double beta_N_t, int covariance_adj, orc_chain* c,
+                         double* logA, int* accepted) {
   for (int i = first_iter; i < first_iter + n_iter && i < T; ++i) {
-    orc_run_sweeps(d, h, seed, chain, ORC_SWEEP_WARM, 0, T, i, 1, c);
+    orc_run_sweeps(d, h, seed, chain, ORC_SWEEP_WARM, covariance_adj, T, i, 1, c);
     if (logA) logA[i] = NAN;
     if (accepted) accepted[i] = -1;
     if (n_temp_trans > 0 && (i % n_temp_trans) == 0 && i > 0) {
       double la; int acc;
-      orc_tt_block(d, h, seed, chain, i, N_t, beta_N_t, c, &la, &acc);
+      orc_tt_block_cov(d, h, seed, chain, i, N_t, beta_N_t, covariance_adj, c, &la, &acc);
       if (logA) logA[i] = la;
       if (accepted) accepted[i] = acc;
       c->loglik[i] = orc_calcLikelihood(d, i, c);       /* BFMMM.h:1670 (after the block) */

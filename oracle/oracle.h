@@ -163,11 +163,17 @@ enum { ORC_SWEEP_NU_Z = 0, ORC_SWEEP_THETA = 1, ORC_SWEEP_WARM = 2 };
 /* tempered transitions (functional model, D == 0): BFMMM.h:1452-1460, :1556-1672; CalculateTTAcceptance.h:22-97 */
 void orc_beta_ladder(int N_t, double beta_N_t, double* ladder);
 double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_chain* c);
+double orc_calculatePZetaCov(const orc_data* d, double beta_i, int iter, const orc_chain* c);   /* updates.c */
 double orc_CalculateTTAcceptance(const orc_data* d, int N_t, const double* beta, const orc_chain* tt);
 void orc_tt_block(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int i, int N_t,
                   double beta_N_t, orc_chain* c, double* logA_out, int* accepted_out);
 void orc_run_warm_tt(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int T, int first_iter,
                      int n_iter, int N_t, int n_temp_trans, double beta_N_t, orc_chain* c, double* logA, int* accepted);
+void orc_tt_block_cov(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int i, int N_t,
+                      double beta_N_t, int covariance_adj, orc_chain* c, double* logA_out, int* accepted_out);
+void orc_run_warm_tt_cov(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain, int T, int first_iter,
+                         int n_iter, int N_t, int n_temp_trans, double beta_N_t, int covariance_adj, orc_chain* c,
+                         double* logA, int* accepted);
 void orc_run_sweeps(const orc_data* d, const orc_hyper* h, uint64_t seed, uint32_t chain,
                     int sweep, int covariance_adj, int T, int first_iter, int n_iter, orc_chain* c);
 /* initial state of BFMMM_Nu_Z (BFMMM.h:1039-1071) / BFMMM_Theta (1210-1250) */

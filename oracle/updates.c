@@ -648,6 +648,33 @@ double orc_calcLikelihood(const orc_data* d, int iter, const orc_chain* c) {
   return log_lik;
 }
 
+/* calculatePZetaCovariateAdj / calculatePZetaMVCovariateAdj, CalculateTTAcceptance.h:195-232, :296-330: the tempered
+ * log-likelihood of state `iter`, per observation, with the covariate-adjusted mean (xi read at the state's own slot:
+ * the documented deviation from the reference's wrong-index reads). */
+double orc_calculatePZetaCov(const orc_data* d, double beta_i, int iter, const orc_chain* c) {
+  DIMS;
+  (void)K; (void)M; (void)D;
+  const double sigma = c->sigma[iter];
+  double logAcceptance = 0;
+  for (int i = 0; i < n; ++i) {
+    const int ni = NI(i);
+    if (d->mv) {
+      double ss = 0.0;
+      for (int l = 0; l < ni; ++l) {
+        const double rr = YOBS(i, l) - fitted_skipzero(d, c, iter, i, BROW(i, l));
+        ss += rr * rr;
+      }
+      logAcceptance = logAcceptance + ((-(beta_i / 2) * log(sigma) * P) - (beta_i / (2 * sigma)) * ss);
+      continue;
+    }
+    for (int l = 0; l < ni; ++l) {
+      const double res = YOBS(i, l) - fitted_skipzero(d, c, iter, i, BROW(i, l));
+      logAcceptance = logAcceptance + ((-(beta_i / 2) * log(sigma)) - (beta_i / (2 * sigma)) * (res * res));
+    }
+  }
+  return logAcceptance;
+}
+
 /* ========================= covariate-adjusted extras ======================================= */
 
 /* updateEta, UpdateEta.h:28-94 (d outer, j inner; pinv + symmetrise; Tempered :116-185) */

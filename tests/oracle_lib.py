@@ -229,17 +229,18 @@ def run_sweeps(model, hyper, chain, sweep, n_iter=None, seed=1, chain_id=0, cova
 SWEEP_NU_Z, SWEEP_THETA, SWEEP_WARM = 0, 1, 2
 
 
-def run_warm_tt(model, hyper, chain, N_t, n_temp_trans, beta_N_t, n_iter=None, seed=1, chain_id=0, first_iter=0):
+def run_warm_tt(model, hyper, chain, N_t, n_temp_trans, beta_N_t, n_iter=None, seed=1, chain_id=0, first_iter=0,
+                covariance_adj=False):
     """BFMMM_MTT_warm_start with tempered transitions (BFMMM.h:1502-1672); returns (logA, accepted) per iteration."""
     n_iter = chain.T if n_iter is None else n_iter
     logA = np.full(chain.T, np.nan)
     acc = np.full(chain.T, -1, dtype=np.int32)
-    f = lib().orc_run_warm_tt
+    f = lib().orc_run_warm_tt_cov
     f.restype = None
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                  C.c_void_p, np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.int32)]
+                  C.c_int, C.c_void_p, np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.int32)]
     f(C.addressof(model.data), C.addressof(hyper), seed, chain_id, chain.T, first_iter, n_iter, N_t, n_temp_trans,
-      float(beta_N_t), C.addressof(chain.c), logA, acc)
+      float(beta_N_t), int(covariance_adj), C.addressof(chain.c), logA, acc)
     return logA, acc
 
 

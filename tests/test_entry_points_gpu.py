@@ -134,5 +134,10 @@ def test_three_stage_pipeline_covariate_adjusted(example, covariance_adj):
     mcmc = api.BFMMM_warm_start(T, K, *common, est1, est2, X=X, covariance_adj=covariance_adj, seed=5)
     assert mcmc["eta"].shape == (P, D, K, T + 1) and np.isfinite(mcmc["loglik"][:T]).all()
     assert ("xi" in mcmc) == covariance_adj
+    # tempered transitions of the covariate-adjusted drivers (BFMMM.h:4313-4440, :4897-5084)
+    tt = api.BFMMM_warm_start(T, K, *common, est1, est2, X=X, covariance_adj=covariance_adj, seed=5,
+                              n_temp_trans=40, N_t=2, beta_N_t=0.8)
+    assert tt["tt_blocks"] == 3 and np.isfinite(tt["loglik"][:T]).all()
+    np.testing.assert_array_equal(tt["eta"][..., :40], mcmc["eta"][..., :40])
     with pytest.raises(Exception, match="'X' must be have 'n_funct' number of rows"):
         api.BFMMM_Nu_Z_multiple_try(T, 1, K, *common, X=X[:10])

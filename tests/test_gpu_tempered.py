@@ -60,3 +60,33 @@ def test_ladder_and_argument_checks(bf):
     sim, model, ch, smp = _setup(seed=3, T=4)
     with pytest.raises(bf._lib.BfmmmError):
         smp.tempered_transition(bf.sampler.SWEEP_WARM, 7, 2, 0.5)
+
+
+@pytest.mark.parametrize("covariance_adj,mv", [(False, False), (True, False), (True, True)])
+def test_tempered_transitions_with_covariates_match_oracle(bf, covariance_adj, mv):
+    """The tempered block of the covariate-adjusted drivers (BFMMM.h:4313-4440 MeanAdj, :4897-5084 Mean_CovAdj; MV
+    :5880-6050, :6420-6590; CalculateTTAcceptance.h:195-290, :296-385): eta, tau_eta (and Xi, delta_xi, A_xi, gamma_xi)
+    are tempered, saved and restored with the rest of the state."""
+    S = bf.sampler
+    T, N_t, ntt, bN = 7, 3, 3, 0.6
+    if mv:
+        from test_gpu_multivariate import setup_mv_cov
+        dims, model, ch, smp = setup_mv_cov(seed=31, T=T, covariance_adj=covariance_adj)
+        K = dims["K"]
+    else:
+        from test_gpu_covariates import setup as setup_cov
+        sim, model, ch, smp = setup_cov(seed=23, T=T, covariance_adj=covariance_adj)
+        K = sim["K"]
+    h = O.make_hyper(K)
+    logA_ref, acc_ref = O.run_warm_tt(model, h, ch, N_t, ntt, bN, seed=8, covariance_adj=covariance_adj)
+    mask = S.SWEEP_WARM | S.COV_MEAN | (S.COV_XI if covariance_adj else 0)
+    smp.run(mask, 4, first_iter=0, seed=8)
+    la3, a3 = smp.tempered_transition(mask, 3, N_t, bN, seed=8)
+    smp.run(mask, 3, first_iter=4, seed=8)
+    la6, a6 = smp.tempered_transition(mask, 6, N_t, bN, seed=8)
+    for la, a, i in ((la3, a3, 3), (la6, a6, 6)):
+        assert int(a) == acc_ref[i] and abs(la - logA_ref[i]) < 1e-6 * max(1.0, abs(logA_ref[i])), (i, la, logA_ref[i])
+    names = ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "eta", "tau_eta", "loglik"]
+    names += ["xi", "delta_xi", "A_xi", "gamma_xi"] if covariance_adj else []
+    for nm in names:
+        assert rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm))) < 2e-6, nm
