@@ -114,6 +114,28 @@ template <int PP>
 __device__ inline bool factor_core(double* S, double* X, const double* zv, int P, int bw, double* Cg, double* Lg,
                                    double* Lz_out, int tid) {
   bool bad = false;
+  if (bw == 0) {
+    // diagonal precision (multivariate model): C = diag(1 / s_pp), chol_lower(C) = diag(1 / sqrt(s_pp)), L z likewise --
+    // no recursion at all.  (1 / sqrt by the same estimate + two Newton steps as the general path, so the factor is the
+    // same function of the pivot.)
+    for (int e = tid; e < P * P; e += 256) {
+      const int p = e % P, q = e / P;
+      double cv = 0.0, lv = 0.0;
+      if (p == q) {
+        const double dk = S[p + PP * p];
+        double rk = __builtin_amdgcn_rsq(dk);
+        rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+        rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+        if (!(dk > 0.0)) bad = true;
+        lv = rk;
+        cv = rk * rk;
+        Lz_out[p] = rk * zv[p];
+      }
+      Cg[q + (size_t)P * p] = cv;
+      if (Lg) Lg[p + (size_t)P * q] = lv;
+    }
+    return __syncthreads_or(bad ? 1 : 0) != 0;       // every thread reports (the callers test thread 0)
+  }
   if (tid < 64) {
     switch (bw) {
       case 0: bad = factor_wave<PP, 0>(S, X, zv, P, Lz_out, tid); break;

@@ -574,7 +574,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
   double* red = dlp + PMAX + 2 * BWMAX;      // 32
   // direct != 0: the column blocks and C_a do not fit the LDS double buffer (A*LG + P*P > 6144 doubles or the total
   // beyond 160 KB): no staging, every step reads them from L2 (slower per step, but no size limit)
-  const int pf_len = direct ? 0 : A * LG + P * P;
+  // diagonal model (multivariate: G_i = I and priors I/tau, diag(tilde_tau gamma)): every H block and every C_a is
+  // diagonal, so only the diagonal of C_a is staged and phase A is one multiply per coordinate
+  const bool diag = (BW == 0 && d.BWP == 0);
+  const int csz = diag ? P : P * P;
+  const int pf_len = direct ? 0 : A * LG + csz;
   double* pbuf0 = red + 32;
   double* pbuf1 = pbuf0 + pf_len;
   int* htab = (int*)(pbuf1 + pf_len);        // A x A : H row of block (b, a)
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
     for (int k = 0; k < NPF; ++k) {
       const int hb = max(pf_b[k], 0);
       const size_t offH = (size_t)htab[hb * A + a] * LG + pf_off[k];
-      const size_t offC = (size_t)a * P * P + pf_off[k];
+      const size_t offC = (size_t)a * P * P + (diag ? (size_t)pf_off[k] * (P + 1) : (size_t)pf_off[k]);
       const double* src = (pf_b[k] == -1) ? (c.Cmat + offC) : (c.H + ((pf_b[k] >= 0) ? offH : 0));
       preg[k] = *src;
     }
@@ -626,6 +630,22 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
       if (pf_b[k] >= -1) buf[tid + SW_THREADS * k] = preg[k];
   };
   if (n_steps > 0) {
+    // H and C were written by other XCDs (k_pg_reduce, k_factor): a first touch costs a trip to memory, several times a
+    // step of the chain.  Touch both once with fire-and-forget loads (one 4-byte load per 128-byte line) so that the
+    // per-step prefetch only sees L2 hits.
+    {
+      int w0 = 0;
+      auto touch = [&](const double* src, size_t count) {
+        const size_t nl = (count * 8 + 127) / 128;
+        for (size_t x = tid; x < nl; x += SW_THREADS) {
+          const uint32_t o = (uint32_t)(x * 128);
+          asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
+        }
+      };
+      touch(c.H, (size_t)d.R * LG);
+      touch(c.Cmat, (size_t)A * P * P);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
+    }
     const int a0 = step_dir(d, 0, n_phi);
     if (!direct) { pf_load(a0); pf_store(pbuf0); }
     if (tid < P) rhs[tid] = f * (r[a0 * P + tid] + hq[a0 * P + tid]);
@@ -639,6 +659,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
     const double* Cg = direct ? c.Cmat + (size_t)a * P * P : buf + (size_t)A * LG;
     if (more && !direct) pf_load(an);
     // phase A: new = C rhs + L z
+    if (diag) {
+      if (tid < P) {
+        const double cd = direct ? Cg[(size_t)tid * (P + 1)] : Cg[tid];
+        const double nw = cd * rhs[tid] + lz[a * P + tid];
+        dlp[BW + tid] = nw - th[a * PS + BW + tid];
+        th[a * PS + BW + tid] = nw;
+      }
+    } else
     for (int p = tid >> 3; p < P; p += SW_THREADS / 8) {
       const int seg = tid & 7;
       double acc = 0.0;
@@ -1126,7 +1154,8 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     }
     return 0;
   }
-  size_t pf_len = (size_t)d.A * d.LG + (size_t)d.P * d.P;
+  const bool diag = (d.BW == 0 && d.BWP == 0);
+  size_t pf_len = (size_t)d.A * d.LG + (diag ? (size_t)d.P : (size_t)d.P * d.P);
   auto lds_for = [&](size_t pf) {
     const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf;
     return doubles * sizeof(double) + (size_t)d.A * d.A * sizeof(int) + 16;

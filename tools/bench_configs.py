@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Times BASELINE.json configs[3] (multivariate: n = 8192, dim = 50, K = 4, M = 8, warm-start sweep of
+BFMMM_MTT_warm_startMV, BFMMM.h:2597-2650) and configs[4] (BFMMM_Nu_Z_multiple_try semantics: 8 independent chains of
+the reduced Nu_Z sweep -- Z, pi, alpha_3, nu, tau, sigma^2, loglik; Phi = chi = 0; BFMMM.h:1073-1113 -- on the config-2
+data, all on ONE GPU here) on one MI355X.  Not the bench line (bench.py measures configs[1]).
+
+  python tools/bench_configs.py --config 4|5 [--steps N] [--no-graph]
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def config4(args):
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    rng = np.random.default_rng(4)
+    n, P, K, M = 8192, 50, 4, 8
+    nu = rng.standard_normal((K, P)) * 2
+    Phi = np.stack([(M - m) / M * 0.5 * rng.standard_normal((K, P)) for m in range(M)], axis=2)
+    chi = rng.standard_normal((n, M))
+    Z = rng.dirichlet(np.ones(K), size=n)
+    Z = np.clip(Z, 1e-10, None); Z /= Z.sum(axis=1, keepdims=True)
+    Y = Z @ nu + np.einsum("ik,im,kpm->ip", Z, chi, Phi) + np.sqrt(0.001) * rng.standard_normal((n, P))
+    T = args.steps + args.warmup
+    cfg = bf.default_config(model=bf.MODEL_MULTIVARIATE, K=K, n_eigen=M, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, Y)
+    smp.set_state(nu=nu, Phi=Phi, chi=chi, Z=Z, pi=np.full(K, 1.0 / K), alpha_3=[10.0], delta=np.ones((K, M)),
+                  A=np.ones((K, 2)), gamma=np.ones((K, P, M)), tau=np.ones(K), sigma_sq=[0.001])
+    if args.no_graph:
+        smp.set_profile(True)
+    smp.run(S.SWEEP_WARM, args.warmup, seed=2)
+    t0 = time.perf_counter()
+    smp.run(S.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=2)
+    dt = (time.perf_counter() - t0) / args.steps
+    b_alg = 5 * n * P * 8 + 8 * n * (2 * M + 2 * K)       # SURVEY.md 8(d), config 4 (G = I: the per-row data is y_i)
+    return {"workload": "config 4: BMVMMM warm-start sweep, N=8192, dim=50, K=4, M=8", "steps": args.steps,
+            "ms_per_sweep": dt * 1e3, "iterations_per_s": 1.0 / dt, "algorithmic_GBps": b_alg / dt / 1e9,
+            "hbm_frac": b_alg / dt / 8e12, "sigma_sq_last": float(smp.get_chain("sigma_sq")[T - 1])}
+
+
+def config5(args):
+    import bayesfmmm_amd as bf
+    from bench import make_config2
+    S = bf.sampler
+    w = make_config2()
+    C = 8
+    T = args.steps + args.warmup
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=3, tot_mcmc_iters=T)
+    smps = [bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"]) for _ in range(C)]
+    for q, s_ in enumerate(smps):
+        s_.init_state(0, 1, chain=q)                        # BFMMM.h:1039-1071
+        if args.no_graph:
+            s_.set_profile(True)
+        s_.run(S.SWEEP_NU_Z, args.warmup, seed=1, chain=q, phi_chi_zero=True)
+    t0 = time.perf_counter()
+    smps[0].run(S.SWEEP_NU_Z, args.steps, first_iter=args.warmup, seed=1, chain=0, phi_chi_zero=True)
+    dt1 = (time.perf_counter() - t0) / args.steps
+
+    def work(q):
+        smps[q].run(S.SWEEP_NU_Z, args.steps, first_iter=args.warmup, seed=1, chain=q, phi_chi_zero=True)
+    ths = [threading.Thread(target=work, args=(q,)) for q in range(1, C)]
+    t1 = time.perf_counter()
+    [t_.start() for t_ in ths]
+    [t_.join() for t_ in ths]
+    dt7 = time.perf_counter() - t1
+    n, P = w["n"], w["P"]
+    b_alg = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * w["K"]      # 3 blocks per chain-iteration
+    return {"workload": "config 5: Nu_Z sweep (BFMMM_Nu_Z_multiple_try chains) on the config-2 data, one GPU",
+            "steps": args.steps, "single_chain_ms_per_sweep": dt1 * 1e3, "single_chain_iterations_per_s": 1.0 / dt1,
+            "seven_concurrent_chains_iterations_per_s": 7 * args.steps / dt7,
+            "single_chain_hbm_frac": b_alg / dt1 / 8e12}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(config4(a) if a.config == 4 else config5(a)))
+
+
+if __name__ == "__main__":
+    main()
