@@ -27,6 +27,7 @@ void prepare_sweep_kernels();
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
+bool sweep_uses_lag(const Dims& d);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_loglik_flush(const Ctx& c, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
@@ -240,7 +241,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) || dalloc(h, &c.Mmat, 2 * (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -644,6 +645,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   // without covariates the iteration ends with k_curve_chi: its scalar-job workgroup advances the counters and the
   // log-likelihood is reduced by the next iteration's k_pair_gram job (one kernel boundary less per iteration)
   c.defer_loglik = (c.d.D == 0) ? 1 : 0;
+  c.use_lag = sweep_uses_lag(c.d) ? 1 : 0;
   c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
   Dyn dyn;

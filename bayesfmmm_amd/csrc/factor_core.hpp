@@ -110,9 +110,10 @@ __device__ inline bool factor_wave(double* S, double* X, const double* zv, int P
   return bad;
 }
 
+// Cl (optional): an LDS copy of C, Cl[q + PP * p] = C(p, q) -- may alias S, whose band has been consumed by then
 template <int PP>
 __device__ inline bool factor_core(double* S, double* X, const double* zv, int P, int bw, double* Cg, double* Lg,
-                                   double* Lz_out, int tid) {
+                                   double* Lz_out, int tid, double* Cl = nullptr) {
   bool bad = false;
   if (bw == 0) {
     // diagonal precision (multivariate model): C = diag(1 / s_pp), chol_lower(C) = diag(1 / sqrt(s_pp)), L z likewise --
@@ -132,6 +133,7 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
         Lz_out[p] = rk * zv[p];
       }
       Cg[q + (size_t)P * p] = cv;
+      if (Cl) Cl[q + PP * p] = cv;
       if (Lg) Lg[p + (size_t)P * q] = lv;
     }
     return __syncthreads_or(bad ? 1 : 0) != 0;       // every thread reports (the callers test thread 0)
@@ -165,6 +167,7 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       for (int r = 0; r < 4; ++r) {
         const int p = pt * 16 + (lane >> 4) + 4 * r;
         if (p < P && q < P) Cg[q + (size_t)P * p] = acc[r];     // C is symmetric: the transposed store is coalesced
+        if (Cl) Cl[q + PP * p] = acc[r];
       }
     }
   }

@@ -25,6 +25,7 @@
 #include "z_proposal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace bfmmm {
@@ -361,6 +362,8 @@ __device__ inline double band_mv(const double* __restrict__ Hb, const double* v,
 }
 
 // ---------------------------------------------------------------------------------------------
+__device__ inline int step_dir(const Dims& d, int s, int n_phi);
+
 // k_factor: one workgroup per active direction a.
 //   r_a  = t_a - sum_b H_ab theta_b,  hq_a = H_aa theta_a      (always: the sweep starts from these)
 //   Prec = (beta/sigma^2) H_aa + Prior_a                        (banded: half-width BWP)
@@ -406,11 +409,20 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   double* part = thp + A * PS;      // A x P  : (H_ab theta_b)[p]
   double* zv = part + AP;           // PP
   double* hb2 = zv + PP;            // P x W  : rows of H_aa
-  double* dsc = hb2 + P * W;        // 16     : delta(j, .)
+  double* hbp = hb2 + P * W;        // 2 x P x W : rows of H_{a, p1}, H_{a, p2} (the two directions drawn before a; k_sweep_lag)
+  double* dsc = hbp + 2 * P * W;    // 16     : delta(j, .)
   const bool upd_nu = (mt == 0) && (c.mask & U_NU);
   const bool upd_phi = (mt > 0) && (c.mask & U_PHI);
   const bool upd = upd_nu || upd_phi;
   const Dyn* dyn = c.dyn;
+  // the directions drawn one and two steps before a in the sweep's order (-1: none)
+  int p1 = -1, p2 = -1;
+  if (c.use_lag) {
+    const int n_phi_s = ((c.mask & U_PHI) && MD > 1) ? K * M : 0;
+    const int rank = (mt >= 1) ? j * M + mt - 1 : n_phi_s + j;
+    if (rank >= 1) p1 = step_dir(d, rank - 1, n_phi_s);
+    if (rank >= 2) p2 = step_dir(d, rank - 2, n_phi_s);
+  }
   // ---- everything this workgroup needs from global memory is requested up front, in one batch ----
   constexpr int MAXI = 4;           // (b, p) items per thread and pass
   v2d hreg[MAXI][BW + 1];
@@ -488,6 +500,11 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
 #pragma unroll
           for (int k = 0; k <= BW; ++k) { hb2[p * W + 2 * k] = hreg[it][k].x; hb2[p * W + 2 * k + 1] = hreg[it][k].y; }
         }
+        if (b == p1 || b == p2) {
+          double* hp = hbp + ((b == p1) ? 0 : P * W);
+#pragma unroll
+          for (int k = 0; k <= BW; ++k) { hp[p * W + 2 * k] = hreg[it][k].x; hp[p * W + 2 * k + 1] = hreg[it][k].y; }
+        }
       }
     }
   }
@@ -528,9 +545,30 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   FST(5);
   __syncthreads();
   const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
-                                   c.Lz + (size_t)a * P, tid);
+                                   c.Lz + (size_t)a * P, tid, c.use_lag ? S : nullptr);
   FST(6);
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
+  if (c.use_lag) {
+    // k_sweep_lag: M1_a = f C_a H_{a,p1}, M2_a = f C_a H_{a,p2} (P x P, column-major) fold the two most recent draws of
+    // the sweep into direction a's draw, theta_a = base_a - M1_a delta_{p1} - M2_a delta_{p2}
+    __syncthreads();
+    double* Mg = c.Mmat + (size_t)a * 2 * P * P;
+    for (int e = tid; e < 2 * P * P; e += 256) {
+      const int which = e / (P * P), idx = e - which * P * P;
+      const int col = idx / P, r = idx - col * P;
+      double acc = 0.0;
+      if ((which == 0 ? p1 : p2) >= 0) {
+        const double* hp = hbp + which * P * W;
+#pragma unroll
+        for (int k2 = 0; k2 <= 2 * BW; ++k2) {
+          const int k = col - BW + k2;                 // H(k, col) = row k, entry BW + col - k
+          if (k >= 0 && k < P) acc += S[r + PP * k] * hp[k * W + 2 * BW - k2];
+        }
+        acc *= f;
+      }
+      Mg[e] = acc;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1061,6 +1099,249 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sweep_lag: the sweep of k_sweep_fast with the dependent chain cut down to ONE small matrix-vector product per
+// direction.  In k_sweep_fast a step is a round trip between two sets of waves (delta_a -> the rows of direction a+1
+// fold H_{a+1,a} delta_a into their residual and publish the next right-hand side -> C_{a+1} rhs), about 1750 clk.
+// Here the two most recent draws enter a direction's draw through matrices prepared by k_factor,
+//     theta_s = base_s - M1_s delta_{s-1} - M2_s delta_{s-2},     M1_s = f C_s H_{s,s-1},  M2_s = f C_s H_{s,s-2},
+//     base_s  = C_s f (r_s + H_ss theta_s) + L_s z_s   with r_s holding every draw up to s-3,
+// so that everything but the M products has at least one full step of slack:
+//   waves 0-1   (chain)  theta_s from base_s, M1_s, M2_s and the last two deltas; publishes delta_s
+//   waves 2-3   (base)   base_{s+1} = C_{s+1} rhs_{s+1} + L z           (rhs_{s+1} was published during step s-1)
+//   waves 4-15  (rows)   r_b -= H_{b,s-1} delta_{s-1} for EVERY row (one step late); the owner of step s+2 publishes
+//                        rhs_{s+2} = f (r + H theta)
+// Every role keeps its operands of the NEXT step (rows of M1 / M2, of C, of H) in the same 16 registers, requested
+// one step ahead with plain loads; one LDS barrier per step.  r follows the general kernel's definition
+// (r_a = t_a - sum_b H_ab theta_b over all b), so sigma^2's residual sum of squares is YY - sum_a theta_a'(t_a + r_a).
+// Requires P <= 32 and A * P <= 768.
+// STATUS (round 1): parity-green but NOT the default (opt in with the environment variable BFMMM_SWEEP_LAG): at
+// config 2 it takes 55 us against k_sweep_fast's 22 us.  The chain itself is short now; what is slow is that this first
+// version requests every role's operands with 8-byte loads one step ahead -- 128 wave-level memory instructions per
+// step on ONE CU (~20 clk each) and an exposed L2 round trip -- and k_factor pays 5 us for M1 / M2.  To win it needs
+// what k_sweep_fast has: 16-byte loads from thread-major copies of M / C, the rank-ordered rows (a direction's rows
+// retire after their step; incremental RSS), and a prefetch distance of two steps.  Floor of the design: ~850 KB of H
+// rows + 450 KB of M / C through one CU's L1 at 64 B/clk, i.e. ~8 us.
+// ---------------------------------------------------------------------------------------------
+constexpr int LAG_THREADS = 1024, LAG_ROW0 = 256, LAG_ROWS = LAG_THREADS - LAG_ROW0;
+
+__device__ inline double dpp_quad_sum(double v) {     // sum over the 4 lanes of a quad
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  return v;
+}
+
+template <int BW>
+__global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
+  TIMELINE(c, 4);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Dims& d = c.d;
+  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;
+  constexpr int W = 2 * BW + 2;
+  constexpr int DLS = 32 + 2 * BW + 2;
+  const int tid = threadIdx.x;
+  Dyn* dyn = c.dyn;
+  const int AP = A * P, PP2 = P * P;
+  double* th = smem;                         // A x P
+  double* lz = th + AP;                      // A x P
+  double* dlb = lz + AP;                     // 3 x DLS   deltas by step mod 3 (zero pads)
+  double* rhsb = dlb + 3 * DLS;              // 2 x 32    rhs by target step parity
+  double* baseb = rhsb + 64;                 // 2 x 32    base by target step parity
+  double* red = baseb + 64;                  // 16
+  int* sdir = (int*)(red + 16);              // step -> direction (+ 4 clamped entries)
+  int* brank = sdir + K * (M + 1) + 8;       // rank -> direction
+  const uint32_t slot = dyn->slot;
+  const uint32_t mask = c.mask;
+  const double beta = dyn->beta;
+  const double f = beta / dyn->sigma2;
+  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
+  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
+  const int n_nu = (mask & U_NU) ? K : 0;
+  const int n_steps = n_phi + n_nu;
+  {   // ranks follow the order of the steps (directions that are not updated come last), as in k_sweep_fast
+    const bool none_phi = (n_phi == 0 && MD > 1), none_nu = (n_nu == 0);
+    const int per_j = (none_phi ? MD - 1 : 0) + (none_nu ? 1 : 0);
+    for (int x = tid; x < A; x += LAG_THREADS) {
+      const int jx = x / MD, mx = x - jx * MD;
+      int rk;
+      if (mx >= 1 && !none_phi) rk = jx * M + mx - 1;
+      else if (mx == 0 && !none_nu) rk = n_phi + jx;
+      else rk = n_steps + jx * per_j + ((mx >= 1) ? (none_nu ? 1 : 0) + mx - 1 : 0);
+      brank[rk] = x;
+    }
+    for (int x = tid; x < n_steps + 4; x += LAG_THREADS) sdir[x] = step_dir(d, min(x, max(n_steps - 1, 0)), n_phi);
+    for (int x = tid; x < 3 * DLS + 128; x += LAG_THREADS) dlb[x] = 0.0;       // deltas, rhs and base buffers
+  }
+  __syncthreads();
+  // roles (wave-uniform)
+  const bool isChain = tid < 128, isBase = tid >= 128 && tid < 256;
+  const bool isRowW = tid >= LAG_ROW0;
+  const int mrow = min((tid & 127) >> 2, P - 1), mq = tid & 3;       // chain / base: row and lane of the 4-lane row group
+  const bool mrow_ok = ((tid & 127) >> 2) < P;
+  const int e = min(max(tid - LAG_ROW0, 0), AP - 1);
+  const bool isRow = isRowW && tid - LAG_ROW0 < AP;
+  const int rk = e / P, p = e - rk * P;
+  const int b = brank[rk];
+  const int fd = full_dir(d, b);
+  const int eb = b * P + p;
+  double r_e = 0.0, hq_e = 0.0, tv_e = 0.0;
+  if (isRowW) {
+    r_e = c.rvec[eb]; hq_e = c.hq[eb]; tv_e = c.tvec[eb];
+    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[eb];
+    if (isRow) { th[eb] = t0; lz[eb] = l0; }
+  }
+  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
+  // the operands of the next step, one set of registers for all roles:
+  //   chain: pre[u] = M1(mrow, mq + 4u), pre[8 + u] = M2(mrow, mq + 4u) of the direction of step t
+  //   base : pre[u] = C(mrow, mq + 4u) of the direction of step t + 1
+  //   rows : pre[0 .. 2BW+1] = H2 row p of block (b, direction of step t - 1)
+  double pre[16], nxt[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { pre[u] = 0.0; nxt[u] = 0.0; }
+  auto fetch = [&](double (&dst)[16], int t) {       // operands used DURING step t
+    if (isChain) {
+      const double* Mg = c.Mmat + (size_t)sdir[min(t, n_steps + 3)] * 2 * PP2 + mrow;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int col = min(mq + 4 * u, P - 1);
+        dst[u] = Mg[P * col];
+        dst[8 + u] = Mg[PP2 + P * col];
+      }
+    } else if (isBase) {
+      const double* Cg = c.Cmat + (size_t)sdir[min(t + 1, n_steps + 3)] * PP2 + mrow;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dst[u] = Cg[P * min(mq + 4 * u, P - 1)];
+    } else {
+      const double* row = c.H2 + ((size_t)hrow(d, b, sdir[min(max(t - 1, 0), n_steps + 3)]) * P + p) * W;
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (k < 16) dst[k] = row[k];
+    }
+  };
+  // 4-lane row product: sum over columns mq, mq + 4, .. of m[u] * v[col]
+  auto row_dot = [&](const double* m, const double* v) {
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int col = mq + 4 * u;
+      acc += ((mrow_ok && col < P) ? m[u] : 0.0) * v[min(col, 31)];
+    }
+    return dpp_quad_sum(acc);
+  };
+  auto band_dot = [&](const double* h, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) v += h[k] * dl[k];
+    return v;
+  };
+  if (n_steps > 0) {
+    // H2, C and M were written by other XCDs (k_pg_reduce, k_factor): a first touch is a trip to memory, several times
+    // a step of the chain.  Touch them once with fire-and-forget loads (one 4-byte load per 128-byte line) so that the
+    // per-step requests only see L2 hits.
+    {
+      int w0 = 0;
+      auto touch = [&](const double* src, size_t count) {
+        const size_t nl = (count * 8 + 127) / 128;
+        for (size_t x = tid; x < nl; x += LAG_THREADS) {
+          const uint32_t o = (uint32_t)(x * 128);
+          asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
+        }
+      };
+      touch(c.H2, (size_t)d.R * P * W);
+      touch(c.Cmat, (size_t)A * PP2);
+      touch(c.Mmat, 2 * (size_t)A * PP2);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
+    }
+    // ---- prologue: rhs_0, rhs_1; base_0; the operands of step 0 ----
+    if (isRow) {
+      if (b == sdir[0]) rhsb[p] = f * (r_e + hq_e);
+      if (n_steps > 1 && b == sdir[1]) rhsb[32 + p] = f * (r_e + hq_e);
+    }
+    if (isBase) fetch(nxt, -1);             // C of step 0's direction
+    fetch(pre, 0);
+    __syncthreads();
+    if (isBase) {
+      const double v = row_dot(nxt, rhsb);
+      if (mq == 0 && mrow_ok) baseb[mrow] = v + lz[sdir[0] * P + mrow];
+    }
+    lds_barrier();
+    for (int s = 0; s < n_steps; ++s) {
+      const int a = sdir[s];
+      fetch(nxt, s + 1);                                             // requested now, used in the next step
+      if (isChain) {
+        const double* d1 = dlb + ((s + 2) % 3) * DLS + BW;           // delta_{s-1}
+        const double* d2 = dlb + ((s + 1) % 3) * DLS + BW;           // delta_{s-2}
+        const double acc = row_dot(pre, d1) + row_dot(pre + 8, d2);
+        if (mq == 0 && mrow_ok) {
+          const double nw = baseb[(s & 1) * 32 + mrow] - acc;
+          dlb[(s % 3) * DLS + BW + mrow] = nw - th[a * P + mrow];
+          th[a * P + mrow] = nw;
+        }
+      } else if (isBase) {
+        if (s + 1 < n_steps) {
+          const int an = sdir[s + 1];
+          const double v = row_dot(pre, rhsb + ((s + 1) & 1) * 32);
+          if (mq == 0 && mrow_ok) baseb[((s + 1) & 1) * 32 + mrow] = v + lz[an * P + mrow];
+        }
+      } else {
+        // rows: the previous step's delta, one step late
+        if (s > 0) {
+          const double v = band_dot(pre, dlb + ((s + 2) % 3) * DLS + p);
+          r_e -= v;
+          if (b == sdir[s - 1]) hq_e += v;
+        }
+        if (isRow && s + 2 < n_steps && b == sdir[s + 2]) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) pre[u] = nxt[u];
+      lds_barrier();
+    }
+    // the last delta (pre holds the row of block (b, direction of the last step))
+    if (isRowW) {
+      const double v = band_dot(pre, dlb + ((n_steps - 1) % 3) * DLS + p);
+      r_e -= v;
+      if (b == sdir[n_steps - 1]) hq_e += v;
+    }
+  }
+  __syncthreads();
+  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
+  const double th_e = th[eb];
+  if (mask & U_SIGMA) {
+    double acc = isRow ? th_e * (tv_e + r_e) : 0.0;          // RSS = YY - sum_a theta_a'(t_a + r_a)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double qs = 0.0;
+      for (int w = 0; w < LAG_THREADS / 64; ++w) qs += red[w];
+      const double rss = c.YY - qs;
+      const bool tempered = (dyn->tt_step != 0);
+      const double bb = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
+      const double s2 = 1.0 / (sig_g * (1.0 / bb));
+      dyn->sigma2 = s2;
+      dyn->rss = rss;
+      c.c_sigma[slot] = s2;
+    }
+  } else if (tid == 0) {
+    c.c_sigma[slot] = dyn->sigma2;
+  }
+  // ---------------- publish theta and its chain slots -------------------------------------------
+  double* s_nu = c.c_nu + (size_t)slot * K * P;
+  double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
+  if (isRow) {
+    const int jj = b / MD, mt = b - jj * MD;
+    c.theta[(size_t)fd * P + p] = th_e;
+    if (mt == 0) s_nu[jj + (size_t)K * p] = th_e;
+    else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = th_e;
+  }
+  if (MD == 1)
+    for (int x = tid; x < K * P * M; x += LAG_THREADS) {
+      const int k = x % K, pm = x / K, pp = pm % P, m = pm / P;
+      s_phi[x] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + pp];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_loglik: calcLikelihood = sum_il dnorm(y_il; mean_il, sqrt(sigma2), log)  and end-of-iteration
 // bookkeeping (advance the iteration counter / slot for graph replay).
 // ---------------------------------------------------------------------------------------------
@@ -1129,7 +1410,7 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
-  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
+  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + 3 * (size_t)c.d.P * W + 16) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
@@ -1139,8 +1420,23 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   else launch_factor_pp<64>(c, grid, lds, st);
 }
 
+bool sweep_uses_lag(const Dims& d) { return d.P <= 32 && d.A * d.P <= LAG_ROWS && d.BW <= 5 && d.D == 0 && getenv("BFMMM_SWEEP_LAG") != nullptr; }
+
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
+  if (c.use_lag) {
+    const size_t lds = (2 * (size_t)d.A * d.P + 3 * (32 + 2 * d.BW + 2) + 128 + 16) * sizeof(double) +
+                       (2 * (size_t)d.K * (d.M + 1) + 16) * sizeof(int) + 16;
+    switch (d.BW) {
+      case 0: hipLaunchKernelGGL(k_sweep_lag<0>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      case 1: hipLaunchKernelGGL(k_sweep_lag<1>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      case 2: hipLaunchKernelGGL(k_sweep_lag<2>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      case 3: hipLaunchKernelGGL(k_sweep_lag<3>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      case 4: hipLaunchKernelGGL(k_sweep_lag<4>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_lag<5>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+    }
+    return 0;
+  }
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
     const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
     const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 24) * sizeof(int) + 16;
@@ -1176,6 +1472,8 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
+  set_max_lds((const void*)k_sweep_lag<0>); set_max_lds((const void*)k_sweep_lag<1>); set_max_lds((const void*)k_sweep_lag<2>);
+  set_max_lds((const void*)k_sweep_lag<3>); set_max_lds((const void*)k_sweep_lag<4>); set_max_lds((const void*)k_sweep_lag<5>);
   set_max_lds((const void*)k_pair_gram);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);
