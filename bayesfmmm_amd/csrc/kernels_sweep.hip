@@ -549,15 +549,17 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   FST(6);
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
   if (c.use_lag) {
-    // k_sweep_lag: M1_a = f C_a H_{a,p1}, M2_a = f C_a H_{a,p2} (P x P, column-major) fold the two most recent draws of
-    // the sweep into direction a's draw, theta_a = base_a - M1_a delta_{p1} - M2_a delta_{p2}
+    // k_sweep_lag: M1_a = f C_a H_{a,p1}, M2_a = f C_a H_{a,p2} fold the two most recent draws of the sweep into
+    // direction a's draw, theta_a = base_a - M1_a delta_{p1} - M2_a delta_{p2}.  Stored thread-major for the sweep's
+    // 4-lane row groups: thread t = 4 row + q owns [M1(row, q + 4u), u < 8 | M2(row, q + 4u), u < 8] (Mmat, 16 doubles)
+    // and C(row, q + 4u), u < 8 (Cperm, 8 doubles), so that its operands are 16-byte loads of one contiguous run.
     __syncthreads();
-    double* Mg = c.Mmat + (size_t)a * 2 * P * P;
-    for (int e = tid; e < 2 * P * P; e += 256) {
-      const int which = e / (P * P), idx = e - which * P * P;
-      const int col = idx / P, r = idx - col * P;
+    double* Mg = c.Mmat + (size_t)a * 128 * 16;
+    for (int e = tid; e < 128 * 16; e += 256) {
+      const int t = e >> 4, u16 = e & 15, which = u16 >> 3, u = u16 & 7;
+      const int r = t >> 2, col = (t & 3) + 4 * u;
       double acc = 0.0;
-      if ((which == 0 ? p1 : p2) >= 0) {
+      if (r < P && col < P && (which == 0 ? p1 : p2) >= 0) {
         const double* hp = hbp + which * P * W;
 #pragma unroll
         for (int k2 = 0; k2 <= 2 * BW; ++k2) {
@@ -567,6 +569,12 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
         acc *= f;
       }
       Mg[e] = acc;
+    }
+    double* Cp = c.Cperm + (size_t)a * 128 * 8;
+    for (int e = tid; e < 128 * 8; e += 256) {
+      const int t = e >> 3, u = e & 7;
+      const int r = t >> 2, col = (t & 3) + 4 * u;
+      Cp[e] = (r < P && col < P) ? S[r + PP * col] : 0.0;
     }
   }
 }
@@ -1115,12 +1123,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 // (r_a = t_a - sum_b H_ab theta_b over all b), so sigma^2's residual sum of squares is YY - sum_a theta_a'(t_a + r_a).
 // Requires P <= 32 and A * P <= 768.
 // STATUS (round 1): parity-green but NOT the default (opt in with the environment variable BFMMM_SWEEP_LAG): at
-// config 2 it takes 55 us against k_sweep_fast's 22 us.  The chain itself is short now; what is slow is that this first
-// version requests every role's operands with 8-byte loads one step ahead -- 128 wave-level memory instructions per
-// step on ONE CU (~20 clk each) and an exposed L2 round trip -- and k_factor pays 5 us for M1 / M2.  To win it needs
-// what k_sweep_fast has: 16-byte loads from thread-major copies of M / C, the rank-ordered rows (a direction's rows
-// retire after their step; incremental RSS), and a prefetch distance of two steps.  Floor of the design: ~850 KB of H
-// rows + 450 KB of M / C through one CU's L1 at 64 B/clk, i.e. ~8 us.
+// config 2 it takes 37 us against k_sweep_fast's 22 us, and k_factor pays 6 us for M1 / M2 / Cperm.  Measured on the
+// way: 55 us with column-major 8-byte operand loads; 63 us when the two operand sets spilled to scratch (arrays passed
+// by reference); 37 us with thread-major 16-byte loads and compile-time indexed sets.  What is left is the exposed L2
+// round trip of a one-step prefetch distance and the memory-instruction issue rate of ONE CU (~64 wave-level loads per
+// step at ~20 clk).  To win it needs a prefetch distance of two steps (three operand sets: chain on 8 lanes per row
+// so that every role's set is 4 x 16 bytes), the rank-ordered rows of k_sweep_fast (a direction's rows retire after
+// their step; incremental RSS) and a cheaper M product in k_factor.  Floor of the design: ~430 KB of H rows + 430 KB
+// of M / C through one CU's L1 at 64 B/clk, i.e. ~6 us for the loop against 15 us in k_sweep_fast.
 // ---------------------------------------------------------------------------------------------
 constexpr int LAG_THREADS = 1024, LAG_ROW0 = 256, LAG_ROWS = LAG_THREADS - LAG_ROW0;
 
@@ -1190,48 +1200,77 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
     if (isRow) { th[eb] = t0; lz[eb] = l0; }
   }
   const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
-  // the operands of the next step, one set of registers for all roles:
-  //   chain: pre[u] = M1(mrow, mq + 4u), pre[8 + u] = M2(mrow, mq + 4u) of the direction of step t
-  //   base : pre[u] = C(mrow, mq + 4u) of the direction of step t + 1
-  //   rows : pre[0 .. 2BW+1] = H2 row p of block (b, direction of step t - 1)
-  double pre[16], nxt[16];
+  // the operands of a step, one set of registers for all roles (two sets, used alternately: the set of step t + 1 is
+  // requested at the start of step t and first touched at the start of step t + 1):
+  //   chain: [M1(mrow, mq + 4u) | M2(mrow, mq + 4u)] of the direction of step t      (thread-major, 16-byte loads)
+  //   base : C(mrow, mq + 4u) of the direction of step t + 1
+  //   rows : H2 row p of block (b, direction of step t - 1)
+  v2d ops[2][8];       // (always indexed with compile-time constants: the two sets stay in registers)
 #pragma unroll
-  for (int u = 0; u < 16; ++u) { pre[u] = 0.0; nxt[u] = 0.0; }
-  auto fetch = [&](double (&dst)[16], int t) {       // operands used DURING step t
+  for (int u = 0; u < 8; ++u) { ops[0][u] = v2d{0.0, 0.0}; ops[1][u] = v2d{0.0, 0.0}; }
+  int* htab = brank + K * (M + 1);           // A x A : 16-byte offset of row p = 0 of block (b, a) in H2
+  for (int x = tid; x < A * A; x += LAG_THREADS) htab[x] = hrow(d, x / A, x % A) * P * W / 2;
+  __syncthreads();
+  auto fetch = [&](auto which, int t) {       // operands used DURING step t, into set `which`
+    constexpr int Q = decltype(which)::value;
     if (isChain) {
-      const double* Mg = c.Mmat + (size_t)sdir[min(t, n_steps + 3)] * 2 * PP2 + mrow;
+      const v2d* Mg = (const v2d*)(c.Mmat + ((size_t)sdir[min(t, n_steps + 3)] * 128 + (tid & 127)) * 16);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int col = min(mq + 4 * u, P - 1);
-        dst[u] = Mg[P * col];
-        dst[8 + u] = Mg[PP2 + P * col];
-      }
+      for (int u = 0; u < 8; ++u) ops[Q][u] = Mg[u];
     } else if (isBase) {
-      const double* Cg = c.Cmat + (size_t)sdir[min(t + 1, n_steps + 3)] * PP2 + mrow;
+      const v2d* Cg = (const v2d*)(c.Cperm + ((size_t)sdir[min(t + 1, n_steps + 3)] * 128 + (tid & 127)) * 8);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) dst[u] = Cg[P * min(mq + 4 * u, P - 1)];
+      for (int u = 0; u < 4; ++u) ops[Q][u] = Cg[u];
     } else {
-      const double* row = c.H2 + ((size_t)hrow(d, b, sdir[min(max(t - 1, 0), n_steps + 3)]) * P + p) * W;
+      const v2d* row = (const v2d*)c.H2 + htab[b * A + sdir[min(max(t - 1, 0), n_steps + 3)]] + p * (W / 2);
 #pragma unroll
-      for (int k = 0; k < W; ++k)
-        if (k < 16) dst[k] = row[k];
+      for (int k = 0; k <= BW; ++k) ops[Q][k] = row[k];
     }
   };
-  // 4-lane row product: sum over columns mq, mq + 4, .. of m[u] * v[col]
-  auto row_dot = [&](const double* m, const double* v) {
+  // 4-lane row product: sum over u of m[u] * v[mq + 4u]  (m = 4 v2d = 8 doubles; zero where row / column >= P)
+  auto row_dot = [&](const v2d* m, const double* v) {
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int col = mq + 4 * u;
-      acc += ((mrow_ok && col < P) ? m[u] : 0.0) * v[min(col, 31)];
-    }
+    for (int u = 0; u < 4; ++u) acc += m[u].x * v[min(mq + 8 * u, 31)] + m[u].y * v[min(mq + 8 * u + 4, 31)];
     return dpp_quad_sum(acc);
   };
-  auto band_dot = [&](const double* h, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
+  auto band_dot = [&](const v2d* h, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; ++k) v += h[k] * dl[k];
+    for (int k = 0; k <= BW; ++k) v += h[k].x * dl[2 * k] + h[k].y * dl[2 * k + 1];
     return v;
+  };
+  // one step with the operands `cur`; `nxt` receives the operands of step s + 1
+  auto step = [&](int s, auto which) {
+    constexpr int Q = decltype(which)::value;
+    const v2d* cur = ops[Q];
+    const int a = sdir[s];
+    fetch(std::integral_constant<int, Q ^ 1>{}, s + 1);
+    if (isChain) {
+      const double* d1 = dlb + ((s + 2) % 3) * DLS + BW;           // delta_{s-1}
+      const double* d2 = dlb + ((s + 1) % 3) * DLS + BW;           // delta_{s-2}
+      const double acc = row_dot(cur, d1) + row_dot(cur + 4, d2);
+      if (mq == 0 && mrow_ok) {
+        const double nw = baseb[(s & 1) * 32 + mrow] - acc;
+        dlb[(s % 3) * DLS + BW + mrow] = nw - th[a * P + mrow];
+        th[a * P + mrow] = nw;
+      }
+    } else if (isBase) {
+      if (s + 1 < n_steps) {
+        const int an = sdir[s + 1];
+        const double v = row_dot(cur, rhsb + ((s + 1) & 1) * 32);
+        if (mq == 0 && mrow_ok) baseb[((s + 1) & 1) * 32 + mrow] = v + lz[an * P + mrow];
+      }
+    } else {
+      // rows: the previous step's delta, one step late
+      if (s > 0) {
+        const double v = band_dot(cur, dlb + ((s + 2) % 3) * DLS + p);
+        r_e -= v;
+        if (b == sdir[s - 1]) hq_e += v;
+      }
+      if (isRow && s + 2 < n_steps && b == sdir[s + 2]) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
+    }
+    lds_barrier();
   };
   if (n_steps > 0) {
     // H2, C and M were written by other XCDs (k_pg_reduce, k_factor): a first touch is a trip to memory, several times
@@ -1247,8 +1286,8 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
         }
       };
       touch(c.H2, (size_t)d.R * P * W);
-      touch(c.Cmat, (size_t)A * PP2);
-      touch(c.Mmat, 2 * (size_t)A * PP2);
+      touch(c.Cperm, (size_t)A * 128 * 8);
+      touch(c.Mmat, (size_t)A * 128 * 16);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
     }
     // ---- prologue: rhs_0, rhs_1; base_0; the operands of step 0 ----
@@ -1256,48 +1295,24 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
       if (b == sdir[0]) rhsb[p] = f * (r_e + hq_e);
       if (n_steps > 1 && b == sdir[1]) rhsb[32 + p] = f * (r_e + hq_e);
     }
-    if (isBase) fetch(nxt, -1);             // C of step 0's direction
-    fetch(pre, 0);
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    if (isBase) fetch(Q1{}, -1);            // C of step 0's direction
+    fetch(Q0{}, 0);
     __syncthreads();
     if (isBase) {
-      const double v = row_dot(nxt, rhsb);
+      const double v = row_dot(ops[1], rhsb);
       if (mq == 0 && mrow_ok) baseb[mrow] = v + lz[sdir[0] * P + mrow];
     }
     lds_barrier();
-    for (int s = 0; s < n_steps; ++s) {
-      const int a = sdir[s];
-      fetch(nxt, s + 1);                                             // requested now, used in the next step
-      if (isChain) {
-        const double* d1 = dlb + ((s + 2) % 3) * DLS + BW;           // delta_{s-1}
-        const double* d2 = dlb + ((s + 1) % 3) * DLS + BW;           // delta_{s-2}
-        const double acc = row_dot(pre, d1) + row_dot(pre + 8, d2);
-        if (mq == 0 && mrow_ok) {
-          const double nw = baseb[(s & 1) * 32 + mrow] - acc;
-          dlb[(s % 3) * DLS + BW + mrow] = nw - th[a * P + mrow];
-          th[a * P + mrow] = nw;
-        }
-      } else if (isBase) {
-        if (s + 1 < n_steps) {
-          const int an = sdir[s + 1];
-          const double v = row_dot(pre, rhsb + ((s + 1) & 1) * 32);
-          if (mq == 0 && mrow_ok) baseb[((s + 1) & 1) * 32 + mrow] = v + lz[an * P + mrow];
-        }
-      } else {
-        // rows: the previous step's delta, one step late
-        if (s > 0) {
-          const double v = band_dot(pre, dlb + ((s + 2) % 3) * DLS + p);
-          r_e -= v;
-          if (b == sdir[s - 1]) hq_e += v;
-        }
-        if (isRow && s + 2 < n_steps && b == sdir[s + 2]) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) pre[u] = nxt[u];
-      lds_barrier();
-    }
-    // the last delta (pre holds the row of block (b, direction of the last step))
+    int s = 0;
+    for (; s + 1 < n_steps; s += 2) { step(s, Q0{}); step(s + 1, Q1{}); }
+    if (s < n_steps) { step(s, Q0{}); ++s; }
+    // the last delta (`last` holds the row of block (b, direction of the last step))
     if (isRowW) {
-      const double v = band_dot(pre, dlb + ((n_steps - 1) % 3) * DLS + p);
+      // (the set requested during the last step: 1 after an odd number of steps, else 0)
+      const double v = (n_steps & 1) ? band_dot(ops[1], dlb + ((n_steps - 1) % 3) * DLS + p)
+                                     : band_dot(ops[0], dlb + ((n_steps - 1) % 3) * DLS + p);
       r_e -= v;
       if (b == sdir[n_steps - 1]) hq_e += v;
     }
@@ -1426,7 +1441,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   if (c.use_lag) {
     const size_t lds = (2 * (size_t)d.A * d.P + 3 * (32 + 2 * d.BW + 2) + 128 + 16) * sizeof(double) +
-                       (2 * (size_t)d.K * (d.M + 1) + 16) * sizeof(int) + 16;
+                       (2 * (size_t)d.K * (d.M + 1) + 16 + (size_t)d.A * d.A) * sizeof(int) + 16;
     switch (d.BW) {
       case 0: hipLaunchKernelGGL(k_sweep_lag<0>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_lag<1>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
