@@ -241,7 +241,7 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) || dalloc(h, &c.Mmat, (size_t)d.A * 128 * 16) || dalloc(h, &c.Cperm, (size_t)d.A * 128 * 8) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) || dalloc(h, &c.Mmat, (size_t)d.A * 256 * 8) || dalloc(h, &c.Cperm, (size_t)d.A * 128 * 8) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;

@@ -551,13 +551,13 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   if (c.use_lag) {
     // k_sweep_lag: M1_a = f C_a H_{a,p1}, M2_a = f C_a H_{a,p2} fold the two most recent draws of the sweep into
     // direction a's draw, theta_a = base_a - M1_a delta_{p1} - M2_a delta_{p2}.  Stored thread-major for the sweep's
-    // 4-lane row groups: thread t = 4 row + q owns [M1(row, q + 4u), u < 8 | M2(row, q + 4u), u < 8] (Mmat, 16 doubles)
-    // and C(row, q + 4u), u < 8 (Cperm, 8 doubles), so that its operands are 16-byte loads of one contiguous run.
+    // row groups: chain thread t = 8 row + q owns [M1(row, q + 8u), u < 4 | M2(row, q + 8u), u < 4] (Mmat, 8 doubles),
+    // base thread t = 4 row + q owns C(row, q + 4u), u < 8 (Cperm, 8 doubles): every set is four 16-byte loads.
     __syncthreads();
-    double* Mg = c.Mmat + (size_t)a * 128 * 16;
-    for (int e = tid; e < 128 * 16; e += 256) {
-      const int t = e >> 4, u16 = e & 15, which = u16 >> 3, u = u16 & 7;
-      const int r = t >> 2, col = (t & 3) + 4 * u;
+    double* Mg = c.Mmat + (size_t)a * 256 * 8;
+    for (int e = tid; e < 256 * 8; e += 256) {
+      const int t = e >> 3, j8 = e & 7, which = j8 >> 2, u = j8 & 3;
+      const int r = t >> 3, col = (t & 7) + 8 * u;
       double acc = 0.0;
       if (r < P && col < P && (which == 0 ? p1 : p2) >= 0) {
         const double* hp = hbp + which * P * W;
@@ -1121,18 +1121,20 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 // Every role keeps its operands of the NEXT step (rows of M1 / M2, of C, of H) in the same 16 registers, requested
 // one step ahead with plain loads; one LDS barrier per step.  r follows the general kernel's definition
 // (r_a = t_a - sum_b H_ab theta_b over all b), so sigma^2's residual sum of squares is YY - sum_a theta_a'(t_a + r_a).
-// Requires P <= 32 and A * P <= 768.
+// Requires P <= 32, A * P <= 640 and a band half-width <= 3.
 // STATUS (round 1): parity-green but NOT the default (opt in with the environment variable BFMMM_SWEEP_LAG): at
-// config 2 it takes 37 us against k_sweep_fast's 22 us, and k_factor pays 6 us for M1 / M2 / Cperm.  Measured on the
-// way: 55 us with column-major 8-byte operand loads; 63 us when the two operand sets spilled to scratch (arrays passed
-// by reference); 37 us with thread-major 16-byte loads and compile-time indexed sets.  What is left is the exposed L2
-// round trip of a one-step prefetch distance and the memory-instruction issue rate of ONE CU (~64 wave-level loads per
-// step at ~20 clk).  To win it needs a prefetch distance of two steps (three operand sets: chain on 8 lanes per row
-// so that every role's set is 4 x 16 bytes), the rank-ordered rows of k_sweep_fast (a direction's rows retire after
-// their step; incremental RSS) and a cheaper M product in k_factor.  Floor of the design: ~430 KB of H rows + 430 KB
-// of M / C through one CU's L1 at 64 B/clk, i.e. ~6 us for the loop against 15 us in k_sweep_fast.
+// config 2 it takes 32 us against k_sweep_fast's 22 us, and k_factor pays 6 us for M1 / M2 / Cperm.  Measured on the
+// way: 55 us with column-major 8-byte operand loads; 63 us when the operand sets spilled to scratch (arrays passed by
+// reference); 37 us with thread-major 16-byte loads and compile-time indexed sets; 32 us with three sets (prefetch
+// distance two steps) and the chain on 8 lanes per row.  Phase clocks (tools/lag_stamps.py, -DLAG_STAMPS): L2 warm-up
+// 8-15 k, prologue 6-12 k, loop 43.7 k = 2080 clk per step, tail 3 k.  So the step is no shorter than k_sweep_fast's
+// 1750 clk although its dependent chain is: with 16 waves on one CU the fixed costs of a step -- a dozen dependent LDS
+// round trips for indices, deltas and hand-offs, the barrier, instruction issue at four waves per SIMD -- dominate
+// either formulation.  What it would take: the per-step indices in SGPRs ahead of time, deltas kept in registers of
+// the chain waves (DPP broadcast) instead of LDS, rows retiring after their step (incremental RSS) so that late steps
+// run with fewer waves, and a cheaper M product in k_factor.
 // ---------------------------------------------------------------------------------------------
-constexpr int LAG_THREADS = 1024, LAG_ROW0 = 256, LAG_ROWS = LAG_THREADS - LAG_ROW0;
+constexpr int LAG_THREADS = 1024, LAG_ROW0 = 384, LAG_ROWS = LAG_THREADS - LAG_ROW0;
 
 __device__ inline double dpp_quad_sum(double v) {     // sum over the 4 lanes of a quad
   v = dpp_add<0xB1>(v);
@@ -1183,10 +1185,12 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
   }
   __syncthreads();
   // roles (wave-uniform)
-  const bool isChain = tid < 128, isBase = tid >= 128 && tid < 256;
+  const bool isChain = tid < 256, isBase = tid >= 256 && tid < LAG_ROW0;
   const bool isRowW = tid >= LAG_ROW0;
-  const int mrow = min((tid & 127) >> 2, P - 1), mq = tid & 3;       // chain / base: row and lane of the 4-lane row group
-  const bool mrow_ok = ((tid & 127) >> 2) < P;
+  // chain: 8 lanes per row (row = tid / 8); base: 4 lanes per row (row = (tid - 256) / 4)
+  const int mrow_raw = isChain ? (tid >> 3) : ((tid - 256) >> 2);
+  const int mrow = min(max(mrow_raw, 0), P - 1), mq = isChain ? (tid & 7) : (tid & 3);
+  const bool mrow_ok = mrow_raw >= 0 && mrow_raw < P;
   const int e = min(max(tid - LAG_ROW0, 0), AP - 1);
   const bool isRow = isRowW && tid - LAG_ROW0 < AP;
   const int rk = e / P, p = e - rk * P;
@@ -1205,30 +1209,44 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
   //   chain: [M1(mrow, mq + 4u) | M2(mrow, mq + 4u)] of the direction of step t      (thread-major, 16-byte loads)
   //   base : C(mrow, mq + 4u) of the direction of step t + 1
   //   rows : H2 row p of block (b, direction of step t - 1)
-  v2d ops[2][8];       // (always indexed with compile-time constants: the two sets stay in registers)
+  v2d ops[3][4];       // three sets (prefetch distance two steps), always indexed with compile-time constants
 #pragma unroll
-  for (int u = 0; u < 8; ++u) { ops[0][u] = v2d{0.0, 0.0}; ops[1][u] = v2d{0.0, 0.0}; }
+  for (int u = 0; u < 4; ++u) { ops[0][u] = v2d{0.0, 0.0}; ops[1][u] = v2d{0.0, 0.0}; ops[2][u] = v2d{0.0, 0.0}; }
   int* htab = brank + K * (M + 1);           // A x A : 16-byte offset of row p = 0 of block (b, a) in H2
   for (int x = tid; x < A * A; x += LAG_THREADS) htab[x] = hrow(d, x / A, x % A) * P * W / 2;
   __syncthreads();
+  static_assert(BW <= 3, "an operand set is four 16-byte values: band half-width <= 3");
+  // per-thread bases, so that a step's request is one scalar multiply away from its address
+  const v2d* Mthr = (const v2d*)(c.Mmat + (size_t)(tid & 255) * 8);
+  const v2d* Cthr = (const v2d*)(c.Cperm + (size_t)max(min(tid - 256, 127), 0) * 8);
+  const v2d* Hthr = (const v2d*)c.H2 + p * (W / 2);
+  const int* hrowb = htab + b * A;
+  auto sdir_at = [&](int t) { return __builtin_amdgcn_readfirstlane(sdir[min(max(t, 0), n_steps + 3)]); };   // wave-uniform
   auto fetch = [&](auto which, int t) {       // operands used DURING step t, into set `which`
     constexpr int Q = decltype(which)::value;
     if (isChain) {
-      const v2d* Mg = (const v2d*)(c.Mmat + ((size_t)sdir[min(t, n_steps + 3)] * 128 + (tid & 127)) * 16);
+      const v2d* Mg = Mthr + (size_t)sdir_at(t) * (256 * 4);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) ops[Q][u] = Mg[u];
+      for (int u = 0; u < 4; ++u) ops[Q][u] = Mg[u];
     } else if (isBase) {
-      const v2d* Cg = (const v2d*)(c.Cperm + ((size_t)sdir[min(t + 1, n_steps + 3)] * 128 + (tid & 127)) * 8);
+      const v2d* Cg = Cthr + (size_t)sdir_at(t + 1) * (128 * 4);
 #pragma unroll
       for (int u = 0; u < 4; ++u) ops[Q][u] = Cg[u];
     } else {
-      const v2d* row = (const v2d*)c.H2 + htab[b * A + sdir[min(max(t - 1, 0), n_steps + 3)]] + p * (W / 2);
+      const v2d* row = Hthr + hrowb[sdir_at(t - 1)];
 #pragma unroll
-      for (int k = 0; k <= BW; ++k) ops[Q][k] = row[k];
+      for (int k = 0; k <= BW && k < 4; ++k) ops[Q][k] = row[k];
     }
   };
-  // 4-lane row product: sum over u of m[u] * v[mq + 4u]  (m = 4 v2d = 8 doubles; zero where row / column >= P)
-  auto row_dot = [&](const v2d* m, const double* v) {
+  // chain: sum over u < 4 of m(u) v[mq + 8u], m = 2 v2d; 8-lane sum
+  auto row_dot8 = [&](const v2d* m, const double* v) {
+    double acc = (m[0].x * v[mq] + m[0].y * v[mq + 8]) + (m[1].x * v[mq + 16] + m[1].y * v[mq + 24]);
+    acc = dpp_add<0xB1>(acc);
+    acc = dpp_add<0x4E>(acc);
+    return dpp_add<0x141>(acc);
+  };
+  // base: sum over u < 8 of m(u) v[mq + 4u], m = 4 v2d; 4-lane sum
+  auto row_dot4 = [&](const v2d* m, const double* v) {
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc += m[u].x * v[min(mq + 8 * u, 31)] + m[u].y * v[min(mq + 8 * u + 4, 31)];
@@ -1237,19 +1255,19 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
   auto band_dot = [&](const v2d* h, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k <= BW; ++k) v += h[k].x * dl[2 * k] + h[k].y * dl[2 * k + 1];
+    for (int k = 0; k <= BW && k < 4; ++k) v += h[k].x * dl[2 * k] + h[k].y * dl[2 * k + 1];
     return v;
   };
-  // one step with the operands `cur`; `nxt` receives the operands of step s + 1
+  // one step with the operand set Q; set (Q + 2) % 3 receives the operands of step s + 2
   auto step = [&](int s, auto which) {
     constexpr int Q = decltype(which)::value;
     const v2d* cur = ops[Q];
-    const int a = sdir[s];
-    fetch(std::integral_constant<int, Q ^ 1>{}, s + 1);
+    const int a = sdir_at(s);
+    fetch(std::integral_constant<int, (Q + 2) % 3>{}, s + 2);
     if (isChain) {
       const double* d1 = dlb + ((s + 2) % 3) * DLS + BW;           // delta_{s-1}
       const double* d2 = dlb + ((s + 1) % 3) * DLS + BW;           // delta_{s-2}
-      const double acc = row_dot(cur, d1) + row_dot(cur + 4, d2);
+      const double acc = row_dot8(cur, d1) + row_dot8(cur + 2, d2);
       if (mq == 0 && mrow_ok) {
         const double nw = baseb[(s & 1) * 32 + mrow] - acc;
         dlb[(s % 3) * DLS + BW + mrow] = nw - th[a * P + mrow];
@@ -1257,8 +1275,8 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
       }
     } else if (isBase) {
       if (s + 1 < n_steps) {
-        const int an = sdir[s + 1];
-        const double v = row_dot(cur, rhsb + ((s + 1) & 1) * 32);
+        const int an = sdir_at(s + 1);
+        const double v = row_dot4(cur, rhsb + ((s + 1) & 1) * 32);
         if (mq == 0 && mrow_ok) baseb[((s + 1) & 1) * 32 + mrow] = v + lz[an * P + mrow];
       }
     } else {
@@ -1266,12 +1284,18 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
       if (s > 0) {
         const double v = band_dot(cur, dlb + ((s + 2) % 3) * DLS + p);
         r_e -= v;
-        if (b == sdir[s - 1]) hq_e += v;
+        if (b == sdir_at(s - 1)) hq_e += v;
       }
-      if (isRow && s + 2 < n_steps && b == sdir[s + 2]) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
+      if (isRow && s + 2 < n_steps && b == sdir_at(s + 2)) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
     }
     lds_barrier();
   };
+#ifdef LAG_STAMPS
+#define LST(k) do { if (tid == 0 || tid == 640) dyn->stamps[40 + (k) + (tid ? 8 : 0)] = clock64(); } while (0)
+#else
+#define LST(k) do { } while (0)
+#endif
+  LST(0);
   if (n_steps > 0) {
     // H2, C and M were written by other XCDs (k_pg_reduce, k_factor): a first touch is a trip to memory, several times
     // a step of the chain.  Touch them once with fire-and-forget loads (one 4-byte load per 128-byte line) so that the
@@ -1287,7 +1311,7 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
       };
       touch(c.H2, (size_t)d.R * P * W);
       touch(c.Cperm, (size_t)A * 128 * 8);
-      touch(c.Mmat, (size_t)A * 128 * 16);
+      touch(c.Mmat, (size_t)A * 256 * 8);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
     }
     // ---- prologue: rhs_0, rhs_1; base_0; the operands of step 0 ----
@@ -1295,24 +1319,30 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
       if (b == sdir[0]) rhsb[p] = f * (r_e + hq_e);
       if (n_steps > 1 && b == sdir[1]) rhsb[32 + p] = f * (r_e + hq_e);
     }
+    LST(1);
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
-    if (isBase) fetch(Q1{}, -1);            // C of step 0's direction
+    using Q2 = std::integral_constant<int, 2>;
+    if (isBase) fetch(Q2{}, -1);            // C of step 0's direction (set 2 is free until step 0 refills it)
     fetch(Q0{}, 0);
+    fetch(Q1{}, 1);
     __syncthreads();
     if (isBase) {
-      const double v = row_dot(ops[1], rhsb);
+      const double v = row_dot4(ops[2], rhsb);
       if (mq == 0 && mrow_ok) baseb[mrow] = v + lz[sdir[0] * P + mrow];
     }
     lds_barrier();
+    LST(2);
     int s = 0;
-    for (; s + 1 < n_steps; s += 2) { step(s, Q0{}); step(s + 1, Q1{}); }
+    for (; s + 2 < n_steps; s += 3) { step(s, Q0{}); step(s + 1, Q1{}); step(s + 2, Q2{}); }
     if (s < n_steps) { step(s, Q0{}); ++s; }
-    // the last delta (`last` holds the row of block (b, direction of the last step))
+    if (s < n_steps) { step(s, Q1{}); ++s; }
+    LST(3);
+    // the last delta: the rows' operands "of step n_steps" (block (b, direction of the last step)) are in set n_steps % 3
     if (isRowW) {
-      // (the set requested during the last step: 1 after an odd number of steps, else 0)
-      const double v = (n_steps & 1) ? band_dot(ops[1], dlb + ((n_steps - 1) % 3) * DLS + p)
-                                     : band_dot(ops[0], dlb + ((n_steps - 1) % 3) * DLS + p);
+      const double* dl = dlb + ((n_steps - 1) % 3) * DLS + p;
+      const int q3 = n_steps % 3;
+      const double v = (q3 == 0) ? band_dot(ops[0], dl) : ((q3 == 1) ? band_dot(ops[1], dl) : band_dot(ops[2], dl));
       r_e -= v;
       if (b == sdir[n_steps - 1]) hq_e += v;
     }
@@ -1340,6 +1370,7 @@ __global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
   } else if (tid == 0) {
     c.c_sigma[slot] = dyn->sigma2;
   }
+  LST(4);
   // ---------------- publish theta and its chain slots -------------------------------------------
   double* s_nu = c.c_nu + (size_t)slot * K * P;
   double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
@@ -1435,7 +1466,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   else launch_factor_pp<64>(c, grid, lds, st);
 }
 
-bool sweep_uses_lag(const Dims& d) { return d.P <= 32 && d.A * d.P <= LAG_ROWS && d.BW <= 5 && d.D == 0 && getenv("BFMMM_SWEEP_LAG") != nullptr; }
+bool sweep_uses_lag(const Dims& d) { return d.P <= 32 && d.A * d.P <= LAG_ROWS && d.BW <= 3 && d.D == 0 && getenv("BFMMM_SWEEP_LAG") != nullptr; }
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
@@ -1446,9 +1477,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
       case 0: hipLaunchKernelGGL(k_sweep_lag<0>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_lag<1>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
       case 2: hipLaunchKernelGGL(k_sweep_lag<2>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      case 3: hipLaunchKernelGGL(k_sweep_lag<3>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      case 4: hipLaunchKernelGGL(k_sweep_lag<4>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      default: hipLaunchKernelGGL(k_sweep_lag<5>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_lag<3>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
     }
     return 0;
   }
@@ -1488,7 +1517,7 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
   set_max_lds((const void*)k_sweep_lag<0>); set_max_lds((const void*)k_sweep_lag<1>); set_max_lds((const void*)k_sweep_lag<2>);
-  set_max_lds((const void*)k_sweep_lag<3>); set_max_lds((const void*)k_sweep_lag<4>); set_max_lds((const void*)k_sweep_lag<5>);
+  set_max_lds((const void*)k_sweep_lag<3>);
   set_max_lds((const void*)k_pair_gram);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);
