@@ -130,10 +130,12 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   double* sLog = sThX + (size_t)nth * D;             // GPB*KMAX
   double* sYp = sLog + GPB * KMAX;                   // GPB
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int per_group = (2 * K + 3) * T::STR + MMAX + 32;
+  // multivariate model: G_i = I, so G u = u and the GU tile is the U tile (one tile less: a third workgroup per CU)
+  const int TW = d.mv ? 1 : 2;
+  const int per_group = (TW * K + 3) * T::STR + MMAX + 32;
   double* gbase = sYp + GPB + (size_t)grp * per_group;
-  T tU{gbase}, tG{gbase + K * T::STR}, tS{gbase + 2 * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
-  double* sChi = gbase + (2 * K + 3) * T::STR;
+  T tU{gbase}, tG{gbase + (TW - 1) * K * T::STR}, tS{gbase + TW * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
+  double* sChi = gbase + (TW * K + 3) * T::STR;
   double* sRes = sChi + MMAX;
   const int i = blockIdx.x * GPB + grp;
   const bool valid = i < n;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
   if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
-    tU.zero_pads(2 * K + 3, lp);
+    tU.zero_pads(TW * K + 3, lp);
     if (lp <= M) sChi[lp] = chi_l;                   // [M] = 0: pad of the 2-unrolled loops
     tS.row(0)[lp] = cv.s;
   }
@@ -226,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
     }
     ZT();
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
+    if (!d.mv)
+      for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
     ZT();
     __builtin_amdgcn_wave_barrier();
     // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2  -- one lane each
@@ -379,10 +382,11 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
   const int RT = max(M, K);                          // rows of the U / GU tiles (the fused Z update needs K of them)
   const int nres = max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2);
-  const int per_group = (2 * RT + 3) * T::STR + 2 * M + 2 + nres;
+  const int TW = d.mv ? 1 : 2;                       // multivariate model: G u = u, the GU tile is the U tile
+  const int per_group = (TW * RT + 3) * T::STR + 2 * M + 2 + nres;
   double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
-  T tU{gbase}, tG{gbase + RT * T::STR}, tX{gbase + 2 * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
-  double* sChi = gbase + (2 * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
+  T tU{gbase}, tG{gbase + (TW - 1) * RT * T::STR}, tX{gbase + TW * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
+  double* sChi = gbase + (TW * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
   double* sZn = sChi + M + 1;
   double* sRes = sZn + M + 1;
   copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
   Curve<BW, LPC> cv;
   if (valid) {
     cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
-    tU.zero_pads(2 * RT + 3, lp);
+    tU.zero_pads(TW * RT + 3, lp);
     if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;
     tX.row(2)[lp] = cv.s;
   }
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
     __builtin_amdgcn_wave_barrier();
     const double g0 = cv.matvec(tX.row(0), lp);
     tX.row(1)[lp] = cv.s - g0;
-    for (int m = 0; m < Mu; ++m) tG.row(m)[lp] = cv.matvec(tU.row(m), lp);
+    if (!d.mv)
+      for (int m = 0; m < Mu; ++m) tG.row(m)[lp] = cv.matvec(tU.row(m), lp);
     __builtin_amdgcn_wave_barrier();
     // tasks: [0, Mu(Mu+1)/2): A_{m,m2} = u_m' G u_m2 (m <= m2);  then Mu of b_m = u_m'(s - G c0);
     //        then  c0's  and  c0'(s - G c0)
@@ -547,7 +552,8 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
       for (int k = 0; k < KMAX; ++k)
         if (k < K) tU.row(k)[lp] = uk[k];
       __builtin_amdgcn_wave_barrier();
-      for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
+      if (!d.mv)
+        for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
       __builtin_amdgcn_wave_barrier();
       const int nzt = K + K * (K + 1) / 2;       // q < K: a_q = u_q's ;  q >= K: pair (k, k2), k <= k2: u_k' G u_k2
       if (lp < nzt) {
@@ -624,8 +630,9 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const size_t nth = (size_t)K * (M + 1) * c.d.P;
   const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
   size_t lds;
-  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((2 * K + 3) * STR + MMAX + 32 + tileE);
-  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((2 * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
+  const int TW = c.d.mv ? 1 : 2;
+  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 32 + tileE);
+  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
   if (which == 1) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;
