@@ -790,6 +790,164 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sweep_diag: the sweep of the DIAGONAL model (multivariate: G_i = I, priors I/tau and diag(tilde_tau gamma)).
+// Every H block and every C_a is diagonal, so the coordinates p are independent scalar Gauss-Seidel chains: 8 lanes
+// per coordinate share its A directions (direction b lives on lane b % 8, slot b / 8) and keep r_b, H_bb theta_b, C_a,
+// L z, theta in registers; a step is a handful of FMAs, an 8-lane DPP sum that broadcasts delta, and the H entries of
+// the next step requested one step ahead.  No LDS hand-off and no barrier inside the sweep.  r follows the general
+// kernel's definition (r_a = t_a - sum_b H_ab theta_b over all b).  One workgroup of 8 P threads; A <= 64.
+// ---------------------------------------------------------------------------------------------
+constexpr int DG_RPL = 8;          // directions per lane
+
+__global__ __launch_bounds__(512) void k_sweep_diag(Ctx c) {
+  TIMELINE(c, 4);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Dims& d = c.d;
+  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD, LG = d.LG;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  Dyn* dyn = c.dyn;
+  double* red = smem;                          // 16
+  int* htab = (int*)(red + 16);                // A x A : element offset of block (b, a) in H
+  int* sdir = htab + A * A;
+  const uint32_t slot = dyn->slot;
+  const uint32_t mask = c.mask;
+  const double beta = dyn->beta;
+  const double f = beta / dyn->sigma2;
+  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
+#ifdef DG_STAMPS
+#define DST(k) do { if (tid == 0) dyn->stamps[40 + (k)] = clock64(); } while (0)
+#else
+#define DST(k) do { } while (0)
+#endif
+  DST(0);
+  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
+  const int n_nu = (mask & U_NU) ? K : 0;
+  const int n_steps = n_phi + n_nu;
+  for (int x = tid; x < A * A; x += nthr) htab[x] = hrow(d, x / A, x % A) * LG;
+  for (int x = tid; x < n_steps + 2; x += nthr) sdir[x] = step_dir(d, min(x, max(n_steps - 1, 0)), n_phi);
+  const int p = min(tid >> 3, P - 1), g = tid & 7;
+  const bool live = (tid >> 3) < P;
+  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
+  double r[DG_RPL], hq[DG_RPL], cd[DG_RPL], lz[DG_RPL], th[DG_RPL], tv[DG_RPL];
+#pragma unroll
+  for (int j = 0; j < DG_RPL; ++j) {
+    const int b = min(g + 8 * j, A - 1);
+    const bool on = g + 8 * j < A;
+    const int e = b * P + p;
+    const double rv = c.rvec[e], hv = c.hq[e], cv = c.Cmat[(size_t)b * P * P + (size_t)p * (P + 1)], lv = c.Lz[e];
+    const double t0 = c.theta[(size_t)full_dir(d, b) * P + p], t1 = c.tvec[e];
+    r[j] = on ? rv : 0.0; hq[j] = on ? hv : 0.0; cd[j] = on ? cv : 0.0; lz[j] = on ? lv : 0.0; th[j] = on ? t0 : 0.0; tv[j] = on ? t1 : 0.0;
+  }
+  __syncthreads();
+  DST(1);
+  // H was written by another XCD (k_pg_reduce): touch it once (one 4-byte load per 128-byte line, fire and forget) so
+  // that the per-step requests are L2 hits; they are issued two steps ahead (three register sets, compile-time indexed)
+  if (n_steps > 0) {
+    int w0 = 0;
+    const size_t nl = ((size_t)d.R * LG * 8 + 127) / 128;
+    for (size_t x = tid; x < nl; x += nthr) {
+      const uint32_t o = (uint32_t)(x * 128);
+      asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(c.H));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
+  }
+  DST(2);
+  double hs[3][DG_RPL];
+  auto fetch = [&](auto which, int a) {       // H_{b,a}[p] for this lane's directions
+    constexpr int Q = decltype(which)::value;
+#pragma unroll
+    for (int j = 0; j < DG_RPL; ++j) {
+      const int b = min(g + 8 * j, A - 1);
+      hs[Q][j] = c.H[(size_t)htab[b * A + a] + p];
+    }
+  };
+  auto step = [&](int s, auto which) {
+    constexpr int Q = decltype(which)::value;
+    const int a = __builtin_amdgcn_readfirstlane(sdir[s]);
+    fetch(std::integral_constant<int, (Q + 2) % 3>{}, __builtin_amdgcn_readfirstlane(sdir[min(s + 2, n_steps + 1)]));
+    const int owner = a & 7, js = a >> 3;
+    double dsel = 0.0;
+#pragma unroll
+    for (int j = 0; j < DG_RPL; ++j)
+      if (j == js) {                                     // uniform: the slot of this step's direction
+        const double nw = cd[j] * (f * (r[j] + hq[j])) + lz[j];
+        if (g == owner) { dsel = nw - th[j]; th[j] = nw; }
+      }
+    dsel = dpp_add<0xB1>(dsel);
+    dsel = dpp_add<0x4E>(dsel);
+    const double delta = dpp_add<0x141>(dsel);           // broadcast to the 8 lanes of the coordinate
+#pragma unroll
+    for (int j = 0; j < DG_RPL; ++j) {
+      const double v = hs[Q][j] * delta;
+      if (g + 8 * j < A) r[j] -= v;
+      if (j == js && g == owner) hq[j] += v;
+    }
+  };
+  if (n_steps > 0) {
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    fetch(Q0{}, __builtin_amdgcn_readfirstlane(sdir[0]));
+    fetch(Q1{}, __builtin_amdgcn_readfirstlane(sdir[1]));
+    int s = 0;
+    for (; s + 2 < n_steps; s += 3) { step(s, Q0{}); step(s + 1, Q1{}); step(s + 2, Q2{}); }
+    if (s < n_steps) { step(s, Q0{}); ++s; }
+    if (s < n_steps) { step(s, Q1{}); ++s; }
+  }
+  DST(3);
+  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:127-165 MV) ---------------------------------
+  if (mask & U_SIGMA) {
+    double acc = 0.0;                                       // RSS = YY - sum_a theta_a'(t_a + r_a)
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < DG_RPL; ++j) acc += th[j] * (tv[j] + r[j]);
+    }
+    if (d.D > 0)
+      for (int x = tid; x < c.nblk_curve; x += nthr) acc -= c.yyp_part[x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double qs = 0.0;
+      for (int w = 0; w < nthr / 64; ++w) qs += red[w];
+      const double rss = (d.D > 0) ? -qs : (c.YY - qs);
+      const bool tempered = (dyn->tt_step != 0);
+      const double bb = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
+      const double s2 = 1.0 / (sig_g * (1.0 / bb));
+      dyn->sigma2 = s2;
+      dyn->rss = rss;
+      c.c_sigma[slot] = s2;
+    }
+  } else if (tid == 0) {
+    c.c_sigma[slot] = dyn->sigma2;
+  }
+  DST(4);
+  // ---------------- publish theta and its chain slots -------------------------------------------
+  double* s_nu = c.c_nu + (size_t)slot * K * P;
+  double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < DG_RPL; ++j) {
+      const int b = g + 8 * j;
+      if (b < A) {
+        const int jj = b / MD, mt = b - jj * MD;
+        c.theta[(size_t)(jj * (M + 1) + mt) * P + p] = th[j];
+        if (mt == 0) s_nu[jj + (size_t)K * p] = th[j];
+        else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = th[j];
+      }
+    }
+  }
+  if (MD == 1) {
+    __syncthreads();
+    for (int x = tid; x < K * P * M; x += nthr) {
+      const int k = x % K, pm = x / K, pp = pm % P, m = pm / P;
+      s_phi[x] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + pp];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_sweep_fast: the same sweep for P <= 32 and A*P <= 1024 (every configuration of BASELINE.json).
 // The kernel is a chain of K*M + K dependent steps on one CU, so what matters is the length of the
 // per-step dependency chain, not throughput:
@@ -1479,6 +1637,11 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
       case 2: hipLaunchKernelGGL(k_sweep_lag<2>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
       default: hipLaunchKernelGGL(k_sweep_lag<3>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
     }
+    return 0;
+  }
+  if (d.BW == 0 && d.BWP == 0 && d.A <= 8 * DG_RPL && d.P <= 64) {        // diagonal model: independent scalar chains per coordinate
+    const size_t lds = 16 * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
+    hipLaunchKernelGGL(k_sweep_diag, dim3(1), dim3((8 * d.P + 63) / 64 * 64), lds, st, c);
     return 0;
   }
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
