@@ -61,7 +61,9 @@ struct Curve {
 
 template <int BW, int LPC>
 struct Tile {
-  static constexpr int STR = LPC + 2 * BW;     // padded row stride
+  // padded row stride, ODD: lane a of a group reads row a in the dot products, and with an even stride the rows fall on
+  // the same LDS banks (stride 64 at BW = 0: every row on the same banks)
+  static constexpr int STR = LPC + 2 * BW + 1;
   double* base;
   __device__ inline double* row(int r) const { return base + r * STR + BW; }
   __device__ inline void zero_pads(int rows, int lp) const {
@@ -625,7 +627,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int GPB = 256 / LPC;
   const int nblk = (c.d.n + GPB - 1) / GPB;
   const int K = c.d.K, M = c.d.M;
-  const int STR = LPC + 2 * BW;
+  const int STR = LPC + 2 * BW + 1;
   const int D = c.d.D;
   const size_t nth = (size_t)K * (M + 1) * c.d.P;
   const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
