@@ -67,3 +67,65 @@ def test_warm_trajectory_matches_oracle_across_shapes(K, M, degree, n_internal, 
     for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]:
         err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
         assert err < 1e-6, (nm, err)
+
+
+@pytest.mark.parametrize("K,M,degree,n_internal,n,D,cov_adj", [
+    (2, 2, 3, 31, 70, 3, True),     # P = 35 (odd, > 32): 64-lane groups, C_a not 16-byte aligned for odd directions
+    (3, 3, 2, 37, 45, 2, True),     # P = 40, band width 2
+    (2, 1, 1, 6, 130, 8, True),     # the largest D, band width 1, more than one k_cov_group workgroup
+    (4, 2, 5, 10, 37, 1, False),    # band width 5, mean adjustment only
+    (3, 5, 4, 20, 33, 4, True),     # band width 4, P = 25, odd M
+])
+def test_covariate_adjusted_trajectory_across_shapes(K, M, degree, n_internal, n, D, cov_adj):
+    """The eta / Xi block (k_cov_prep, k_cov_w2, k_cov_factor, k_cov_group, k_cov_hyper) and the covariate variants of the
+    per-curve kernels for shapes other than the benchmark's."""
+    import bayesfmmm_amd as bf
+    from gpu_parity import oracle_slot
+    S = bf.sampler
+    T = 3
+    sim = simulate(n, K, M, degree, n_internal, seed=200 + K * 10 + M + D)
+    rng = np.random.default_rng(17 + D)
+    P = sim["P"]
+    X = rng.standard_normal((n, D))
+    eta = 0.5 * rng.standard_normal((P, D, K))
+    xi = 0.2 * rng.standard_normal((P, D, M, K)) * (1.0 if cov_adj else 0.0)
+    for i in range(n):          # add the covariate part of the mean to the simulated curves
+        c = np.zeros(P)
+        for k in range(K):
+            u = eta[:, :, k] @ X[i]
+            for m in range(M):
+                u = u + sim["chi"][i, m] * (xi[:, :, m, k] @ X[i])
+            c += sim["Z"][i, k] * u
+        sim["y"][i] = sim["y"][i] + sim["B"][i] @ c
+    model = O.Model(sim["y"], sim["B"], K, M, X=X)
+    ch = O.Chain(model, T)
+    ch.nu[:, :, 0] = sim["nu"] + 0.2 * rng.standard_normal((K, P))
+    ch.Phi[..., 0] = sim["Phi"] + 0.1 * rng.standard_normal((K, P, M))
+    ch.chi[:, :, 0] = sim["chi"] + 0.2 * rng.standard_normal((n, M))
+    ch.Z[:, :, 0] = rng.dirichlet(np.full(K, 2.0), size=n)
+    ch.pi[:, 0] = rng.dirichlet(np.full(K, 5.0))
+    ch.alpha3[0] = 3.5
+    ch.delta[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, M))
+    ch.A[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, 2))
+    ch.gamma[..., 0] = rng.gamma(2.0, 0.7, size=(K, P, M))
+    ch.tau[0, :] = rng.gamma(3.0, 0.5, size=K)
+    ch.sigma[0] = 0.02
+    ch.eta[..., 0] = eta + 0.1 * rng.standard_normal((P, D, K))
+    ch.xi[..., 0] = (xi + 0.05 * rng.standard_normal((P, D, M, K))) if cov_adj else 0.0
+    ch.tau_eta[..., 0] = rng.gamma(3.0, 0.5, size=(K, D))
+    ch.gamma_xi[..., 0] = rng.gamma(2.0, 0.7, size=(P, D, M, K))
+    ch.delta_xi[..., 0] = rng.gamma(2.0, 1.0, size=(K, M, D))
+    ch.A_xi[..., 0] = rng.gamma(2.0, 1.0, size=(K, 2, D))
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=degree, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, sim["y"], sim["t"], sim["internal_knots"], sim["boundary_knots"])
+    smp.set_covariates(X, cov_adj)
+    push_state(smp, ch)
+    smp.set_state(**{nm: oracle_slot(ch, nm, 0) for nm in ["eta", "xi", "tau_eta", "gamma_xi", "delta_xi", "A_xi"]})
+    h = O.make_hyper(K)
+    O.run_sweeps(model, h, ch, O.SWEEP_WARM, seed=3, covariance_adj=cov_adj)
+    smp.run(S.SWEEP_WARM | S.COV_MEAN | (S.COV_XI if cov_adj else 0), T, seed=3)
+    names = ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "eta", "tau_eta", "loglik"]
+    names += ["xi", "delta_xi", "A_xi", "gamma_xi"] if cov_adj else []
+    for nm in names:
+        err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
+        assert err < 1e-6, (nm, err)
