@@ -240,3 +240,18 @@ def test_mv_pipeline_covariate_adjusted(covariance_adj, tmp_path):
     assert os.path.exists(d + "Xi0.txt") == covariance_adj
     with pytest.raises(Exception, match="'X' must be have 'n_funct' number of rows"):
         api.BMVMMM_Nu_Z_multiple_try(T, 1, K, Y, M, X=X[:5])
+
+
+def test_mv_large_dim_with_covariates_matches_oracle():
+    """dim = 40 (> 32: 64-lane groups, k_sweep_diag with the covariate-adjusted residual term, the eta / Xi block at band
+    width 0) against the oracle."""
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    T = 3
+    dims, model, ch, smp = setup_mv_cov(seed=44, n=53, P=40, K=2, M=3, D=2, T=T, covariance_adj=True)
+    h = O.make_hyper(dims["K"])
+    O.run_sweeps(model, h, ch, O.SWEEP_WARM, seed=6, covariance_adj=True)
+    smp.run(S.SWEEP_WARM | S.COV_MEAN | S.COV_XI, T, seed=6)
+    for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "eta", "tau_eta", "xi",
+               "delta_xi", "A_xi", "gamma_xi", "loglik"]:
+        assert rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm))) < 1e-6, nm
