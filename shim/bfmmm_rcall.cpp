@@ -1,0 +1,380 @@
+// .Call shim: the BayesFMMM R package's compiled entry points over the C ABI of this repository.
+//
+// Drop this file into src/ of the R package in place of the bodies behind the Rcpp-generated stubs and link with
+// -lbfmmm_hip (PKG_LIBS).  It exports the SAME symbols with the SAME arity as src/RcppExports.cpp, so R/RcppExports.R and
+// every R-level signature, default and returned list name stay as they are:
+//
+//   _BayesFMMM_BFMMM_Nu_Z_multiple_try (28 args, RcppExports.cpp:358)   -> bfmmm_BFMMM_Nu_Z_multiple_try
+//   _BayesFMMM_BFMMM_Theta_est         (32,      :396)                  -> bfmmm_BFMMM_Theta_est
+//   _BayesFMMM_BFMMM_warm_start        (38,      :438)                  -> bfmmm_BFMMM_warm_start
+//   _BayesFMMM_BMVMMM_Nu_Z_multiple_try (23, :680), _BMVMMM_Theta_est (27, :713), _BMVMMM_warm_start (33, :750)
+//   _BayesFMMM_ReadVec / ReadMat / ReadCube / ReadFieldCube / ReadFieldMat / ReadFieldVec (1 arg each, :486-541)
+//
+// It is pure marshalling (no arithmetic): R lists of numeric vectors become CSR arrays, Rcpp::List arguments become
+// bfmmm_result objects, results become named R lists with the reference's shapes.  It needs <Rinternals.h> and is NOT
+// built by this repository's Makefile (the image has no R); INTEGRATION.md explains the build line.
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Random.h>
+#include <R_ext/Rdynload.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bfmmm_entry.h"
+
+namespace {
+
+struct Ragged { std::vector<double> v; std::vector<int64_t> off; };
+
+Ragged flatten(SEXP lst) {                              // R list of numeric vectors -> CSR
+  Ragged r;
+  r.off.push_back(0);
+  for (R_xlen_t i = 0; i < Rf_xlength(lst); ++i) {
+    SEXP e = VECTOR_ELT(lst, i);
+    r.v.insert(r.v.end(), REAL(e), REAL(e) + Rf_xlength(e));
+    r.off.push_back((int64_t)r.v.size());
+  }
+  return r;
+}
+
+uint64_t seed_from_R() {                                // one pair of uniforms from R's stream: set.seed() stays meaningful
+  GetRNGstate();
+  const uint64_t hi = (uint64_t)(unif_rand() * 4294967296.0), lo = (uint64_t)(unif_rand() * 4294967296.0);
+  PutRNGstate();
+  return (hi << 32) | lo;
+}
+
+std::vector<int64_t> dims_of(SEXP x) {
+  std::vector<int64_t> d;
+  SEXP ds = Rf_getAttrib(x, R_DimSymbol);
+  if (ds == R_NilValue) d.push_back((int64_t)Rf_xlength(x));
+  else for (int k = 0; k < Rf_length(ds); ++k) d.push_back(INTEGER(ds)[k]);
+  return d;
+}
+
+// Rcpp::List of a previous stage -> bfmmm_result.  Numeric arrays go in as they are; the list-valued elements of the
+// reference ("gamma", "Phi", "eta", "delta_xi", "A_xi": T arrays; "xi", "gamma_xi": a T x K list-matrix of cubes) are
+// stacked into one array with the slot last (xi / gamma_xi: slot t = the K cubes of that iteration, k fastest).
+bfmmm_result* list_to_result(SEXP lst) {
+  bfmmm_result* r = bfmmm_result_create();
+  SEXP nm = Rf_getAttrib(lst, R_NamesSymbol);
+  for (R_xlen_t i = 0; i < Rf_xlength(lst); ++i) {
+    SEXP e = VECTOR_ELT(lst, i);
+    const char* name = CHAR(STRING_ELT(nm, i));
+    if (TYPEOF(e) == REALSXP) {
+      std::vector<int64_t> d = dims_of(e);
+      bfmmm_result_set(r, name, REAL(e), (int64_t)Rf_xlength(e), d.data(), (int)d.size());
+    } else if (TYPEOF(e) == VECSXP && Rf_xlength(e) > 0 && TYPEOF(VECTOR_ELT(e, 0)) == REALSXP &&
+               std::strcmp(name, "B") != 0 && std::strcmp(name, "B_obs") != 0) {
+      SEXP fd = Rf_getAttrib(e, R_DimSymbol);            // T x K list-matrix (xi, gamma_xi) or a plain list of T arrays
+      const int64_t T = (fd == R_NilValue) ? (int64_t)Rf_xlength(e) : INTEGER(fd)[0];
+      const int64_t Kc = (fd == R_NilValue) ? 1 : INTEGER(fd)[1];
+      SEXP first = VECTOR_ELT(e, 0);
+      const int64_t len = (int64_t)Rf_xlength(first);
+      std::vector<double> all((size_t)(len * T * Kc));
+      for (int64_t t = 0; t < T; ++t)
+        for (int64_t k = 0; k < Kc; ++k)
+          std::memcpy(all.data() + (size_t)((t * Kc + k) * len), REAL(VECTOR_ELT(e, t + T * k)), sizeof(double) * (size_t)len);
+      std::vector<int64_t> d = dims_of(first);
+      if (Kc > 1) d.push_back(Kc);
+      d.push_back(T);
+      bfmmm_result_set(r, name, all.data(), (int64_t)all.size(), d.data(), (int)d.size());
+    }
+  }
+  return r;
+}
+
+SEXP array_of(const double* data, const int64_t* dims, int nd) {
+  SEXP ds = PROTECT(Rf_allocVector(INTSXP, nd));
+  R_xlen_t len = 1;
+  for (int k = 0; k < nd; ++k) { INTEGER(ds)[k] = (int)dims[k]; len *= (R_xlen_t)dims[k]; }
+  SEXP a = PROTECT(Rf_allocVector(REALSXP, len));
+  if (len > 0) std::memcpy(REAL(a), data, sizeof(double) * (size_t)len);
+  if (nd > 1) Rf_setAttrib(a, R_DimSymbol, ds);
+  UNPROTECT(2);
+  return a;
+}
+
+bool is_slot_list(const std::string& n) {     // returned as a list of T arrays by the reference (arma::field<arma::cube>)
+  return n == "gamma" || n == "Phi" || n == "eta" || n == "delta_xi" || n == "A_xi";
+}
+
+// bfmmm_result -> the named list the reference returns (UserFunctions.cpp:327-336, 887-897, 1094-1110)
+SEXP result_to_list(const bfmmm_result* r, const std::vector<int64_t>* offsets) {
+  const int n = bfmmm_result_count(r);
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, n));
+  SEXP names = PROTECT(Rf_allocVector(STRSXP, n));
+  for (int i = 0; i < n; ++i) {
+    const char* name = bfmmm_result_name(r, i);
+    const double* data; int64_t cnt; const int64_t* dims; int nd;
+    bfmmm_result_get(r, name, &data, &cnt, &dims, &nd);
+    const std::string s(name);
+    SEXP el;
+    if ((s == "B" || s == "B_obs") && offsets) {
+      // all basis rows, row-major (row l of curve i at (off[i] + l) * P): list of n_i x P column-major matrices
+      const int64_t P = dims[1], nf = (int64_t)offsets->size() - 1;
+      el = PROTECT(Rf_allocVector(VECSXP, nf));
+      for (int64_t c = 0; c < nf; ++c) {
+        const int64_t ni = (*offsets)[c + 1] - (*offsets)[c];
+        SEXP m = PROTECT(Rf_allocMatrix(REALSXP, (int)ni, (int)P));
+        for (int64_t l = 0; l < ni; ++l)
+          for (int64_t p = 0; p < P; ++p) REAL(m)[l + ni * p] = data[((*offsets)[c] + l) * P + p];
+        SET_VECTOR_ELT(el, c, m);
+        UNPROTECT(1);
+      }
+    } else if (is_slot_list(s)) {
+      const int64_t T = dims[nd - 1], len = cnt / T;
+      el = PROTECT(Rf_allocVector(VECSXP, T));
+      for (int64_t t = 0; t < T; ++t) SET_VECTOR_ELT(el, t, array_of(data + t * len, dims, nd - 1));
+    } else if (s == "xi" || s == "gamma_xi") {           // P x D x M x K x T -> T x K list-matrix of P x D x M cubes
+      const int64_t T = dims[nd - 1], Kc = dims[nd - 2], len = cnt / (T * Kc);
+      el = PROTECT(Rf_allocVector(VECSXP, T * Kc));
+      for (int64_t t = 0; t < T; ++t)
+        for (int64_t k = 0; k < Kc; ++k) SET_VECTOR_ELT(el, t + T * k, array_of(data + (t * Kc + k) * len, dims, nd - 2));
+      SEXP fd = PROTECT(Rf_allocVector(INTSXP, 2));
+      INTEGER(fd)[0] = (int)T; INTEGER(fd)[1] = (int)Kc;
+      Rf_setAttrib(el, R_DimSymbol, fd);
+      UNPROTECT(1);
+    } else {
+      el = PROTECT(array_of(data, dims, nd));
+    }
+    SET_VECTOR_ELT(out, i, el);
+    SET_STRING_ELT(names, i, Rf_mkChar(name));
+    UNPROTECT(1);
+  }
+  Rf_setAttrib(out, R_NamesSymbol, names);
+  UNPROTECT(2);
+  return out;
+}
+
+// the hyper-parameters every entry point shares, in the order of the reference's signatures
+struct Hyper {
+  SEXP c, b, nu_1, alpha1l, alpha2l, beta1l, beta2l, a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2, alpha_nu, beta_nu,
+       alpha_eta, beta_eta, alpha_0, beta_0;
+};
+
+void set_hyper(bfmmm_entry_args& a, const Hyper& h) {
+  a.c = (h.c == R_NilValue) ? NULL : REAL(h.c);
+  a.b = Rf_asReal(h.b);
+  if (h.nu_1 != R_NilValue) a.nu_1 = Rf_asReal(h.nu_1);
+  a.alpha1l = Rf_asReal(h.alpha1l); a.alpha2l = Rf_asReal(h.alpha2l);
+  a.beta1l = Rf_asReal(h.beta1l); a.beta2l = Rf_asReal(h.beta2l);
+  a.a_Z_PM = Rf_asReal(h.a_Z_PM); a.a_pi_PM = Rf_asReal(h.a_pi_PM); a.var_alpha3 = Rf_asReal(h.var_alpha3);
+  a.var_epsilon1 = Rf_asReal(h.var_epsilon1); a.var_epsilon2 = Rf_asReal(h.var_epsilon2);
+  a.alpha_nu = Rf_asReal(h.alpha_nu); a.beta_nu = Rf_asReal(h.beta_nu);
+  a.alpha_eta = Rf_asReal(h.alpha_eta); a.beta_eta = Rf_asReal(h.beta_eta);
+  a.alpha_0 = Rf_asReal(h.alpha_0); a.beta_0 = Rf_asReal(h.beta_0);
+}
+
+void set_X(bfmmm_entry_args& a, SEXP X, SEXP covariance_adj) {
+  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+  if (covariance_adj != R_NilValue) a.covariance_adj = Rf_asLogical(covariance_adj) ? 1 : 0;
+}
+
+void set_functional(bfmmm_entry_args& a, const Ragged& Y, const Ragged& tm, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
+                    SEXP boundary_knots, SEXP internal_knots) {
+  a.n_funct = Rf_asInteger(n_funct);
+  a.y = Y.v.data(); a.t = tm.v.data(); a.offsets = Y.off.data();
+  a.basis_degree = Rf_asInteger(basis_degree); a.n_eigen = Rf_asInteger(n_eigen);
+  a.n_internal_knots = Rf_length(internal_knots);
+  a.boundary_knots = REAL(boundary_knots); a.internal_knots = REAL(internal_knots);
+}
+
+void set_multivariate(bfmmm_entry_args& a, SEXP Y, SEXP n_eigen) {
+  a.model = 1;                                           // BFMMM_MODEL_MULTIVARIATE
+  a.y = REAL(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
+  a.n_eigen = Rf_asInteger(n_eigen);
+}
+
+void set_warm(bfmmm_entry_args& a, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans, SEXP r_stored_iters) {
+  a.dir = (dir == R_NilValue) ? NULL : CHAR(STRING_ELT(dir, 0));
+  a.thinning_num = Rf_asReal(thinning_num); a.beta_N_t = Rf_asReal(beta_N_t);
+  a.N_t = Rf_asInteger(N_t); a.n_temp_trans = Rf_asInteger(n_temp_trans); a.r_stored_iters = Rf_asInteger(r_stored_iters);
+}
+
+SEXP finish(int rc, bfmmm_result* r, const std::vector<int64_t>* offsets, bfmmm_result* p1 = NULL, bfmmm_result* p2 = NULL) {
+  if (p1) bfmmm_result_free(p1);
+  if (p2) bfmmm_result_free(p2);
+  if (rc) Rf_error("%s", bfmmm_entry_last_error());      // (r is NULL on failure)
+  SEXP out = PROTECT(result_to_list(r, offsets));
+  bfmmm_result_free(r);
+  UNPROTECT(1);
+  return out;
+}
+
+SEXP read_plain(SEXP file, bool as_vector) {
+  bfmmm_result* r = NULL;
+  if (bfmmm_arma_read(CHAR(STRING_ELT(file, 0)), &r)) Rf_error("%s", bfmmm_entry_last_error());
+  const double* data; int64_t cnt; const int64_t* dims; int nd;
+  bfmmm_result_get(r, "value", &data, &cnt, &dims, &nd);
+  const int64_t one = cnt;
+  SEXP out = PROTECT(as_vector ? array_of(data, &one, 1) : array_of(data, dims, nd));
+  bfmmm_result_free(r);
+  UNPROTECT(1);
+  return out;
+}
+
+SEXP read_field(SEXP file, bool as_vectors) {             // arma::field -> list-matrix (n_rows x n_cols)
+  bfmmm_result* r = NULL;
+  if (bfmmm_arma_read_field(CHAR(STRING_ELT(file, 0)), &r)) Rf_error("%s", bfmmm_entry_last_error());
+  const double* fd; int64_t cnt; const int64_t* dims; int nd;
+  bfmmm_result_get(r, "field_dims", &fd, &cnt, &dims, &nd);
+  const int64_t nr = (int64_t)fd[0], nc = (int64_t)fd[1];
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, nr * nc));
+  for (int64_t e = 0; e < nr * nc; ++e) {
+    const double* data;
+    bfmmm_result_get(r, std::to_string(e).c_str(), &data, &cnt, &dims, &nd);
+    const int64_t one = cnt;
+    SET_VECTOR_ELT(out, e, as_vectors ? array_of(data, &one, 1) : array_of(data, dims, nd));
+  }
+  SEXP d2 = PROTECT(Rf_allocVector(INTSXP, 2));
+  INTEGER(d2)[0] = (int)nr; INTEGER(d2)[1] = (int)nc;
+  Rf_setAttrib(out, R_DimSymbol, d2);
+  bfmmm_result_free(r);
+  UNPROTECT(2);
+  return out;
+}
+
+}  // namespace
+
+#define H18 SEXP c, SEXP b, SEXP alpha1l, SEXP alpha2l, SEXP beta1l, SEXP beta2l, SEXP a_Z_PM, SEXP a_pi_PM, SEXP var_alpha3, \
+            SEXP var_epsilon1, SEXP var_epsilon2, SEXP alpha_nu, SEXP beta_nu, SEXP alpha_eta, SEXP beta_eta, SEXP alpha_0, SEXP beta_0
+#define H19 SEXP c, SEXP b, SEXP nu_1, SEXP alpha1l, SEXP alpha2l, SEXP beta1l, SEXP beta2l, SEXP a_Z_PM, SEXP a_pi_PM, \
+            SEXP var_alpha3, SEXP var_epsilon1, SEXP var_epsilon2, SEXP alpha_nu, SEXP beta_nu, SEXP alpha_eta, SEXP beta_eta, \
+            SEXP alpha_0, SEXP beta_0
+#define HY18 Hyper{c, b, R_NilValue, alpha1l, alpha2l, beta1l, beta2l, a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2, \
+                   alpha_nu, beta_nu, alpha_eta, beta_eta, alpha_0, beta_0}
+#define HY19 Hyper{c, b, nu_1, alpha1l, alpha2l, beta1l, beta2l, a_Z_PM, a_pi_PM, var_alpha3, var_epsilon1, var_epsilon2, \
+                   alpha_nu, beta_nu, alpha_eta, beta_eta, alpha_0, beta_0}
+
+extern "C" {
+
+// ---- functional model ----------------------------------------------------------------------------------------
+SEXP _BayesFMMM_BFMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
+                                        SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP X, H18) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 0);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, R_NilValue);
+  set_hyper(a, HY18);
+  a.seed = seed_from_R();
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BFMMM_Nu_Z_multiple_try(&a, &r), r, &y.off);
+}
+
+SEXP _BayesFMMM_BFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
+                                SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP X,
+                                SEXP burnin_prop, H19, SEXP covariance_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 1);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, covariance_adj);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
+}
+
+SEXP _BayesFMMM_BFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
+                                 SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP theta_est, SEXP X,
+                                 SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
+                                 SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 2);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, covariance_adj);
+  set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* te = list_to_result(theta_est);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
+}
+
+// ---- multivariate model ----------------------------------------------------------------------------------------
+SEXP _BayesFMMM_BMVMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP n_eigen, SEXP X, H18) {
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 3);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  set_multivariate(a, Y, n_eigen);
+  set_X(a, X, R_NilValue);
+  set_hyper(a, HY18);
+  a.seed = seed_from_R();
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BMVMMM_Nu_Z_multiple_try(&a, &r), r, NULL);
+}
+
+SEXP _BayesFMMM_BMVMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP n_eigen, SEXP multiple_try, SEXP X,
+                                 SEXP burnin_prop, H19, SEXP covariance_adj) {
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 4);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_multivariate(a, Y, n_eigen);
+  set_X(a, X, covariance_adj);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BMVMMM_Theta_est(&a, mt, &r), r, NULL, mt);
+}
+
+SEXP _BayesFMMM_BMVMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP n_eigen, SEXP multiple_try, SEXP theta_est, SEXP X,
+                                  SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
+                                  SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  bfmmm_entry_args a;
+  bfmmm_entry_defaults(&a, 5);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_multivariate(a, Y, n_eigen);
+  set_X(a, X, covariance_adj);
+  set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* te = list_to_result(theta_est);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BMVMMM_warm_start(&a, mt, te, &r), r, NULL, mt, te);
+}
+
+// ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
+SEXP _BayesFMMM_ReadVec(SEXP file) { return read_plain(file, true); }
+SEXP _BayesFMMM_ReadMat(SEXP file) { return read_plain(file, false); }
+SEXP _BayesFMMM_ReadCube(SEXP file) { return read_plain(file, false); }
+SEXP _BayesFMMM_ReadFieldCube(SEXP file) { return read_field(file, false); }
+SEXP _BayesFMMM_ReadFieldMat(SEXP file) { return read_field(file, false); }
+SEXP _BayesFMMM_ReadFieldVec(SEXP file) { return read_field(file, true); }
+
+static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.cpp:794-835 (the entries this shim replaces)
+    {"_BayesFMMM_BFMMM_Nu_Z_multiple_try", (DL_FUNC)&_BayesFMMM_BFMMM_Nu_Z_multiple_try, 28},
+    {"_BayesFMMM_BFMMM_Theta_est", (DL_FUNC)&_BayesFMMM_BFMMM_Theta_est, 32},
+    {"_BayesFMMM_BFMMM_warm_start", (DL_FUNC)&_BayesFMMM_BFMMM_warm_start, 38},
+    {"_BayesFMMM_BMVMMM_Nu_Z_multiple_try", (DL_FUNC)&_BayesFMMM_BMVMMM_Nu_Z_multiple_try, 23},
+    {"_BayesFMMM_BMVMMM_Theta_est", (DL_FUNC)&_BayesFMMM_BMVMMM_Theta_est, 27},
+    {"_BayesFMMM_BMVMMM_warm_start", (DL_FUNC)&_BayesFMMM_BMVMMM_warm_start, 33},
+    {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
+    {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
+    {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
+    {"_BayesFMMM_ReadFieldCube", (DL_FUNC)&_BayesFMMM_ReadFieldCube, 1},
+    {"_BayesFMMM_ReadFieldMat", (DL_FUNC)&_BayesFMMM_ReadFieldMat, 1},
+    {"_BayesFMMM_ReadFieldVec", (DL_FUNC)&_BayesFMMM_ReadFieldVec, 1},
+    {NULL, NULL, 0}};
+
+void R_init_BayesFMMM(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
+
+}  // extern "C"
