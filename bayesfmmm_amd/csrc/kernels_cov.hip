@@ -11,7 +11,10 @@
 // steps over the per-curve fitted coefficient c_i and g_i = G_i c_i kept in HBM:
 //     rhs_a = (1/sigma^2) [ sum_i w_i (s_i - g_i) + (sum_i w_i^2 G_i) theta_a ],   theta_a ~ N(C_a rhs_a, C_a),
 //     c_i += w_i (theta_a_new - theta_a_old),   g_i += w_i G_i (theta_a_new - theta_a_old)
-// (the c_i / g_i update of step s is applied lazily at the start of step s+1): one launch per direction, k_cov_step.
+// The directions are visited in the reference's order, D consecutive directions ("group") per launch: inside a group a
+// direction sees the earlier draws through the in-group pair blocks H_su = sum_i w_s w_u G_i (k_cov_w2), the c_i / g_i
+// update of a group is applied at the start of the next launch (k_cov_group).  Launch sequence of one iteration:
+//   k_cov_prep -> k_cov_w2 -> k_cov_factor -> (K + K M) x k_cov_group -> k_cov_hyper.
 #include "model.hpp"
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
