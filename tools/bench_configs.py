@@ -72,12 +72,46 @@ def config5(args):
     [t_.start() for t_ in ths]
     [t_.join() for t_ in ths]
     dt7 = time.perf_counter() - t1
+    cpu = cpu_chains(w, args.cpu_iters) if args.cpu_iters > 0 else None
     n, P = w["n"], w["P"]
     b_alg = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * w["K"]      # 3 blocks per chain-iteration
     return {"workload": "config 5: Nu_Z sweep (BFMMM_Nu_Z_multiple_try chains) on the config-2 data, one GPU",
             "steps": args.steps, "single_chain_ms_per_sweep": dt1 * 1e3, "single_chain_iterations_per_s": 1.0 / dt1,
             "seven_concurrent_chains_iterations_per_s": 7 * args.steps / dt7,
-            "single_chain_hbm_frac": b_alg / dt1 / 8e12}
+            "single_chain_hbm_frac": b_alg / dt1 / 8e12, "cpu_all_cores": cpu}
+
+
+def cpu_chains(w, iters):
+    """the CPU restatement of the same chains on ALL host cores -- one independent Nu_Z chain per core
+    (the reference itself is single-threaded; independent multi-try chains are the only parallelism it offers)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = len(os.sched_getaffinity(0))
+    C = min(8, cores)
+    h = O.make_hyper(w["K"])
+    models, chains = [], []
+    for q in range(C):
+        model = O.Model(w["y"], w["B"], w["K"], w["M"])
+        ch = O.Chain(model, iters)
+        st = w["state"]
+        ch.nu[:, :, 0] = st["nu"]; ch.Z[:, :, 0] = st["Z"]; ch.pi[:, 0] = st["pi"]; ch.alpha3[0] = st["alpha_3"][0]
+        ch.tau[0, :] = st["tau"]; ch.sigma[0] = st["sigma_sq"][0]
+        ch.delta[:, :, 0] = 1.0; ch.A[:, :, 0] = 1.0; ch.gamma[..., 0] = 1.0
+        models.append(model); chains.append(ch)
+
+    def work(q):
+        O.run_sweeps(models[q], h, chains[q], O.SWEEP_NU_Z, n_iter=iters, seed=1, chain_id=q)
+    t0 = time.perf_counter()
+    work(0)
+    dt1 = time.perf_counter() - t0
+    ths = [threading.Thread(target=work, args=(q,)) for q in range(C)]
+    t0 = time.perf_counter()
+    [t_.start() for t_ in ths]
+    [t_.join() for t_ in ths]
+    dtc = time.perf_counter() - t0
+    return {"threads": C, "host_cores": cores, "one_thread_iterations_per_s": iters / dt1,
+            "all_threads_chain_iterations_per_s": C * iters / dtc,
+            "sample": f"{iters} Nu_Z sweeps per chain of the reference-structure C restatement, gcc -O2"}
 
 
 def main():
@@ -86,6 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="config 5: also time the CPU restatement, this many sweeps per chain")
     a = ap.parse_args()
     print(json.dumps(config4(a) if a.config == 4 else config5(a)))
 
