@@ -80,9 +80,25 @@ def cpu_baseline(w, iters=2):
     t0 = time.perf_counter()
     O.run_sweeps(model, h, ch, O.SWEEP_WARM, n_iter=iters, seed=1)
     dt = time.perf_counter() - t0
+    # the same sweep in sufficient-statistics ("Gram") form on the same core (oracle/gram.c): splits the GPU speed-up
+    # into its algorithmic part (this / the reference-structure loops) and its hardware part (GPU / this)
+    g_iters = 20
+    ch2 = O.Chain(model, g_iters)
+    for nm, v in w["state"].items():
+        arr = getattr(ch2, names.get(nm, nm))
+        if nm == "tau":
+            arr[0, :] = v
+        elif arr.ndim == 1:
+            arr[0] = v[0]
+        else:
+            arr[..., 0] = v
+    dtg = O.run_warm_gram(model, h, ch2, n_iter=g_iters, seed=1)
     return dict(value=iters / dt, unit="Gibbs iterations/sec", cores=1, kind="port",
                 sample=f"{iters} full-size warm-start sweeps (n_funct={w['n']}) of the reference-structure C "
-                       f"restatement of the Armadillo path, {dt:.1f} s, gcc -O2, 1 thread")
+                       f"restatement of the Armadillo path, {dt:.1f} s, gcc -O2, 1 thread",
+                gram_form=dict(value=g_iters / dtg, unit="Gibbs iterations/sec", cores=1,
+                               sample=f"{g_iters} sweeps of the same restatement in sufficient-statistics form "
+                                      f"(oracle/gram.c), {dtg:.1f} s; G_i, s_i, yy_i prepared once, not timed"))
 
 
 def main():

@@ -161,6 +161,15 @@ enum { ORC_SWEEP_NU_Z = 0, ORC_SWEEP_THETA = 1, ORC_SWEEP_WARM = 2 };
  * d->D > 0, the covariate-adjusted orders (BFMMM.h:3741-3780 / 3944-4010 / 4809-4894).
  * covariance_adj selects the Xi block in the covariate-adjusted sweeps. */
 /* tempered transitions (functional model, D == 0): BFMMM.h:1452-1460, :1556-1672; CalculateTTAcceptance.h:22-97 */
+void orc_rdirichlet(const orc_rng* r, uint32_t upd, uint32_t idx0, int K, const double* alpha, double* out);   /* updates.c */
+
+/* ---- gram.c : the warm-start sweep in sufficient-statistics form (algorithm vs hardware) ---- */
+struct orc_gram_s;
+struct orc_gram_s* orc_gram_prepare(const orc_data* d);
+void orc_gram_free(struct orc_gram_s* g);
+void orc_gram_run_warm(const orc_data* d, const struct orc_gram_s* g, const orc_hyper* h, uint64_t seed, uint32_t chain, int T,
+                       int first_iter, int n_iter, orc_chain* c);
+
 void orc_beta_ladder(int N_t, double beta_N_t, double* ladder);
 double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_chain* c);
 double orc_calculatePZetaCov(const orc_data* d, double beta_i, int iter, const orc_chain* c);   /* updates.c */

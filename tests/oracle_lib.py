@@ -229,6 +229,26 @@ def run_sweeps(model, hyper, chain, sweep, n_iter=None, seed=1, chain_id=0, cova
 SWEEP_NU_Z, SWEEP_THETA, SWEEP_WARM = 0, 1, 2
 
 
+def run_warm_gram(model, hyper, chain, n_iter=None, seed=1, chain_id=0, first_iter=0):
+    """The warm-start sweep in sufficient-statistics form on the CPU (oracle/gram.c); returns the seconds spent in the
+    sweeps (the one-off G_i, s_i, yy_i pass is not included)."""
+    import time
+    n_iter = chain.T if n_iter is None else n_iter
+    L = lib()
+    L.orc_gram_prepare.restype = C.c_void_p
+    L.orc_gram_prepare.argtypes = [C.c_void_p]
+    L.orc_gram_free.argtypes = [C.c_void_p]
+    L.orc_gram_run_warm.restype = None
+    L.orc_gram_run_warm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    g = L.orc_gram_prepare(C.addressof(model.data))
+    t0 = time.perf_counter()
+    L.orc_gram_run_warm(C.addressof(model.data), g, C.addressof(hyper), seed, chain_id, chain.T, first_iter, n_iter,
+                        C.addressof(chain.c))
+    dt = time.perf_counter() - t0
+    L.orc_gram_free(g)
+    return dt
+
+
 def run_warm_tt(model, hyper, chain, N_t, n_temp_trans, beta_N_t, n_iter=None, seed=1, chain_id=0, first_iter=0,
                 covariance_adj=False):
     """BFMMM_MTT_warm_start with tempered transitions (BFMMM.h:1502-1672); returns (logA, accepted) per iteration."""
