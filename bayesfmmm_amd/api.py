@@ -56,6 +56,9 @@ ENTRY_SYMBOLS = {
     "bfmmm_arma_read_field": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfmmm_arma_write_ascii": (C.c_int, [C.c_char_p, c_double_p, c_int64_p, C.c_int]),
     "bfmmm_arma_write_field": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "bfmmm_tensor_bspline": (C.c_int, [C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int),
+                                       c_double_p, c_double_p]),
+    "bfmmm_tensor_penalty": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p]),
     "bfmmm_entry_last_error": (C.c_char_p, []),
 }
 
@@ -363,3 +366,30 @@ def write_arma_field(file, field):
         _check(lib.bfmmm_arma_write_field(str(file).encode(), res, nr, nc))
     finally:
         lib.bfmmm_result_free(res)
+
+
+# ---- set-up pieces of the high-dimensional functional model (BSplines.h:18-120) -----------------------------------
+def TensorBSpline(t, basis_degree, boundary_knots, internal_knots):
+    """Tensor-product B-spline basis of the points t (n_pts x dim): n_pts x prod_l (len(internal_knots[l]) + degree[l] + 1)."""
+    t = np.asfortranarray(np.asarray(t, dtype=np.float64))
+    n_pts, dim = t.shape
+    deg = (C.c_int * dim)(*[int(x) for x in basis_degree])
+    nint = (C.c_int * dim)(*[len(k) for k in internal_knots])
+    bk = np.ascontiguousarray(np.asarray(boundary_knots, dtype=np.float64).reshape(dim, 2))
+    ik = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=np.float64).reshape(-1) for k in internal_knots]) if dim else [])
+    P = int(np.prod([len(k) + int(g) + 1 for k, g in zip(internal_knots, basis_degree)]))
+    out = np.zeros((n_pts, P), order="F")
+    _check(_lib_entry().bfmmm_tensor_bspline(n_pts, dim, t.ctypes.data_as(c_double_p), deg, bk.ctypes.data_as(c_double_p), nint,
+                                             ik.ctypes.data_as(c_double_p), out.ctypes.data_as(c_double_p)))
+    return out
+
+
+def GetP(basis_degree, n_internal_knots):
+    """Penalty matrix of the tensor-product basis (BSplines.h:74-120)."""
+    dim = len(basis_degree)
+    deg = (C.c_int * dim)(*[int(x) for x in basis_degree])
+    nint = (C.c_int * dim)(*[int(x) for x in n_internal_knots])
+    P = int(np.prod([int(k) + int(g) + 1 for k, g in zip(n_internal_knots, basis_degree)]))
+    out = np.zeros((P, P), order="F")
+    _check(_lib_entry().bfmmm_tensor_penalty(dim, deg, nint, out.ctypes.data_as(c_double_p)))
+    return out

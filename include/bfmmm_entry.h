@@ -122,6 +122,15 @@ int bfmmm_arma_read_field(const char* file, bfmmm_result** out);
 int bfmmm_arma_write_ascii(const char* file, const double* data, const int64_t* dims, int n_dims);
 int bfmmm_arma_write_field(const char* file, const bfmmm_result* items, int64_t n_rows, int64_t n_cols);
 
+/* Set-up pieces of the high-dimensional functional model (BHDFMMM_*; the sampler for its wide-band statistics is not
+ * built yet): the tensor-product B-spline basis of TensorBSpline (inst/include/BayesFMMM/BSplines.h:18-66) for n_pts
+ * points in `dim` dimensions -- t is n_pts x dim column-major, boundary_knots dim x 2 row-major, internal_knots the
+ * dimensions' knots one after the other, out n_pts x P column-major with the last dimension's index running fastest --
+ * and the penalty matrix of GetP (BSplines.h:74-120), P x P. */
+int bfmmm_tensor_bspline(int n_pts, int dim, const double* t, const int* degree, const double* boundary_knots,
+                         const int* n_internal, const double* internal_knots, double* out);
+int bfmmm_tensor_penalty(int dim, const int* degree, const int* n_internal, double* out);
+
 /* message of the last failing bfmmm_result_* / bfmmm_BFMMM_* call on this thread */
 const char* bfmmm_entry_last_error(void);
 
