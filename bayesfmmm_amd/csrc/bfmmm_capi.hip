@@ -87,6 +87,7 @@ struct bfmmm_handle {
   bool g_valid = false;                // the captured graphs match (g_mask, g_md, g_seed, g_chain)
   int slot_base = 0;                   // chain slot of iteration i is i - slot_base (bfmmm_set_slot_base)
   double* tt_save = nullptr;            // state saved across a tempered-transition block
+  std::vector<double> B_host;           // bfmmm_create_from_basis: the caller's basis rows (bfmmm_get_basis)
   bool state_dirty = true;             // the state was changed from the host: proposals prepared on the device are stale
   int profile = 0;
   double fam_ms[FAM_COUNT] = {0};
@@ -156,8 +157,33 @@ static void pg_geometry(const Dims& d, int& NTG, int& NKS, int& KS) {
   NTG = 1;
 }
 
+// a basis supplied by the caller (bfmmm_create_from_basis): rows of B, its band, the penalty of the nu prior
+struct BasisSpec {
+  int P, band, pen_band;
+  const double* B;        // n_obs x P row-major
+  const double* Pmat;     // P x P column-major
+};
+
+static int create_impl(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, bfmmm_handle** out);
+
 extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
                             const double* internal_knots, const double* boundary_knots, bfmmm_handle** out) {
+  return create_impl(cfg, device, y, t, offsets, internal_knots, boundary_knots, nullptr, out);
+}
+
+extern "C" int bfmmm_create_from_basis(const bfmmm_config* cfg, int device, const double* y, const double* B, const int64_t* offsets,
+                                       int P, int band, const double* Pmat, int pen_band, bfmmm_handle** out) {
+  if (!cfg || !y || !B || !offsets || !Pmat || !out) return fail("bfmmm_create_from_basis: null argument");
+  if (cfg->model != BFMMM_MODEL_FUNCTIONAL) return fail("bfmmm_create_from_basis: functional model only");
+  if (P < 1 || band < 0 || pen_band < 0) return fail("bfmmm_create_from_basis: bad dimensions");
+  if (band > BWWIDE) return fail("bfmmm_create_from_basis: the band half-width of B'B must not exceed 31 in this build");
+  BasisSpec bs = {P, band, pen_band, B, Pmat};
+  return create_impl(cfg, device, y, nullptr, offsets, nullptr, nullptr, &bs, out);
+}
+
+static int create_impl(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, bfmmm_handle** out) {
   if (!cfg || !out || !y) return fail("bfmmm_create: null argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -174,6 +200,9 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   if (mv) {
     P = cfg->P; BW = 0;
     if (P < 1) return fail("multivariate model: P must be positive");
+  } else if (bs) {
+    P = bs->P;
+    BW = (bs->band <= BWMAX) ? std::min(bs->band, std::max(P - 1, 0)) : BWWIDE;     // wide bands share one instantiation (zero padded)
   } else {
     if (!t || !offsets || !boundary_knots || (cfg->n_internal_knots > 0 && !internal_knots))
       return fail("bfmmm_create: null argument");
@@ -215,6 +244,8 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   d.LREC = (d.LG + P + 1 + 1) / 2 * 2;
   d.mv = mv ? 1 : 0;
   d.BWP = mv ? 0 : std::max(BW, 1);   // RW1 penalty is tridiagonal
+  if (bs) d.BWP = std::min(std::max(BW, bs->pen_band), (BW > BWMAX) ? BWWIDE : BWMAX);
+  if (bs && BW <= BWMAX && bs->pen_band > BWMAX) return fail("bfmmm_create_from_basis: a penalty band wider than 5 needs a basis band wider than 5 in this build");
   set_md(d, M + 1);
   for (int k = 0; k < KMAX; ++k) c.h.c[k] = (k < 8) ? cfg->c[k] : 10.0;
   c.h.b = cfg->b; c.h.nu_1 = cfg->nu_1;
@@ -247,7 +278,9 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   double* pm;
   if (dalloc(h, &pm, (size_t)P * P)) return 1;
   c.Pmat = pm;
-  {
+  if (bs) {
+    HIPCHK(copy_sync(h, pm, bs->Pmat, sizeof(double) * (size_t)P * P, hipMemcpyHostToDevice));
+  } else {
     // RW1 penalty, BFMMM.h:1027-1037
     std::vector<double> Pm((size_t)P * P, 0.0);
     for (int j = 0; j < P; ++j) {
@@ -271,6 +304,27 @@ extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y
   if (dalloc(h, &d_err, 1)) return 1;
   if (mv) {
     launch_stats_multivariate(n, P, d.LREC, h->d_y, rec, ni, h->st);
+  } else if (bs) {
+    // per-curve statistics from the supplied basis rows, on the host (a set-up step): band-packed G_i = B_i'B_i
+    // ([dd * P + lo] = G(lo, lo + dd), dd <= BW), s_i = B_i'y_i, yy_i
+    std::vector<double> hrec((size_t)n * d.LREC, 0.0);
+    std::vector<int> hni((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      double* r = hrec.data() + (size_t)i * d.LREC;
+      hni[i] = (int)(offsets[i + 1] - offsets[i]);
+      for (int64_t l = offsets[i]; l < offsets[i + 1]; ++l) {
+        const double* b = bs->B + (size_t)l * P;
+        for (int lo = 0; lo < P; ++lo) {
+          if (b[lo] == 0.0) continue;
+          for (int dd = 0; dd <= BW && lo + dd < P; ++dd) r[dd * P + lo] += b[lo] * b[lo + dd];
+          r[d.LG + lo] += b[lo] * y[l];
+        }
+        r[d.LG + P] += y[l] * y[l];
+      }
+    }
+    HIPCHK(copy_sync(h, rec, hrec.data(), sizeof(double) * hrec.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, ni, hni.data(), sizeof(int) * hni.size(), hipMemcpyHostToDevice));
+    h->B_host.assign(bs->B, bs->B + (size_t)n_obs * P);
   } else {
     const int deg = cfg->basis_degree, nint = cfg->n_internal_knots;
     h->n_knots = nint + 2 * (deg + 1);
@@ -313,6 +367,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   if (!h || !X) return fail("bfmmm_set_covariates: null argument");
   if (D < 1 || D > 8) return fail("bfmmm_set_covariates: the number of covariates must be between 1 and 8 in this build");
   if (h->c.d.D != 0) return fail("bfmmm_set_covariates: covariates are already set");
+  if (h->c.d.BW > BWMAX) return fail("bfmmm_set_covariates: covariate adjustment with a wide-band basis is not supported in this build");
   HIPCHK(hipSetDevice(h->device));
   Ctx& c = h->c;
   Dims& d = c.d;
@@ -374,6 +429,7 @@ extern "C" int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity) {
   if (d.mv) return fail("bfmmm_get_basis: the multivariate model has no basis");
   const int64_t need = h->n_obs * d.P;
   if (capacity < need) return fail("bfmmm_get_basis: buffer too small");
+  if (!h->B_host.empty()) { std::copy(h->B_host.begin(), h->B_host.end(), out); return 0; }
   HIPCHK(hipSetDevice(h->device));
   double* dB = nullptr; double* rec_tmp = nullptr; int* ni_tmp = nullptr; int* err = nullptr;
   HIPCHK(hipMalloc((void**)&dB, sizeof(double) * (size_t)need));

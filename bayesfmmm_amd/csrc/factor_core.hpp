@@ -138,7 +138,45 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
     }
     return __syncthreads_or(bad ? 1 : 0) != 0;       // every thread reports (the callers test thread 0)
   }
-  if (tid < 64) {
+  if (bw > 5) {
+    // wide band (user-supplied / tensor-product bases): plain dense reverse Cholesky in LDS.  S must be fully defined.
+    // Prec = U U', U upper, columns from the last to the first: U(k,k) = sqrt(A(k,k)), U(i,k) = A(i,k) / U(k,k) (i < k),
+    // then A(i,j) -= U(i,k) U(j,k) for i, j < k (right-looking).  U overwrites the upper triangle of S (S[i + PP*k]).
+    for (int k = P - 1; k >= 0; --k) {
+      __syncthreads();                               // the previous column's update of the leading block is complete
+      const double dk = S[k + PP * k];
+      if (!(dk > 0.0)) bad = true;
+      const double rk = 1.0 / sqrt(dk);
+      __syncthreads();                               // everyone has the pivot before column k is overwritten
+      if (tid <= k) S[tid + PP * k] = (tid == k) ? dk * rk : S[tid + PP * k] * rk;
+      __syncthreads();
+      for (int e = tid; e < k * k; e += 256) {
+        const int i = e % k, j = e / k;
+        S[i + PP * j] -= S[i + PP * k] * S[j + PP * k];
+      }
+    }
+    __syncthreads();
+    // X = U^-1 (upper, row-major X[i*PP + c]): row i from the last up, column c >= i, 4 lanes per column
+    for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
+    __syncthreads();
+    const int cc = tid >> 2, ql = tid & 3;
+    for (int i = P - 1; i >= 0; --i) {
+      double acc = 0.0;
+      if (cc < P && cc > i)
+        for (int m = i + 1 + ql; m <= cc; m += 4) acc += S[i + PP * m] * X[m * PP + cc];
+      acc = dpp_add<0xB1>(acc);
+      acc = dpp_add<0x4E>(acc);
+      __syncthreads();
+      if (ql == 0 && cc < P && cc >= i) X[i * PP + cc] = ((cc == i) ? 1.0 - acc : -acc) / S[i + PP * i];
+      __syncthreads();
+    }
+    if (tid < P) {
+      double lz = 0.0;
+      for (int i = 0; i <= tid; ++i) lz += X[i * PP + tid] * zv[i];
+      Lz_out[tid] = lz;
+    }
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+  } else if (tid < 64) {
     switch (bw) {
       case 0: bad = factor_wave<PP, 0>(S, X, zv, P, Lz_out, tid); break;
       case 1: bad = factor_wave<PP, 1>(S, X, zv, P, Lz_out, tid); break;

@@ -409,8 +409,8 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   double* part = thp + A * PS;      // A x P  : (H_ab theta_b)[p]
   double* zv = part + AP;           // PP
   double* hb2 = zv + PP;            // P x W  : rows of H_aa
-  double* hbp = hb2 + P * W;        // 2 x P x W : rows of H_{a, p1}, H_{a, p2} (the two directions drawn before a; k_sweep_lag)
-  double* dsc = hbp + 2 * P * W;    // 16     : delta(j, .)
+  double* hbp = hb2 + P * W;        // 2 x P x W : rows of H_{a, p1}, H_{a, p2} (the two directions drawn before a; k_sweep_lag only)
+  double* dsc = hbp + (c.use_lag ? 2 * P * W : 0);    // 16     : delta(j, .)
   const bool upd_nu = (mt == 0) && (c.mask & U_NU);
   const bool upd_phi = (mt > 0) && (c.mask & U_PHI);
   const bool upd = upd_nu || upd_phi;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
     if (rank >= 2) p2 = step_dir(d, rank - 2, n_phi_s);
   }
   // ---- everything this workgroup needs from global memory is requested up front, in one batch ----
-  constexpr int MAXI = 4;           // (b, p) items per thread and pass
+  constexpr int MAXI = (BW > 5) ? 1 : 4;          // (b, p) items per thread and pass (wide band: a row is 64 doubles)
   v2d hreg[MAXI][BW + 1];
   double tval[MAXI];
   {
@@ -440,9 +440,10 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   }
   const double tv0 = c.tvec[a * P + min(tid >> 3, P - 1)];      // t_a[p] of the r-reduction's first pass
   // prior entries of the band of Prec this thread will build: element (p, p + t), t <= BWP (two per thread at most)
-  double pri[2];
+  constexpr int NPRI = (BW > 5) ? ((BWWIDE + 1) * PP + 255) / 256 : 2;
+  double pri[NPRI];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NPRI; ++u) {
     const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
     const bool in = t <= d.BWP && q < P;
     const int pc = min(p, P - 1), qc = min(q, P - 1);
@@ -532,14 +533,19 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
   // only the band of Prec is read by the factorisation (factor_core): (BWP + 1) x P entries
   for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
+  if (BW > 5) {                     // the dense factorisation reads all of S
+    for (int e = tid; e < PP * PP; e += 256) S[e] = (e % PP == e / PP) ? 1.0 : 0.0;
+    __syncthreads();
+  }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NPRI; ++u) {
     const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
     if (t <= d.BWP && q < P) {
       double v = (t <= BW) ? f * hb2[p * W + BW + t] : 0.0;
       if (mt == 0) v += d.mv ? ((t == 0) ? 1.0 / tau_j : 0.0) : tau_j * pri[u];    // UpdateNu.h:197 (MV) / :66
       else v += tt * pri[u];                                                       // UpdatePhi.h:76-78 (diagonal)
       S[p + PP * q] = v;
+      if (BW > 5) S[q + PP * p] = v;
     }
   }
   FST(5);
@@ -616,8 +622,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
   double* hq = r + AP;                       // A x P   H_aa theta_a
   double* lz = hq + AP;                      // A x P   L_a z_a
   double* rhs = lz + AP;                     // PMAX
-  double* dlp = rhs + PMAX;                  // PMAX + 2*BWMAX (zero pads)
-  double* red = dlp + PMAX + 2 * BWMAX;      // 32
+  double* dlp = rhs + PMAX;                  // PMAX + 2*BWWIDE (zero pads)
+  double* red = dlp + PMAX + 2 * BWWIDE;     // 32
   // direct != 0: the column blocks and C_a do not fit the LDS double buffer (A*LG + P*P > 6144 doubles or the total
   // beyond 160 KB): no staging, every step reads them from L2 (slower per step, but no size limit)
   // diagonal model (multivariate: G_i = I and priors I/tau, diag(tilde_tau gamma)): every H block and every C_a is
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
     th[e] = (pp >= 0 && pp < P) ? c.theta[(size_t)full_dir(d, b) * P + pp] : 0.0;
   }
   for (int e = tid; e < AP; e += SW_THREADS) { tv[e] = c.tvec[e]; r[e] = c.rvec[e]; hq[e] = c.hq[e]; lz[e] = c.Lz[e]; }
-  for (int e = tid; e < PMAX + 2 * BWMAX; e += SW_THREADS) dlp[e] = 0.0;
+  for (int e = tid; e < PMAX + 2 * BWWIDE; e += SW_THREADS) dlp[e] = 0.0;
   for (int e = tid; e < A * A; e += SW_THREADS) htab[e] = hrow(d, e / A, e % A);
   __syncthreads();
   // per-thread prefetch map: element e of [ H column blocks | C ] of a step
@@ -1607,14 +1613,15 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
     case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(grid), dim3(256), lds, st, c); break;
     case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(grid), dim3(256), lds, st, c); break;
     case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(grid), dim3(256), lds, st, c); break;
-    default: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid), dim3(256), lds, st, c); break;
+    case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid), dim3(256), lds, st, c); break;
+    default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(grid), dim3(256), lds, st, c); break;
   }
 }
 
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
-  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + 3 * (size_t)c.d.P * W + 16) * sizeof(double);
+  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (c.use_lag ? 3 : 1) * (size_t)c.d.P * W + 16) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
@@ -1660,7 +1667,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   const bool diag = (d.BW == 0 && d.BWP == 0);
   size_t pf_len = (size_t)d.A * d.LG + (diag ? (size_t)d.P : (size_t)d.P * d.P);
   auto lds_for = [&](size_t pf) {
-    const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWMAX + 32 + 2 * pf;
+    const size_t doubles = (size_t)d.A * (d.P + 2 * d.BW) + 4 * (size_t)d.A * d.P + PMAX + PMAX + 2 * BWWIDE + 32 + 2 * pf;
     return doubles * sizeof(double) + (size_t)d.A * d.A * sizeof(int) + 16;
   };
   int direct = 0;
@@ -1688,6 +1695,7 @@ void prepare_sweep_kernels() {
   set_max_lds((const void*)k_factor<32, 3>); set_max_lds((const void*)k_factor<64, 3>);
   set_max_lds((const void*)k_factor<32, 4>); set_max_lds((const void*)k_factor<64, 4>);
   set_max_lds((const void*)k_factor<32, 5>); set_max_lds((const void*)k_factor<64, 5>);
+  set_max_lds((const void*)k_factor<32, BWWIDE>); set_max_lds((const void*)k_factor<64, BWWIDE>);
 }
 
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {

@@ -17,6 +17,7 @@ namespace bfmmm {
 constexpr int KMAX = 6;     // clusters supported by the unrolled per-curve code
 constexpr int PMAX = 64;    // basis functions: one lane per basis function inside a curve group
 constexpr int BWMAX = 5;    // spline degree (band half-width) instantiated
+constexpr int BWWIDE = 31;  // the one wide-band instantiation (user-supplied / tensor-product bases, bfmmm_create_from_basis)
 
 // update mask bits, in the (fixed) order in which every reference driver applies them
 // (BFMMM.h:1073-1107, 1253-1292, 1502-1553, 3741-3780, 3944-4010, 4809-4894)

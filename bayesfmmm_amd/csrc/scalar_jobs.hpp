@@ -365,7 +365,9 @@ __device__ inline void job_hyper(const Ctx& c) {
       const int k = e / P, p = e - k * P;
       double s = 0.0;
       if (d.mv) s = snu[e];
-      else {
+      else if (d.BWP > BWMAX) {       // wide penalty band (tensor-product bases): the plain row product of UpdateTau.h:26-28
+        for (int q = 0; q < P; ++q) s += c.Pmat[p + (size_t)P * q] * snu[k * P + q];
+      } else {
         // the penalty is banded (half-width BWP, the same assumption the factorisation makes): the other products of
         // row p are exact zeros, so skipping them leaves the sum of UpdateTau.h:26-28 unchanged
         double pv[2 * BWMAX + 1];

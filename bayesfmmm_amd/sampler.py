@@ -38,13 +38,28 @@ def default_config(**kw):
 
 
 class Sampler:
-    def __init__(self, cfg, Y, time=None, internal_knots=None, boundary_knots=None, device=0):
+    def __init__(self, cfg, Y, time=None, internal_knots=None, boundary_knots=None, device=0, basis=None, band=None,
+                 penalty=None, penalty_band=None):
         """Functional model: Y, time are lists of 1-D arrays (one per curve).
-        Multivariate model: Y is an (n, P) matrix."""
+        Multivariate model: Y is an (n, P) matrix.
+        Functional model over a caller-supplied basis (bfmmm_create_from_basis; the high-dimensional model's tensor-product
+        basis): `basis` is a list of n_i x P matrices, `band` the half-bandwidth of B'B, `penalty` the P x P penalty of the
+        nu prior and `penalty_band` its half-bandwidth."""
         self.lib = _lib.load()
         self.cfg = cfg
         self.h = C.c_void_p()
-        if cfg.model == MODEL_FUNCTIONAL:
+        if basis is not None:
+            self.offsets = np.zeros(len(Y) + 1, dtype=np.int64)
+            self.offsets[1:] = np.cumsum([len(y) for y in Y])
+            y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))
+            B = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.float64) for b in basis], axis=0))
+            Pm = np.asfortranarray(penalty, dtype=np.float64)
+            cfg.n_funct = len(Y)
+            self.P = B.shape[1]
+            _lib.check(self.lib.bfmmm_create_from_basis(C.byref(cfg), device, _dp(y), _dp(B),
+                                                        self.offsets.ctypes.data_as(_lib.c_int64_p), self.P, int(band), _dp(Pm),
+                                                        int(penalty_band), C.byref(self.h)))
+        elif cfg.model == MODEL_FUNCTIONAL:
             self.offsets = np.zeros(len(Y) + 1, dtype=np.int64)
             self.offsets[1:] = np.cumsum([len(y) for y in Y])
             y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))

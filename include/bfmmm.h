@@ -83,6 +83,15 @@ void bfmmm_config_defaults(bfmmm_config* cfg);
  * the device (replacing BFMMM.h:1017-1025).  The caller's arrays are not retained. */
 int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
                  const double* internal_knots, const double* boundary_knots, bfmmm_handle** out);
+
+/* The functional model over a basis supplied by the caller instead of univariate B-splines: B holds one row of P basis
+ * values per observation (row-major, curve i's rows at offsets[i] .. offsets[i+1]), `band` is the half-bandwidth of
+ * B_i'B_i (|p - q| > band => zero), Pmat (P x P, column-major) the penalty of the nu prior and pen_band its
+ * half-bandwidth.  This is how the high-dimensional functional model enters (BHDFMMM_*: tensor-product basis and
+ * penalty of inst/include/BayesFMMM/BSplines.h:18-120, bfmmm_tensor_bspline / bfmmm_tensor_penalty in bfmmm_entry.h);
+ * the drivers of that model (BFMMM.h:2892, :3041, :3210) run the same updates.  band <= 31, P <= 64. */
+int bfmmm_create_from_basis(const bfmmm_config* cfg, int device, const double* y, const double* B, const int64_t* offsets,
+                            int P, int band, const double* Pmat, int pen_band, bfmmm_handle** out);
 void bfmmm_destroy(bfmmm_handle* h);
 
 /* Covariate adjustment (the `X` argument of the reference's entry points, UserFunctions.cpp:176): X is the

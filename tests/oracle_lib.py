@@ -159,7 +159,7 @@ def make_hyper(K, c=None, **kw):
 class Model:
     """Owns the numpy buffers behind an orc_data."""
 
-    def __init__(self, y_list, B_list, K, M, X=None, mv=False):
+    def __init__(self, y_list, B_list, K, M, X=None, mv=False, Pmat=None):
         self.n = len(y_list)
         self.K, self.M = K, M
         self.P = B_list[0].shape[1]
@@ -169,7 +169,7 @@ class Model:
         self.B = np.ascontiguousarray(np.concatenate(B_list, axis=0), dtype=np.float64)
         self.X = None if X is None else np.asfortranarray(X, dtype=np.float64)
         self.D = 0 if X is None else self.X.shape[1]
-        self.Pmat = np.asfortranarray(pmat_rw1(self.P))
+        self.Pmat = np.asfortranarray(pmat_rw1(self.P) if Pmat is None else np.asarray(Pmat, dtype=np.float64))
         self.mv = mv
         self.data = OrcData(self.n, K, self.P, M, self.D, self.off.ctypes.data_as(C.POINTER(C.c_int64)),
                             dp(self.y), dp(self.B), dp(self.X) if self.X is not None else None,
