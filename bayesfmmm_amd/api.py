@@ -34,7 +34,8 @@ class EntryArgs(C.Structure):
                 ("N_t", C.c_int32), ("n_temp_trans", C.c_int32), ("r_stored_iters", C.c_int32),
                 ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
                 ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32),
-                ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32), ("dir", C.c_char_p)]
+                ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32), ("dir", C.c_char_p),
+                ("dim", C.c_int32), ("basis_degree_hd", C.POINTER(C.c_int32)), ("n_internal_hd", C.POINTER(C.c_int32))]
 
 
 ENTRY_SYMBOLS = {
@@ -52,6 +53,9 @@ ENTRY_SYMBOLS = {
     "bfmmm_BMVMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_BMVMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
     "bfmmm_BMVMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_BHDFMMM_Nu_Z_multiple_try": (C.c_int, [C.POINTER(EntryArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_BHDFMMM_Theta_est": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bfmmm_BHDFMMM_warm_start": (C.c_int, [C.POINTER(EntryArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bfmmm_arma_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfmmm_arma_read_field": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfmmm_arma_write_ascii": (C.c_int, [C.c_char_p, c_double_p, c_int64_p, C.c_int]),
@@ -393,3 +397,78 @@ def GetP(basis_degree, n_internal_knots):
     out = np.zeros((P, P), order="F")
     _check(_lib_entry().bfmmm_tensor_penalty(dim, deg, nint, out.ctypes.data_as(c_double_p)))
     return out
+
+
+# ---- high-dimensional functional model (src/UserFunctions.cpp:2519, :3030, :3676) --------------------------------
+class _ArgsHD:
+    """bfmmm_entry_args of the BHDFMMM_* entry points: `time` is a list of n_i x dim matrices, `basis_degree` a vector,
+    `boundary_knots` a dim x 2 matrix, `internal_knots` a list of vectors."""
+
+    def __init__(self, entry, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw):
+        if len(Y) != n_funct or len(time) != n_funct:
+            raise ValueError("'Y' and 'time' must have 'n_funct' elements")
+        lib = _lib_entry()
+        self.a = EntryArgs()
+        lib.bfmmm_entry_defaults(C.byref(self.a), entry)
+        dim = len(basis_degree)
+        tm = [np.asfortranarray(np.asarray(t, dtype=np.float64).reshape(len(y), -1)) for t, y in zip(time, Y)]
+        if tm[0].shape[1] != dim:
+            raise _lib.BfmmmError("number of elemnts in 'basis_degree' does not match number of columns in time matrix")
+        self.offsets = np.zeros(n_funct + 1, dtype=np.int64)
+        self.offsets[1:] = np.cumsum([len(v) for v in Y])
+        self.y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))
+        self.t = np.ascontiguousarray(np.concatenate([t.reshape(-1, order="F") for t in tm]))
+        self.bk = np.ascontiguousarray(np.asarray(boundary_knots, dtype=np.float64).reshape(dim, 2))
+        self.ik = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=np.float64).reshape(-1) for k in internal_knots]))
+        self.deg = (C.c_int32 * dim)(*[int(x) for x in basis_degree])
+        self.nint = (C.c_int32 * dim)(*[len(k) for k in internal_knots])
+        a = self.a
+        a.n_funct, a.tot_mcmc_iters, a.K, a.n_eigen, a.dim = n_funct, tot_mcmc_iters, K, n_eigen, dim
+        a.basis_degree = max(int(x) for x in basis_degree)
+        a.y, a.t = self.y.ctypes.data_as(c_double_p), self.t.ctypes.data_as(c_double_p)
+        a.offsets = self.offsets.ctypes.data_as(c_int64_p)
+        a.boundary_knots, a.internal_knots = self.bk.ctypes.data_as(c_double_p), self.ik.ctypes.data_as(c_double_p)
+        a.basis_degree_hd, a.n_internal_hd = self.deg, self.nint
+        self.P = int(np.prod([len(k) + int(g) + 1 for k, g in zip(internal_knots, basis_degree)]))
+        c = kw.pop("c", None)
+        if c is not None:
+            self.c = np.ascontiguousarray(c, dtype=np.float64)
+            if self.c.size != K:
+                raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
+            a.c = self.c.ctypes.data_as(c_double_p)
+        for k, v in kw.items():
+            if not hasattr(a, k):
+                raise TypeError(f"unexpected argument '{k}'")
+            setattr(a, k, v)
+
+
+def BHDFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
+                              internal_knots, **kw):
+    """src/UserFunctions.cpp:2519."""
+    lib = _lib_entry()
+    args = _ArgsHD(0, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args.a.n_try = n_try
+    return _call1(lib.bfmmm_BHDFMMM_Nu_Z_multiple_try, args)
+
+
+def BHDFMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
+                      multiple_try, burnin_prop=0.8, **kw):
+    """src/UserFunctions.cpp:3030."""
+    lib = _lib_entry()
+    args = _ArgsHD(1, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
+    return _call1(lib.bfmmm_BHDFMMM_Theta_est, args, {k: multiple_try[k] for k in ("Z", "nu")})
+
+
+def BHDFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
+                       multiple_try, theta_est, burnin_prop=0.8, dir=None, **kw):
+    """src/UserFunctions.cpp:3676."""
+    lib = _lib_entry()
+    args = _ArgsHD(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args.a.burnin_prop = burnin_prop
+    if dir is not None:
+        args.dir = str(dir).encode()
+        args.a.dir = args.dir
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
+    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
+    return _call1(lib.bfmmm_BHDFMMM_warm_start, args, mt, te)

@@ -104,9 +104,26 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   }
   if (a->K < 2) return efail("'K' must be an integer greater than or equal to 2");
   if (a->n_funct < 1) return efail("'n_funct' must be an integer greater than or equal to 1");
-  if (!mv && a->basis_degree < 1) return efail("'basis_degree' must be an integer greater than or equal to 1");
+  const bool hd = a->dim > 0;
+  if (hd) {      // UserFunctions.cpp:2563-2588
+    if (mv) return efail("the high-dimensional model is a functional model");
+    if (!a->basis_degree_hd || !a->n_internal_hd) return efail("null argument");
+    if (a->X) return efail("covariate adjustment of the high-dimensional model is not supported by this build");
+    size_t ko = 0;
+    for (int j = 0; j < a->dim; ++j) {
+      if (a->basis_degree_hd[j] < 1) return efail("'basis_degree' elements must be an integer greater than or equal to 1");
+      for (int i = 0; i < a->n_internal_hd[j]; ++i) {
+        if (a->boundary_knots[2 * j] >= a->internal_knots[ko + i])
+          return efail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+        if (a->boundary_knots[2 * j + 1] <= a->internal_knots[ko + i])
+          return efail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+      }
+      ko += (size_t)a->n_internal_hd[j];
+    }
+  }
+  if (!mv && !hd && a->basis_degree < 1) return efail("'basis_degree' must be an integer greater than or equal to 1");
   if (a->n_eigen < 1) return efail("'n_eigen' must be an integer greater than or equal to 1");
-  for (int i = 0; !mv && i < a->n_internal_knots; ++i) {
+  for (int i = 0; !mv && !hd && i < a->n_internal_knots; ++i) {
     if (a->boundary_knots[0] >= a->internal_knots[i])
       return efail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
     if (a->boundary_knots[1] <= a->internal_knots[i])
@@ -137,6 +154,8 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   if (a->chain_stride < 1 || a->chain_offset < 0) return efail("invalid chain_offset / chain_stride");
   return 0;
 }
+
+static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, bfmmm_handle** h);
 
 static void make_cfg(const bfmmm_entry_args* a, int T, bfmmm_config* cfg) {
   bfmmm_config_defaults(cfg);
@@ -208,7 +227,7 @@ static int run_multi_try(const bfmmm_entry_args* a, const bfmmm_config& cfg, uin
       th.emplace_back([&, q]() {
         ChainRun& r = runs[q];
         auto lib_fail = [&]() { r.rc = 1; r.err = bfmmm_last_error(); };
-        if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &r.h)) return lib_fail();
+        if (make_handle(a, &cfg, &r.h)) return lib_fail();
         if (setup(r.h, r.chain, ctx)) return lib_fail();
         if (bfmmm_run(r.h, mask, 0, T, a->seed, (uint32_t)r.chain, phi_chi_zero, 1.0)) return lib_fail();
         std::vector<double> ll(T);
@@ -260,7 +279,42 @@ static int fetch_tau(bfmmm_handle* h, bfmmm_result* r, int T, int K, int extra_s
 }
 
 static int dimP(const bfmmm_entry_args* a) {
+  if (a->dim > 0) {
+    int P = 1;
+    for (int j = 0; j < a->dim; ++j) P *= a->n_internal_hd[j] + a->basis_degree_hd[j] + 1;
+    return P;
+  }
   return (a->model == BFMMM_MODEL_MULTIVARIATE) ? a->P : a->n_internal_knots + a->basis_degree + 1;
+}
+
+// sampler handle of an entry point: univariate B-splines / multivariate data (bfmmm_create) or, for the high-dimensional
+// model, the tensor-product basis and penalty of BSplines.h:18-120 built on the host (BFMMM.h:2923-2936 does the same
+// per call) and handed to bfmmm_create_from_basis
+static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, bfmmm_handle** h) {
+  if (a->dim <= 0) return bfmmm_create(cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, h);
+  const int dim = a->dim, P = dimP(a);
+  const int64_t n_obs = a->offsets[a->n_funct];
+  std::vector<double> B((size_t)n_obs * P), tmp;
+  for (int i = 0; i < a->n_funct; ++i) {
+    const int64_t o = a->offsets[i], ni = a->offsets[i + 1] - o;
+    tmp.assign((size_t)ni * P, 0.0);
+    if (bfmmm_tensor_bspline((int)ni, dim, a->t + (size_t)o * dim, a->basis_degree_hd, a->boundary_knots, a->n_internal_hd,
+                             a->internal_knots, tmp.data()))
+      return 1;
+    for (int64_t l = 0; l < ni; ++l)
+      for (int p = 0; p < P; ++p) B[(size_t)(o + l) * P + p] = tmp[(size_t)l + (size_t)ni * p];      // column-major -> rows
+  }
+  std::vector<double> Pm((size_t)P * P);
+  if (bfmmm_tensor_penalty(dim, a->basis_degree_hd, a->n_internal_hd, Pm.data())) return 1;
+  // band of B'B: basis functions whose multi-indices differ by more than the degree in some dimension never overlap
+  int band = 0, pen_band = 1, stride = 1;
+  for (int j = dim - 1; j >= 0; --j) {
+    band += a->basis_degree_hd[j] * stride;
+    pen_band = stride;
+    stride *= a->n_internal_hd[j] + a->basis_degree_hd[j] + 1;
+  }
+  return bfmmm_create_from_basis(cfg, a->device, a->y, B.data(), a->offsets, P, std::min(band, P - 1), Pm.data(),
+                                 std::min(pen_band, P - 1), h);
 }
 
 static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a, const char* name) {
@@ -574,7 +628,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   bfmmm_config cfg;
   make_cfg(a, batched ? rs : T, &cfg);          // chain slots in HBM
   bfmmm_handle* h = nullptr;
-  if (bfmmm_create(&cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, &h)) return efail_lib();
+  if (make_handle(a, &cfg, &h)) return efail_lib();
   const uint32_t mask_ws = BFMMM_SWEEP_WARM | (a->X ? (BFMMM_COV_MEAN | (a->covariance_adj ? BFMMM_COV_XI : 0)) : 0);   // BFMMM.h:4248-4312 / 4809-4894
   int rc = attach_cov(h, a) ||
            (a->X && (bfmmm_set_state(h, "eta", eta_est.data(), (int64_t)eta_est.size()) ||
@@ -683,4 +737,20 @@ extern "C" int bfmmm_BMVMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_res
 extern "C" int bfmmm_BMVMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* mt, const bfmmm_result* te,
                                        bfmmm_result** out) {
   return need_mv(a) || bfmmm_BFMMM_warm_start(a, mt, te, out);
+}
+
+// ---- high-dimensional functional model (BHDFMMM_*): the same drivers over the tensor-product basis ------------------
+static int need_hd(const bfmmm_entry_args* a) {
+  if (!a || a->dim <= 0) return efail("bfmmm_BHDFMMM_*: args.dim must be positive");
+  return 0;
+}
+extern "C" int bfmmm_BHDFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out) {
+  return need_hd(a) || bfmmm_BFMMM_Nu_Z_multiple_try(a, out);
+}
+extern "C" int bfmmm_BHDFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* mt, bfmmm_result** out) {
+  return need_hd(a) || bfmmm_BFMMM_Theta_est(a, mt, out);
+}
+extern "C" int bfmmm_BHDFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* mt, const bfmmm_result* te,
+                                        bfmmm_result** out) {
+  return need_hd(a) || bfmmm_BFMMM_warm_start(a, mt, te, out);
 }

@@ -83,6 +83,14 @@ typedef struct {
    * Delta_Xi, A_Xi, Tau_Eta with covariates -- exactly as BFMMM_MTT_warm_start does (BFMMM.h:1680-1746, :5086-5165);
    * the returned arrays then have r_stored_iters slots (the last batch in memory). */
   const char* dir;
+  /* high-dimensional functional model (BHDFMMM_*, src/UserFunctions.cpp:2519, :3030, :3676): dim > 0.  Then `t` holds,
+   * curve after curve, the n_i x dim matrix of time points (column-major, as R stores each element of the `time` list);
+   * basis_degree_hd / n_internal_hd have dim entries (the arma::vec `basis_degree` and the lengths of the
+   * `internal_knots` list); internal_knots holds the dimensions' knots one after the other; boundary_knots is dim x 2
+   * row-major (lower, upper per dimension); basis_degree / n_internal_knots are ignored.  No covariates in this build. */
+  int32_t dim;
+  const int32_t* basis_degree_hd;
+  const int32_t* n_internal_hd;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:
@@ -122,14 +130,21 @@ int bfmmm_arma_read_field(const char* file, bfmmm_result** out);
 int bfmmm_arma_write_ascii(const char* file, const double* data, const int64_t* dims, int n_dims);
 int bfmmm_arma_write_field(const char* file, const bfmmm_result* items, int64_t n_rows, int64_t n_cols);
 
-/* Set-up pieces of the high-dimensional functional model (BHDFMMM_*; the sampler for its wide-band statistics is not
- * built yet): the tensor-product B-spline basis of TensorBSpline (inst/include/BayesFMMM/BSplines.h:18-66) for n_pts
+/* Set-up pieces of the high-dimensional functional model (the BHDFMMM_* entry points build them per call): the tensor-product B-spline basis of TensorBSpline (inst/include/BayesFMMM/BSplines.h:18-66) for n_pts
  * points in `dim` dimensions -- t is n_pts x dim column-major, boundary_knots dim x 2 row-major, internal_knots the
  * dimensions' knots one after the other, out n_pts x P column-major with the last dimension's index running fastest --
  * and the penalty matrix of GetP (BSplines.h:74-120), P x P. */
 int bfmmm_tensor_bspline(int n_pts, int dim, const double* t, const int* degree, const double* boundary_knots,
                          const int* n_internal, const double* internal_knots, double* out);
 int bfmmm_tensor_penalty(int dim, const int* degree, const int* n_internal, double* out);
+
+/* High-dimensional functional model: BHDFMMM_Nu_Z_multiple_try (src/UserFunctions.cpp:2519), BHDFMMM_Theta_est (:3030),
+ * BHDFMMM_warm_start (:3676); args.dim > 0.  Same results as the functional entry points ("B" / "B_obs": the rows of the
+ * tensor-product basis). */
+int bfmmm_BHDFMMM_Nu_Z_multiple_try(const bfmmm_entry_args* a, bfmmm_result** out);
+int bfmmm_BHDFMMM_Theta_est(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, bfmmm_result** out);
+int bfmmm_BHDFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_result* multiple_try, const bfmmm_result* theta_est,
+                             bfmmm_result** out);
 
 /* message of the last failing bfmmm_result_* / bfmmm_BFMMM_* call on this thread */
 const char* bfmmm_entry_last_error(void);

@@ -8,6 +8,7 @@
 //   _BayesFMMM_BFMMM_Theta_est         (32,      :396)                  -> bfmmm_BFMMM_Theta_est
 //   _BayesFMMM_BFMMM_warm_start        (38,      :438)                  -> bfmmm_BFMMM_warm_start
 //   _BayesFMMM_BMVMMM_Nu_Z_multiple_try (23, :680), _BMVMMM_Theta_est (27, :713), _BMVMMM_warm_start (33, :750)
+//   _BayesFMMM_BHDFMMM_Nu_Z_multiple_try (28, :552), _BHDFMMM_Theta_est (32, :590), _BHDFMMM_warm_start (38, :632)
 //   _BayesFMMM_ReadVec / ReadMat / ReadCube / ReadFieldCube / ReadFieldMat / ReadFieldVec (1 arg each, :486-541)
 //
 // It is pure marshalling (no arithmetic): R lists of numeric vectors become CSR arrays, Rcpp::List arguments become
@@ -182,6 +183,27 @@ void set_functional(bfmmm_entry_args& a, const Ragged& Y, const Ragged& tm, SEXP
   a.boundary_knots = REAL(boundary_knots); a.internal_knots = REAL(internal_knots);
 }
 
+// high-dimensional model: `time` is a list of n_i x dim matrices (flattened as they are: column-major per curve),
+// `basis_degree` an arma::vec, `boundary_knots` a dim x 2 matrix (column-major in R -> row-major for the ABI),
+// `internal_knots` a list of vectors (UserFunctions.cpp:2519-2545)
+struct HDArgs { std::vector<int32_t> deg, nint; std::vector<double> bk; Ragged ik; };
+
+void set_hd(bfmmm_entry_args& a, HDArgs& h, const Ragged& Y, const Ragged& tm, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
+            SEXP boundary_knots, SEXP internal_knots) {
+  const int dim = Rf_length(basis_degree);
+  a.n_funct = Rf_asInteger(n_funct); a.n_eigen = Rf_asInteger(n_eigen); a.dim = dim;
+  a.y = Y.v.data(); a.t = tm.v.data(); a.offsets = Y.off.data();
+  h.ik = flatten(internal_knots);
+  for (int j = 0; j < dim; ++j) {
+    h.deg.push_back((int32_t)REAL(basis_degree)[j]);
+    h.nint.push_back((int32_t)(h.ik.off[j + 1] - h.ik.off[j]));
+    h.bk.push_back(REAL(boundary_knots)[j]);
+    h.bk.push_back(REAL(boundary_knots)[j + dim]);
+  }
+  a.basis_degree_hd = h.deg.data(); a.n_internal_hd = h.nint.data();
+  a.boundary_knots = h.bk.data(); a.internal_knots = h.ik.v.data();
+}
+
 void set_multivariate(bfmmm_entry_args& a, SEXP Y, SEXP n_eigen) {
   a.model = 1;                                           // BFMMM_MODEL_MULTIVARIATE
   a.y = REAL(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
@@ -349,6 +371,61 @@ SEXP _BayesFMMM_BMVMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP n_ei
   return finish(bfmmm_BMVMMM_warm_start(&a, mt, te, &r), r, NULL, mt, te);
 }
 
+// ---- high-dimensional functional model (RcppExports.cpp:552, :590, :632) -----------------------------------------
+SEXP _BayesFMMM_BHDFMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
+                                          SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP X, H18) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  HDArgs h;
+  bfmmm_entry_defaults(&a, 0);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, R_NilValue);
+  set_hyper(a, HY18);
+  a.seed = seed_from_R();
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BHDFMMM_Nu_Z_multiple_try(&a, &r), r, &y.off);
+}
+
+SEXP _BayesFMMM_BHDFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
+                                  SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP X,
+                                  SEXP burnin_prop, H19, SEXP covariance_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  HDArgs h;
+  bfmmm_entry_defaults(&a, 1);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, covariance_adj);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BHDFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
+}
+
+SEXP _BayesFMMM_BHDFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
+                                   SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP theta_est, SEXP X,
+                                   SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
+                                   SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_entry_args a;
+  HDArgs h;
+  bfmmm_entry_defaults(&a, 2);
+  a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
+  set_X(a, X, covariance_adj);
+  set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
+  set_hyper(a, HY19);
+  a.seed = seed_from_R();
+  bfmmm_result* mt = list_to_result(multiple_try);
+  bfmmm_result* te = list_to_result(theta_est);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_BHDFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
+}
+
 // ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
 SEXP _BayesFMMM_ReadVec(SEXP file) { return read_plain(file, true); }
 SEXP _BayesFMMM_ReadMat(SEXP file) { return read_plain(file, false); }
@@ -364,6 +441,9 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_BMVMMM_Nu_Z_multiple_try", (DL_FUNC)&_BayesFMMM_BMVMMM_Nu_Z_multiple_try, 23},
     {"_BayesFMMM_BMVMMM_Theta_est", (DL_FUNC)&_BayesFMMM_BMVMMM_Theta_est, 27},
     {"_BayesFMMM_BMVMMM_warm_start", (DL_FUNC)&_BayesFMMM_BMVMMM_warm_start, 33},
+    {"_BayesFMMM_BHDFMMM_Nu_Z_multiple_try", (DL_FUNC)&_BayesFMMM_BHDFMMM_Nu_Z_multiple_try, 28},
+    {"_BayesFMMM_BHDFMMM_Theta_est", (DL_FUNC)&_BayesFMMM_BHDFMMM_Theta_est, 32},
+    {"_BayesFMMM_BHDFMMM_warm_start", (DL_FUNC)&_BayesFMMM_BHDFMMM_warm_start, 38},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
