@@ -404,7 +404,7 @@ class _ArgsHD:
     """bfmmm_entry_args of the BHDFMMM_* entry points: `time` is a list of n_i x dim matrices, `basis_degree` a vector,
     `boundary_knots` a dim x 2 matrix, `internal_knots` a list of vectors."""
 
-    def __init__(self, entry, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw):
+    def __init__(self, entry, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw):
         if len(Y) != n_funct or len(time) != n_funct:
             raise ValueError("'Y' and 'time' must have 'n_funct' elements")
         lib = _lib_entry()
@@ -430,6 +430,14 @@ class _ArgsHD:
         a.boundary_knots, a.internal_knots = self.bk.ctypes.data_as(c_double_p), self.ik.ctypes.data_as(c_double_p)
         a.basis_degree_hd, a.n_internal_hd = self.deg, self.nint
         self.P = int(np.prod([len(k) + int(g) + 1 for k, g in zip(internal_knots, basis_degree)]))
+        if X is not None:        # UserFunctions.cpp:2531 / :3043 / :3689 (`X`, `covariance_adj`)
+            self.X = np.asfortranarray(X, dtype=np.float64)
+            if self.X.shape[0] != n_funct:
+                raise _lib.BfmmmError("'X' must be have 'n_funct' number of rows")
+            a.X, a.D = self.X.ctypes.data_as(c_double_p), self.X.shape[1]
+            a.covariance_adj = int(bool(kw.pop("covariance_adj", False)))
+        else:
+            kw.pop("covariance_adj", None)
         c = kw.pop("c", None)
         if c is not None:
             self.c = np.ascontiguousarray(c, dtype=np.float64)
@@ -443,32 +451,35 @@ class _ArgsHD:
 
 
 def BHDFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
-                              internal_knots, **kw):
+                              internal_knots, X=None, **kw):
     """src/UserFunctions.cpp:2519."""
     lib = _lib_entry()
-    args = _ArgsHD(0, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args = _ArgsHD(0, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.n_try = n_try
     return _call1(lib.bfmmm_BHDFMMM_Nu_Z_multiple_try, args)
 
 
 def BHDFMMM_Theta_est(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
-                      multiple_try, burnin_prop=0.8, **kw):
+                      multiple_try, X=None, burnin_prop=0.8, **kw):
     """src/UserFunctions.cpp:3030."""
     lib = _lib_entry()
-    args = _ArgsHD(1, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args = _ArgsHD(1, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.n_try, args.a.burnin_prop = n_try, burnin_prop
-    return _call1(lib.bfmmm_BHDFMMM_Theta_est, args, {k: multiple_try[k] for k in ("Z", "nu")})
+    mt = {k: multiple_try[k] for k in ("Z", "nu") + (("eta",) if X is not None else ())}
+    return _call1(lib.bfmmm_BHDFMMM_Theta_est, args, mt)
 
 
 def BHDFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots,
-                       multiple_try, theta_est, burnin_prop=0.8, dir=None, **kw):
+                       multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
     """src/UserFunctions.cpp:3676."""
     lib = _lib_entry()
-    args = _ArgsHD(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, kw)
+    args = _ArgsHD(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
     args.a.burnin_prop = burnin_prop
     if dir is not None:
         args.dir = str(dir).encode()
         args.a.dir = args.dir
-    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau")}
-    te = {k: theta_est[k] for k in ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")}
-    return _call1(lib.bfmmm_BHDFMMM_warm_start, args, mt, te)
+    mt = {k: multiple_try[k] for k in ("Z", "nu", "pi", "alpha_3", "tau") + (("eta", "tau_eta") if X is not None else ())}
+    te_names = ("delta", "gamma", "Phi", "A", "sigma_sq", "chi")
+    if X is not None and args.a.covariance_adj:
+        te_names += ("xi", "gamma_xi", "delta_xi", "A_xi")
+    return _call1(lib.bfmmm_BHDFMMM_warm_start, args, mt, {k: theta_est[k] for k in te_names})

@@ -35,6 +35,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st);
 int cov_step_blocks(int nblk_curve);
 int cov_w2_chunks(int n);
 void prepare_cov_kernels();
+bool cov_block_fits(const Ctx& c);
 #ifdef BFMMM_TIMELINE
 void fetch_wgtrace(unsigned long long* out);
 void fetch_ztrace(unsigned long long* out);
@@ -367,7 +368,6 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   if (!h || !X) return fail("bfmmm_set_covariates: null argument");
   if (D < 1 || D > 8) return fail("bfmmm_set_covariates: the number of covariates must be between 1 and 8 in this build");
   if (h->c.d.D != 0) return fail("bfmmm_set_covariates: covariates are already set");
-  if (h->c.d.BW > BWMAX) return fail("bfmmm_set_covariates: covariate adjustment with a wide-band basis is not supported in this build");
   HIPCHK(hipSetDevice(h->device));
   Ctx& c = h->c;
   Dims& d = c.d;
@@ -379,6 +379,10 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   c.NBS = cov_step_blocks(c.nblk_curve);
   c.NPG = D * (D + 1) / 2;
   c.NPAIR = (c.A2 / D) * c.NPG;
+  if (!cov_block_fits(c)) {
+    d.D = 0;
+    return fail("bfmmm_set_covariates: this many covariates with this basis exceed the covariate kernels' on-chip staging (fewer covariates or a narrower band)");
+  }
   double* Xd;
   if (dalloc(h, &Xd, n * D)) return 1;
   HIPCHK(copy_sync(h, Xd, X, sizeof(double) * n * D, hipMemcpyHostToDevice));

@@ -108,7 +108,6 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   if (hd) {      // UserFunctions.cpp:2563-2588
     if (mv) return efail("the high-dimensional model is a functional model");
     if (!a->basis_degree_hd || !a->n_internal_hd) return efail("null argument");
-    if (a->X) return efail("covariate adjustment of the high-dimensional model is not supported by this build");
     size_t ko = 0;
     for (int j = 0; j < a->dim; ++j) {
       if (a->basis_degree_hd[j] < 1) return efail("'basis_degree' elements must be an integer greater than or equal to 1");

@@ -268,7 +268,6 @@ __device__ inline double rsum_dpp(double v) {
 constexpr int COV_CPG = 2;     // curves per lane group of k_cov_group
 constexpr int COV_CPB32 = 32;  // curves per workgroup of k_cov_group (P <= 32: 32 lane groups of 32; P > 32: 16 groups of 64)
 constexpr int DMAX = DMAX_COV;
-constexpr int PADW = PMAX + 2 * BWMAX + 2;
 constexpr int GT = 1024;       // threads of k_cov_group
 
 // 1024 threads = four waves per SIMD: every phase of this kernel is bound by instruction issue and latency, not by
@@ -283,6 +282,7 @@ __global__ __launch_bounds__(GT) void k_cov_group(Ctx c, int g_prev, int g_next,
   constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR, tid < 256)
   constexpr int QPL = LPC / LR;           // columns per lane
   constexpr int NSEG = GT / 32;           // segments of the partial-sum reduction
+  constexpr int PADW = PMAX + 2 * BW + 2;  // a coefficient row with BW zeros either side
   extern __shared__ __attribute__((aligned(16))) double sHp[];     // NPG x LG pair blocks of g_prev
   __shared__ double sDl[DMAX][PADW];
   __shared__ double sTh[DMAX][PADW];
@@ -753,7 +753,8 @@ static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hip
     case 2: launch_group_bw<2>(c, g_prev, g_next, par_prev, st); break;
     case 3: launch_group_bw<3>(c, g_prev, g_next, par_prev, st); break;
     case 4: launch_group_bw<4>(c, g_prev, g_next, par_prev, st); break;
-    default: launch_group_bw<5>(c, g_prev, g_next, par_prev, st); break;
+    case 5: launch_group_bw<5>(c, g_prev, g_next, par_prev, st); break;
+    default: launch_group_bw<BWWIDE>(c, g_prev, g_next, par_prev, st); break;
   }
 }
 
@@ -806,7 +807,34 @@ void prepare_cov_kernels() {
   set_max_lds((const void*)k_cov_factor<32>);
   set_max_lds((const void*)k_cov_factor<64>);
   prepare_group_bw<0>(); prepare_group_bw<1>(); prepare_group_bw<2>();
-  prepare_group_bw<3>(); prepare_group_bw<4>(); prepare_group_bw<5>();
+  prepare_group_bw<3>(); prepare_group_bw<4>(); prepare_group_bw<5>(); prepare_group_bw<BWWIDE>();
+}
+
+// does the covariate block of this model fit the kernels' LDS and staging assumptions? (host check at set-up)
+template <int BW>
+static bool group_fits_bw(const Ctx& c) {
+  const Dims& d = c.d;
+  hipFuncAttributes at;
+  const void* fn = (d.P <= 32) ? (const void*)k_cov_group<BW, 32> : (const void*)k_cov_group<BW, 64>;
+  if (hipFuncGetAttributes(&at, fn) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const size_t dyn = ((size_t)c.NPG * d.LG + 2 + (d.P <= 32 ? (size_t)d.D * d.P * d.P + 2 : 0)) * sizeof(double);
+  return at.sharedSizeBytes + dyn <= 160 * 1024 && d.D * (PMAX + 2 * BW + 2) <= GT;
+}
+
+bool cov_block_fits(const Ctx& c) {
+  const Dims& d = c.d;
+  const int PP = (d.P <= 32) ? 32 : 64;
+  if ((2 * (size_t)PP * PP + PP + d.LG) * sizeof(double) > 160 * 1024) return false;                 // k_cov_factor
+  if (((size_t)W2_CH * d.D + (size_t)c.NPG * 128) * sizeof(double) > 160 * 1024) return false;       // k_cov_w2
+  switch (d.BW) {
+    case 0: return group_fits_bw<0>(c);
+    case 1: return group_fits_bw<1>(c);
+    case 2: return group_fits_bw<2>(c);
+    case 3: return group_fits_bw<3>(c);
+    case 4: return group_fits_bw<4>(c);
+    case 5: return group_fits_bw<5>(c);
+    default: return group_fits_bw<BWWIDE>(c);
+  }
 }
 
 }  // namespace bfmmm

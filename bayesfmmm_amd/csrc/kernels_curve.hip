@@ -67,8 +67,8 @@ struct Tile {
   double* base;
   __device__ inline double* row(int r) const { return base + r * STR + BW; }
   __device__ inline void zero_pads(int rows, int lp) const {
-    if (lp < 2 * BW)
-      for (int r = 0; r < rows; ++r) base[r * STR + ((lp < BW) ? lp : (LPC + lp))] = 0.0;
+    for (int q = lp; q < 2 * BW; q += LPC)      // (a wide band has more pad entries than a 32-lane group has lanes)
+      for (int r = 0; r < rows; ++r) base[r * STR + ((q < BW) ? q : (LPC + q))] = 0.0;
   }
 };
 

@@ -85,3 +85,31 @@ def test_hd_argument_checks(example):
         api.BHDFMMM_Nu_Z_multiple_try(50, 1, 2, *base, [2, 2], 2, e["boundary_knots"], e["internal_knots"])
     with pytest.raises(_lib.BfmmmError, match="boundary knot"):
         api.BHDFMMM_Nu_Z_multiple_try(150, 1, 2, *base, [2, 2], 2, e["boundary_knots"], [[250.0, 1500.0], [250.0]])
+
+
+@pytest.mark.parametrize("covariance_adj", [False, True])
+def test_hd_three_stage_pipeline_covariate_adjusted(example, covariance_adj):
+    """Second half of the documented examples (R/RcppExports.R:2352-2375): X = matrix(rnorm(20), 20, 1); drivers
+    BFMMM.h:6750, :6913, :7137 (mean adjusted) and :7655 (mean and covariance adjusted)."""
+    from bayesfmmm_amd import api
+    e = example
+    T, n, K, P, M, D = 150, 20, 2, 36, 2, 1
+    X = np.random.default_rng(2).standard_normal((n, D))
+    common = (e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    est1 = api.BHDFMMM_Nu_Z_multiple_try(T, 1, K, *common, X=X, seed=3)
+    assert est1["eta"].shape == (P, D, K, T) and est1["tau_eta"].shape == (K, D, T)
+    assert np.abs(est1["eta"][..., -1]).max() > 0
+    est2 = api.BHDFMMM_Theta_est(T, 1, K, *common, est1, X=X, covariance_adj=covariance_adj, seed=4)
+    assert est2["xi"].shape == (P, D, M, K, T)
+    assert (np.abs(est2["xi"]).max() > 0) == covariance_adj
+    burn = int(round(T * 0.8))
+    np.testing.assert_allclose(est2["eta"][..., 0], np.median(est1["eta"][..., burn:], axis=3), rtol=1e-13)
+    mcmc = api.BHDFMMM_warm_start(T, K, *common, est1, est2, X=X, covariance_adj=covariance_adj, seed=5)
+    assert mcmc["eta"].shape == (P, D, K, T + 1) and np.isfinite(mcmc["loglik"][:T]).all()
+    assert ("xi" in mcmc) == covariance_adj
+    ysd = np.concatenate(e["Y"]).var()
+    assert np.median(mcmc["sigma_sq"][T // 2:T]) < 0.3 * ysd
+    tt = api.BHDFMMM_warm_start(T, K, *common, est1, est2, X=X, covariance_adj=covariance_adj, seed=5,
+                                n_temp_trans=40, N_t=2, beta_N_t=0.8)
+    assert tt["tt_blocks"] == 3 and np.isfinite(tt["loglik"][:T]).all()
+    np.testing.assert_array_equal(tt["eta"][..., :40], mcmc["eta"][..., :40])

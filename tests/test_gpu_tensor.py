@@ -70,3 +70,53 @@ def test_tensor_model_warm_trajectory_matches_oracle(K, M, degs, n_int, n):
     for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha_3", "delta", "A", "gamma", "tau", "sigma_sq", "loglik"]:
         err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
         assert err < 1e-6, (nm, err)
+
+
+@pytest.mark.parametrize("K,M,degs,n_int,n,D,cov_adj", [
+    (2, 2, [2, 2], [2, 2], 31, 2, True),         # 25 basis functions, band 12, two covariates, mean + covariance adjusted
+    (2, 2, [2, 2], [3, 3], 37, 1, False),        # 36 (the package's HD example basis), band 14: 64-lane groups, mean adjusted
+    (2, 1, [3, 3], [3, 3], 33, 2, True),         # 49, band 24
+])
+def test_tensor_model_with_covariates_matches_oracle(K, M, degs, n_int, n, D, cov_adj):
+    """Covariate-adjusted high-dimensional drivers (BFMMM.h:6750, :6913, :7137 mean-adjusted; :7655 mean + covariance
+    adjusted): the eta / Xi block over wide-band statistics (k_cov_group<31, .>, dense factorisation of the penalised
+    pair blocks)."""
+    import bayesfmmm_amd as bf
+    from gpu_parity import STATE_NAMES, oracle_slot
+    S = bf.sampler
+    T = 3
+    sim = simulate_tensor(n, K, M, degs, n_int, seed=500 + D + len(n_int) + n_int[0])
+    P = sim["P"]
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((n, D))
+    model = O.Model(sim["y"], sim["B"], K, M, X=X, Pmat=sim["Pmat"])
+    ch = O.Chain(model, T)
+    ch.nu[:, :, 0] = sim["nu"] + 0.2 * rng.standard_normal((K, P))
+    ch.Phi[..., 0] = sim["Phi"] + 0.1 * rng.standard_normal((K, P, M))
+    ch.chi[:, :, 0] = sim["chi"] + 0.2 * rng.standard_normal((n, M))
+    ch.Z[:, :, 0] = rng.dirichlet(np.full(K, 2.0), size=n)
+    ch.pi[:, 0] = rng.dirichlet(np.full(K, 5.0))
+    ch.alpha3[0] = 3.5
+    ch.delta[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, M))
+    ch.A[:, :, 0] = rng.gamma(2.0, 1.0, size=(K, 2))
+    ch.gamma[..., 0] = rng.gamma(2.0, 0.7, size=(K, P, M))
+    ch.tau[0, :] = rng.gamma(3.0, 0.5, size=K)
+    ch.sigma[0] = 0.02
+    ch.eta[..., 0] = 0.2 * rng.standard_normal((P, D, K))
+    ch.xi[..., 0] = 0.05 * rng.standard_normal((P, D, M, K)) if cov_adj else 0.0
+    ch.tau_eta[..., 0] = rng.gamma(3.0, 0.5, size=(K, D))
+    ch.gamma_xi[..., 0] = rng.gamma(2.0, 0.7, size=(P, D, M, K))
+    ch.delta_xi[..., 0] = rng.gamma(2.0, 1.0, size=(K, M, D))
+    ch.A_xi[..., 0] = rng.gamma(2.0, 1.0, size=(K, 2, D))
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=max(degs), tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, sim["y"], basis=sim["B"], band=sim["band"], penalty=sim["Pmat"], penalty_band=sim["pen_band"])
+    smp.set_covariates(X, cov_adj)
+    push_state(smp, ch)
+    smp.set_state(**{nm: oracle_slot(ch, nm, 0) for nm in ["eta", "xi", "tau_eta", "gamma_xi", "delta_xi", "A_xi"]})
+    h = O.make_hyper(K)
+    O.run_sweeps(model, h, ch, O.SWEEP_WARM, seed=4, covariance_adj=cov_adj)
+    smp.run(S.SWEEP_WARM | S.COV_MEAN | (S.COV_XI if cov_adj else 0), T, seed=4)
+    names = STATE_NAMES + ["eta", "tau_eta", "loglik"] + (["xi", "delta_xi", "A_xi", "gamma_xi"] if cov_adj else [])
+    for nm in names:
+        err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
+        assert err < 1e-6, (nm, err)
