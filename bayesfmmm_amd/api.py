@@ -69,11 +69,37 @@ ENTRY_SYMBOLS = {
 _bound = False
 
 
+class PostInput(C.Structure):
+    """bfmmm_post_input of include/bfmmm_post.h."""
+    _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("P", C.c_int32), ("M", C.c_int32), ("D", C.c_int32),
+                ("offsets", c_int64_p), ("y", c_double_p), ("B", c_double_p), ("X", c_double_p), ("T", C.c_int32),
+                ("nu", c_double_p), ("Phi", c_double_p), ("Z", c_double_p), ("chi", c_double_p), ("sigma", c_double_p),
+                ("eta", c_double_p), ("xi", c_double_p), ("device", C.c_int32)]
+
+
+class PostArgs(C.Structure):
+    """bfmmm_post_args of include/bfmmm_post.h."""
+    _fields_ = [("dir", C.c_char_p), ("n_files", C.c_int32), ("basis_degree", C.c_int32), ("n_internal_knots", C.c_int32),
+                ("boundary_knots", c_double_p), ("internal_knots", c_double_p), ("n_funct", C.c_int32),
+                ("t", c_double_p), ("y", c_double_p), ("offsets", c_int64_p), ("burnin_prop", C.c_double),
+                ("X", c_double_p), ("D", C.c_int32), ("cov_adj", C.c_int32), ("device", C.c_int32)]
+
+
+POST_SYMBOLS = {
+    "bfmmm_post_pointwise": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_post_defaults": (None, [C.POINTER(PostArgs)]),
+    "bfmmm_FLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_FDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
+    "bfmmm_FAIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
+    "bfmmm_FBIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
+}
+
+
 def _lib_entry():
     global _bound
     lib = _lib.load()
     if not _bound:
-        for name, (res, args) in ENTRY_SYMBOLS.items():
+        for name, (res, args) in list(ENTRY_SYMBOLS.items()) + list(POST_SYMBOLS.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -483,3 +509,100 @@ def BHDFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eige
     if X is not None and args.a.covariance_adj:
         te_names += ("xi", "gamma_xi", "delta_xi", "A_xi")
     return _call1(lib.bfmmm_BHDFMMM_warm_start, args, mt, {k: theta_est[k] for k in te_names})
+
+
+# ---- likelihood-based post-processing (src/PostProcessing.cpp:3660-5114; include/bfmmm_post.h) ----------------------
+def post_pointwise(Y, B, nu, Phi, Z, chi, sigma, first_kept=0, X=None, eta=None, xi=None, device=0):
+    """bfmmm_post_pointwise on in-memory draws in the reference's shapes: nu (K, P, T), Phi (K, P, M, T), Z (n, K, T),
+    chi (n, M, T), sigma (T,), eta (P, D, K, T), xi (P, D, M, K, T).  Returns (llik (T,), mean_pdf, mean_fit) with the
+    per-observation arrays as lists shaped like Y."""
+    lib = _lib_entry()
+    n = len(Y)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(v) for v in Y])
+    y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in Y]))
+    Bm = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.float64) for b in B], axis=0))
+    K, P, T = nu.shape
+    M = chi.shape[1]
+    keep = [off, y, Bm]
+
+    def fa(x):
+        a = np.asfortranarray(x, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data_as(c_double_p)
+
+    inp = PostInput()
+    inp.n, inp.K, inp.P, inp.M, inp.T, inp.device = n, K, P, M, T, device
+    inp.offsets, inp.y, inp.B = off.ctypes.data_as(c_int64_p), y.ctypes.data_as(c_double_p), Bm.ctypes.data_as(c_double_p)
+    inp.nu, inp.Phi, inp.Z, inp.chi, inp.sigma = fa(nu), fa(Phi), fa(Z), fa(chi), fa(sigma)
+    if X is not None:
+        inp.X, inp.D = fa(X), np.asarray(X).shape[1]
+        if eta is not None:
+            inp.eta = fa(eta)
+        if xi is not None:      # (P, D, M, K, T) -> T x K cubes P x D x M
+            inp.xi = fa(np.transpose(np.asarray(xi), (0, 1, 2, 3, 4)))
+    ll, pdf, fit = np.zeros(T), np.zeros(len(y)), np.zeros(len(y))
+    _check(lib.bfmmm_post_pointwise(C.byref(inp), int(first_kept), ll.ctypes.data_as(c_double_p), pdf.ctypes.data_as(c_double_p),
+                                    fit.ctypes.data_as(c_double_p)))
+    split = lambda v: [v[off[i]:off[i + 1]].copy() for i in range(n)]
+    return ll, split(pdf), split(fit)
+
+
+class _PostArgs:
+    def __init__(self, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj, device=0):
+        lib = _lib_entry()
+        self.a = PostArgs()
+        lib.bfmmm_post_defaults(C.byref(self.a))
+        n = len(Y)
+        self.off = np.zeros(n + 1, dtype=np.int64)
+        self.off[1:] = np.cumsum([len(v) for v in Y])
+        self.y = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for v in Y]))
+        self.t = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for v in time]))
+        self.bk = np.ascontiguousarray(boundary_knots, dtype=np.float64)
+        self.ik = np.ascontiguousarray(internal_knots, dtype=np.float64)
+        self.dir = str(dir).encode()
+        a = self.a
+        a.dir, a.n_files, a.basis_degree, a.n_internal_knots = self.dir, n_files, basis_degree, len(self.ik)
+        a.boundary_knots, a.internal_knots = self.bk.ctypes.data_as(c_double_p), self.ik.ctypes.data_as(c_double_p)
+        a.n_funct, a.t, a.y, a.offsets = n, self.t.ctypes.data_as(c_double_p), self.y.ctypes.data_as(c_double_p), self.off.ctypes.data_as(c_int64_p)
+        if burnin_prop is not None:
+            a.burnin_prop = burnin_prop
+        if X is not None:
+            self.X = np.asfortranarray(X, dtype=np.float64)
+            a.X, a.D = self.X.ctypes.data_as(c_double_p), self.X.shape[1]
+        a.cov_adj, a.device = int(bool(cov_adj)), device
+
+
+def FLLik(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:4892: the log-likelihood of every saved draw."""
+    lib = _lib_entry()
+    args = _PostArgs(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, None, X, cov_adj)
+    res = C.c_void_p()
+    _check(lib.bfmmm_FLLik(C.byref(args.a), C.byref(res)))
+    try:
+        return _result_to_dict(lib, res, None, 0)["value"]
+    finally:
+        lib.bfmmm_result_free(res)
+
+
+def _post_scalar(name, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj):
+    lib = _lib_entry()
+    args = _PostArgs(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)
+    out = C.c_double()
+    _check(getattr(lib, name)(C.byref(args.a), C.cast(C.byref(out), c_double_p)))
+    return out.value
+
+
+def FDIC(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:3660."""
+    return _post_scalar("bfmmm_FDIC", dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)
+
+
+def FAIC(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:4041."""
+    return _post_scalar("bfmmm_FAIC", dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)
+
+
+def FBIC(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:4458."""
+    return _post_scalar("bfmmm_FBIC", dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)

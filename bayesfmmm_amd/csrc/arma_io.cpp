@@ -153,6 +153,36 @@ int arma_save_field_cubes(const std::string& path, const std::vector<std::vector
   return write_file(path.c_str(), out);
 }
 
+// ---- internal readers used by the post-processing entry points (post_entry.cpp) --------------------------------
+int arma_load_obj(const std::string& path, std::vector<double>& v, int64_t dims[3]) {
+  Reader rd;
+  if (load(path.c_str(), rd)) return 1;
+  Obj o;
+  if (read_obj(rd, o, path.c_str())) return 1;
+  dims[0] = o.r; dims[1] = o.c; dims[2] = o.s;
+  v = std::move(o.v);
+  return 0;
+}
+
+// objects in the field's column-major order; dims of the first object
+int arma_load_field(const std::string& path, std::vector<std::vector<double>>& objs, int64_t* n_rows, int64_t* n_cols, int64_t dims[3]) {
+  Reader rd;
+  if (load(path.c_str(), rd)) return 1;
+  std::string h, l1, l2;
+  if (!rd.line(h) || h != "ARMA_FLD_BIN" || !rd.line(l1) || !rd.line(l2)) return bfmmm_io_fail("'" + path + "': not an ARMA_FLD_BIN file");
+  const long long nr = atoll(l1.c_str()), nc = atoll(l2.c_str());
+  if (nr < 0 || nc < 0) return bfmmm_io_fail("'" + path + "': bad field dimensions");
+  objs.clear();
+  for (long long e = 0; e < nr * nc; ++e) {
+    Obj o;
+    if (read_obj(rd, o, path.c_str())) return 1;
+    if (e == 0) { dims[0] = o.r; dims[1] = o.c; dims[2] = o.s; }
+    objs.push_back(std::move(o.v));
+  }
+  *n_rows = nr; *n_cols = nc;
+  return 0;
+}
+
 // ---- C ABI --------------------------------------------------------------------------------------------------
 extern "C" int bfmmm_arma_write_ascii(const char* file, const double* data, const int64_t* dims, int n_dims) {
   if (!file || !dims || n_dims < 1 || n_dims > 3) return bfmmm_io_fail("bfmmm_arma_write_ascii: bad arguments");

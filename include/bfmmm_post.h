@@ -1,0 +1,75 @@
+/*
+ * bfmmm_post.h -- C ABI of the likelihood-based post-processing functions of the functional model:
+ *
+ *   bfmmm_FLLik  <-  FLLik  src/PostProcessing.cpp:4892-5114  (log-likelihood of every saved draw)
+ *   bfmmm_FDIC   <-  FDIC   src/PostProcessing.cpp:3660-4039  (deviance information criterion)
+ *   bfmmm_FAIC   <-  FAIC   src/PostProcessing.cpp:4041-4456
+ *   bfmmm_FBIC   <-  FBIC   src/PostProcessing.cpp:4458-4801
+ *
+ * All four evaluate the fitted value of every observation under every saved draw
+ *   f_ij(t) = B_ij' sum_k Z_ik(t) [ nu_k(t) + eta_k(t) x_i + sum_m chi_im(t) (phi_km(t) + xi_km(t) x_i) ]
+ * (calcLikelihoodCovariateAdj / calcDIC2CovariateAdj, inst/include/BayesFMMM/CalculateLikelihood.h:19-44, :59-125) and
+ * differ only in how the residuals are reduced; bfmmm_post_pointwise is that evaluation on the MI355X (one pass over the
+ * draws: per-draw log-likelihood, per-observation mean density and mean fitted value over the kept draws), the four
+ * entry points read the on-disk batches (`<dir>Nu<q>.txt`, `Phi`, `Z`, `Chi`, `Sigma`, and `Eta`, `Xi` with covariates,
+ * q < n_files; the files bfmmm_BFMMM_warm_start writes), call it and apply the reference's formulas.
+ * Errors: non-zero return, message via bfmmm_entry_last_error() (bfmmm_entry.h), with the reference's wording.
+ */
+#ifndef BFMMM_POST_H
+#define BFMMM_POST_H
+
+#include <stdint.h>
+
+#include "bfmmm_entry.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int32_t n, K, P, M, D;           /* curves, clusters, basis functions, eigenfunctions, covariates (0: none) */
+  const int64_t* offsets;          /* n + 1 */
+  const double* y;                 /* offsets[n] observations */
+  const double* B;                 /* offsets[n] x P basis rows, row-major */
+  const double* X;                 /* n x D column-major, or NULL */
+  int32_t T;                       /* draws, in the layouts of the reference's containers: */
+  const double* nu;                /* K x P x T */
+  const double* Phi;               /* T cubes K x P x M */
+  const double* Z;                 /* n x K x T */
+  const double* chi;               /* n x M x T */
+  const double* sigma;             /* T */
+  const double* eta;               /* T cubes P x D x K, or NULL (zero) */
+  const double* xi;                /* T x K cubes P x D x M, cube (t, k) at offset (t * K + k) * P * D * M, or NULL (zero) */
+  int32_t device;
+} bfmmm_post_input;
+
+/* llik: T; mean_pdf, mean_fit: offsets[n] (means over the draws t >= first_kept); any of the three may be NULL */
+int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit);
+
+typedef struct {
+  const char* dir;                 /* as the reference: file = dir + "Nu" + q + ".txt" (end it with "/") */
+  int32_t n_files;
+  int32_t basis_degree, n_internal_knots;
+  const double* boundary_knots;    /* 2 */
+  const double* internal_knots;
+  int32_t n_funct;                 /* CSR form of the R lists `time` and `Y` */
+  const double* t;
+  const double* y;
+  const int64_t* offsets;
+  double burnin_prop;              /* FDIC / FAIC / FBIC (default 0.1) */
+  const double* X;                 /* n_funct x D column-major, or NULL */
+  int32_t D;
+  int32_t cov_adj;
+  int32_t device;
+} bfmmm_post_args;
+
+void bfmmm_post_defaults(bfmmm_post_args* a);
+int bfmmm_FLLik(const bfmmm_post_args* a, bfmmm_result** out);      /* result element "value": one entry per saved draw */
+int bfmmm_FDIC(const bfmmm_post_args* a, double* out);
+int bfmmm_FAIC(const bfmmm_post_args* a, double* out);
+int bfmmm_FBIC(const bfmmm_post_args* a, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

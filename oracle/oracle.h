@@ -143,6 +143,15 @@ void orc_updateTau(const orc_data* d, const orc_rng* r, int iter, int T, double 
 void orc_updateSigma(const orc_data* d, const orc_rng* r, double beta_i, int tempered, int iter, int T, double alpha_0, double beta_0, orc_chain* c);
 void orc_updateChi(const orc_data* d, const orc_rng* r, double beta_i, int iter, int T, orc_chain* c);
 double orc_calcLikelihood(const orc_data* d, int iter, const orc_chain* c);
+double orc_fitted(const orc_data* d, const orc_chain* c, int iter, int i, int l);
+double orc_yobs(const orc_data* d, int i, int l);
+int orc_ni(const orc_data* d, int i);
+
+/* post.c: likelihood-based post-processing over a chain of T saved draws (src/PostProcessing.cpp) */
+void orc_post_llik(const orc_data* d, const orc_chain* c, int T, double* out);
+double orc_post_dic(const orc_data* d, const orc_chain* c, int T, double burnin_prop);
+double orc_post_aic(const orc_data* d, const orc_chain* c, int T, double burnin_prop, int has_x, int cov_adj);
+double orc_post_bic(const orc_data* d, const orc_chain* c, int T, double burnin_prop, int has_x, int cov_adj);
 void orc_tilde_tau(int K, int M, const double* delta_slice, double* tilde_tau);
 /* covariate-adjusted extras */
 void orc_updateEta(const orc_data* d, const orc_rng* r, double beta_i, int iter, int T, orc_chain* c);

@@ -1,0 +1,80 @@
+/* TEST INFRASTRUCTURE ONLY (see oracle.h): CPU restatement of the likelihood-based post-processing functions of the
+ * functional model, over a chain whose T slots hold the saved draws (the concatenated on-disk batches).
+ *
+ *   orc_post_llik  FLLik  src/PostProcessing.cpp:5106-5111   LLik(i) = calcLikelihoodCovariateAdj(draw i)
+ *   orc_post_dic   FDIC   :3835-3853 (no covariates), :3922-3944 (covariates)
+ *   orc_post_aic   FAIC   :4142-4178, :4318-4364
+ *   orc_post_bic   FBIC   :4558-4600, :4738-4792
+ *
+ * Parity unpinned: the reference ships no expected values for these functions (its trace fixtures hold no Z / Chi
+ * files); the restatement follows the reference's loops line by line and shares calcLikelihood / the fitted mean with the
+ * sampler's oracle, which is pinned. */
+#include <math.h>
+#include <stdlib.h>
+
+#include "oracle.h"
+
+static double dnorm(double x, double mean, double sd, int lg) {      /* R::dnorm */
+  const double z = (x - mean) / sd;
+  if (lg) return -(0.91893853320467274178 + 0.5 * z * z + log(sd));
+  return 0.39894228040143267794 * exp(-0.5 * z * z) / sd;
+}
+
+void orc_post_llik(const orc_data* d, const orc_chain* c, int T, double* out) {
+  for (int i = 0; i < T; ++i) out[i] = orc_calcLikelihood(d, i, c);
+}
+
+double orc_post_dic(const orc_data* d, const orc_chain* c, int T, double burnin_prop) {
+  const int kept = (int)round((1 - burnin_prop) * T);
+  double expected_log_f = 0;
+  for (int i = T - kept; i < T; ++i) expected_log_f = expected_log_f + orc_calcLikelihood(d, i, c);
+  expected_log_f = expected_log_f / kept;
+  double f_hat = 0;
+  for (int i = 0; i < d->n; ++i) {
+    for (int j = 0; j < orc_ni(d, i); ++j) {
+      double f_hat_ij = 0;
+      for (int n = T - kept; n < T; ++n)      /* calcDIC2 / calcDIC2CovariateAdj, CalculateLikelihood.h:59-125 */
+        f_hat_ij = f_hat_ij + dnorm(orc_yobs(d, i, j), orc_fitted(d, c, n, i, j), sqrt(c->sigma[n]), 0);
+      f_hat = f_hat + log(f_hat_ij / kept);
+    }
+  }
+  return (2 * f_hat) - (4 * expected_log_f);
+}
+
+/* log-likelihood at the mean curve fits over the kept draws and the mean of all saved sigma^2 */
+static double loglik_at_means(const orc_data* d, const orc_chain* c, int T, double burnin_prop) {
+  const int kept = (int)round((1 - burnin_prop) * T);
+  double mean_sigma = 0;
+  for (int i = 0; i < T; ++i) mean_sigma += c->sigma[i];
+  mean_sigma /= T;
+  double log_lik = 0;
+  for (int i = 0; i < d->n; ++i) {
+    for (int j = 0; j < orc_ni(d, i); ++j) {
+      double m = 0;
+      for (int n = T - kept; n < T; ++n) m += orc_fitted(d, c, n, i, j);
+      m /= kept;
+      log_lik = log_lik + dnorm(orc_yobs(d, i, j), m, sqrt(mean_sigma), 1);
+    }
+  }
+  return log_lik;
+}
+
+static double n_params(const orc_data* d, int has_x, int cov_adj) {
+  const double n = d->n, K = d->K, P = d->P, M = d->M, D = d->D;
+  double v = (n + P) * K + 2 * P * M * K + 2 + 4 * K + n * M + (M * K);
+  if (has_x) {
+    v += P * D * K + D * K;
+    if (cov_adj) v += 2 * P * D * K * M + D * K * M + 2 * D * K;
+  }
+  return v;
+}
+
+double orc_post_aic(const orc_data* d, const orc_chain* c, int T, double burnin_prop, int has_x, int cov_adj) {
+  return 2 * n_params(d, has_x, cov_adj) - (2 * loglik_at_means(d, c, T, burnin_prop));
+}
+
+double orc_post_bic(const orc_data* d, const orc_chain* c, int T, double burnin_prop, int has_x, int cov_adj) {
+  double tilde_N = 0;
+  for (int i = 0; i < d->n; ++i) tilde_N = tilde_N + orc_ni(d, i);
+  return (2 * loglik_at_means(d, c, T, burnin_prop)) - (log(tilde_N) * n_params(d, has_x, cov_adj));
+}

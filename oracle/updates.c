@@ -547,6 +547,14 @@ static double fitted_skipzero(const orc_data* d, const orc_chain* c, int iter, i
   return mean;
 }
 
+/* fitted mean and observation of (i, l) for the post-processing restatements (post.c) */
+double orc_fitted(const orc_data* d, const orc_chain* c, int iter, int i, int l) {
+  DIMS;
+  return fitted_skipzero(d, c, iter, i, BROW(i, l));
+}
+double orc_yobs(const orc_data* d, int i, int l) { return YOBS(i, l); }
+int orc_ni(const orc_data* d, int i) { return NI(i); }
+
 /* updateSigma, UpdateSigma.h:22-58: a += n_i / 2 with INTEGER division (:49);
  * Tempered :75-113 uses (beta_i * n_i) / 2 in floating point (:103) and beta_i/2 weights;
  * MV :127-156 uses y_obs.n_elem / 2 (integer, total element count, :150);

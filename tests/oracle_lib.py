@@ -59,6 +59,7 @@ def lib():
         L.orc_dtruncnorm_log.restype = C.c_double
         L.orc_dtruncnorm_log.argtypes = [C.c_double] * 5
         L.orc_calcLikelihood.restype = C.c_double
+        L.orc_fitted.restype = C.c_double
         L.orc_test_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                     C.c_double, C.c_int, c_double_p]
         L.orc_run_sweeps.argtypes = [C.POINTER(OrcData), C.POINTER(OrcHyper), C.c_uint64, C.c_uint32, C.c_int,
@@ -373,3 +374,29 @@ def updateGammaXi(model, ch, it, nu_gamma, seed=1, chain_id=0):
 
 def calcLikelihood(model, ch, it):
     return lib().orc_calcLikelihood(C.byref(model.data), it, C.byref(ch.c))
+
+
+# ---- post-processing (oracle/post.c) over a chain whose slots are the saved draws ----
+def post_llik(model, ch):
+    L = lib()
+    L.orc_post_llik.restype = None
+    L.orc_post_llik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, c_double_p]
+    out = np.zeros(ch.T)
+    L.orc_post_llik(C.addressof(model.data), C.addressof(ch.c), ch.T, dp(out))
+    return out
+
+
+def post_dic(model, ch, burnin_prop):
+    L = lib()
+    L.orc_post_dic.restype = C.c_double
+    L.orc_post_dic.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+    return L.orc_post_dic(C.addressof(model.data), C.addressof(ch.c), ch.T, burnin_prop)
+
+
+def post_aic_bic(model, ch, burnin_prop, has_x, cov_adj):
+    L = lib()
+    for f in (L.orc_post_aic, L.orc_post_bic):
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int]
+    a = (C.addressof(model.data), C.addressof(ch.c), ch.T, burnin_prop, int(has_x), int(cov_adj))
+    return L.orc_post_aic(*a), L.orc_post_bic(*a)

@@ -24,6 +24,11 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared2:
         assert hasattr(lib, name), f"{name} declared in include/bfmmm_entry.h but not exported"
     assert declared2 == set(api.ENTRY_SYMBOLS), declared2 ^ set(api.ENTRY_SYMBOLS)
+    hdr3 = open(os.path.join(root, "include", "bfmmm_post.h")).read()
+    declared3 = set(re.findall(r"\b(bfmmm_[A-Za-z_0-9]+)\s*\(", hdr3)) - {"bfmmm_entry_last_error"}
+    for name in declared3:
+        assert hasattr(lib, name), f"{name} declared in include/bfmmm_post.h but not exported"
+    assert declared3 == set(api.POST_SYMBOLS), declared3 ^ set(api.POST_SYMBOLS)
 
 
 def test_no_gpu_fails_loudly():
