@@ -87,6 +87,7 @@ class PostArgs(C.Structure):
 
 POST_SYMBOLS = {
     "bfmmm_post_pointwise": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_post_last_kernel_ms": (C.c_double, []),
     "bfmmm_post_defaults": (None, [C.POINTER(PostArgs)]),
     "bfmmm_FLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_FDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),

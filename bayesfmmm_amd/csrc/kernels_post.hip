@@ -7,13 +7,15 @@
 //   phase 0  Z_i.(t), chi_i.(t), sigma^2(t) of the tile                                  -> LDS
 //   phase 1  c_p(t) = sum_k Z_ik [theta_{k,0} + sum_m chi_im theta_{k,m}](p), (g, p) pairs -> LDS   (skip Z_ik == 0 as the
 //            reference does; covariates folded into the rows: theta + sum_d x_id thetaX_d)
-//   phase 2  thread (j, g): f = B_ij' c(t_g), residual, log-density term -> LDS; density and f accumulate in registers
-//   phase 3  thread g: fixed-order sum over j -> llpart[i][t]
+//   phase 2  thread (j, draw lane): f = B_ij' c(t) for NG draws at once over the row's non-zero window, residual,
+//            log-density term; density and f accumulate in registers; the terms of a draw meet by a butterfly over the
+//            observation lanes (fixed order) -> llpart[i][t]
 // and leaves per-observation sums over its chunk in pdf_part / fit_part.  k_post_reduce sums curves (per draw) and chunks
 // (per observation) in a fixed order: results do not depend on the launch geometry's scheduling.
 //
 // Bound: HBM.  Algorithmic bytes per draw = 8 [ n (K + M) + K (M + 1) P (1 + D) + 1 ] read + 8 n written (llpart); the
-// basis rows of a curve (n_i x P) are staged in LDS once per workgroup.  Draw parameters arrive transposed to the
+// non-zero windows of a curve's basis rows (n_i x W, W = degree + 1 for B-splines) are staged in LDS once per workgroup;
+// the next tile's Z / chi / sigma^2 are requested while the current tile is evaluated.  Draw parameters arrive transposed to the
 // sampler's row layout theta[t][r][p] (host, one pass) so that phase 1 reads are contiguous in p.
 #include <hip/hip_runtime.h>
 
@@ -29,125 +31,161 @@ namespace {
 
 constexpr int NJ = 4;            // observations per thread: n_i <= 1024
 constexpr int GMAX = 32;         // draws per tile
-constexpr int BL_MAX = 4096;     // doubles of basis rows staged per curve
-constexpr int PMAXP = 65;        // row stride of the coefficient tile (P <= 64, odd)
+constexpr int BL_MAX = 1536;     // doubles of basis-row windows staged per curve
 constexpr int WMAX = 20;         // K + M + 2 <= 20
+constexpr int NG = 8;            // draws per thread in the fitted-value phase
+constexpr int NWR = 3;           // prefetch registers: GMAX (K + M + 1) <= 768 items per tile
 
 struct PostDev {
   int n, K, P, M, D, T, first_kept, tchunk;
   long long n_obs;
   const long long* off;
-  const double *y, *B, *X, *theta, *thetaX, *Z, *chi, *sigma;
+  const double *y, *Bc, *X, *theta, *thetaX, *Z, *chi, *sigma;      // Bc: the rows' non-zero windows, n_obs x W
+  const int* bstart;                                                // first column of each row's window
+  int W, need_pdf;
   double *llpart, *pdf_part, *fit_part;
 };
 
-__global__ __launch_bounds__(256) void k_post_pointwise(PostDev a) {
+__global__ __launch_bounds__(256, 3) void k_post_pointwise(PostDev a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int i = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
   const long long o = a.off[i];
   const int ni = (int)(a.off[i + 1] - o);
-  const int P = a.P, K = a.K, M = a.M, D = a.D, R = K * (M + 1), n = a.n, T = a.T;
+  const int P = a.P, K = a.K, M = a.M, D = a.D, R = K * (M + 1), n = a.n, T = a.T, W = a.W;
   int JW = 1;
   while (JW < min(ni, 256)) JW <<= 1;
-  const int G = min(256 / JW, GMAX);
-  const int LW = JW * NJ;                   // row stride of the per-tile term table
-  const int PS = P | 1;                     // odd row stride of the staged basis rows
-  const bool staged = (size_t)ni * PS <= BL_MAX;
-  double* sC = sm;                          // GMAX x PMAXP
-  double* sW = sC + GMAX * PMAXP;           // GMAX x WMAX : Z (K), chi (M), sd, sigma^2
-  double* sLL = sW + GMAX * WMAX;           // 2 x 1024: terms of the tile; the final reduction's scratch
-  double* sB = sLL + 2 * 1024;              // BL_MAX
+  const int GT = min(256 / JW, GMAX / NG);  // draw lanes
+  const int G = GT * NG;                    // draws per tile
+  const int LW = JW * NJ;                   // row stride of the per-observation tables
+  const int WS = W | 1;                     // odd row stride of the staged basis rows
+  const int CS = P | 1;                     // odd row stride of the coefficient tile
+  const bool staged = (size_t)ni * WS <= BL_MAX;
+  const int NWI = G * (K + M + 1);          // membership / score / variance items of a tile
+  double* sC = sm;                          // GMAX x CS
+  double* sW = sC + GMAX * CS;              // GMAX x WMAX : Z (K), chi (M), 1 / sd, log sd
+  double* sAccP = sW + GMAX * WMAX;         // 1024: per (draw lane, observation) sums of the density over the kept draws
+  double* sAccF = sAccP + 1024;             // 1024: ... of the fitted value
+  double* sRed = sAccF + 1024;              // 64: wave partials of a draw's log-likelihood
+  double* sB = sRed + 64;                   // BL_MAX
   double* sX = sB + BL_MAX;                 // 8
   if (staged)
-    for (int e = tid; e < ni * P; e += 256) { const int j = e / P, p = e - j * P; sB[j * PS + p] = a.B[(size_t)(o + j) * P + p]; }
+    for (int e = tid; e < ni * W; e += 256) { const int j = e / W, w = e - j * W; sB[j * WS + w] = a.Bc[(size_t)(o + j) * W + w]; }
   if (tid < D) sX[tid] = a.X[i + (size_t)n * tid];
+  for (int e = tid; e < 2048; e += 256) sAccP[e] = 0.0;      // (sAccP and sAccF are adjacent)
   const int jl = tid % JW, gl = tid / JW;
-  double acc_pdf[NJ], acc_fit[NJ], yv[NJ];
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    acc_pdf[jj] = 0.0; acc_fit[jj] = 0.0;
-    const int j = jl + jj * JW;
-    yv[jj] = (j < ni) ? a.y[o + j] : 0.0;
-  }
+  const double y0 = (jl < ni) ? a.y[o + jl] : 0.0;           // the first (usually the only) observation of this thread
+  const int st0 = (jl < ni) ? a.bstart[o + jl] : 0;
   const int t_lo = ch * a.tchunk, t_hi = min(T, t_lo + a.tchunk);
+  // the curve's membership, scores and the variance under a tile's draws are requested one tile ahead
+  double wreg[NWR];
+  auto request = [&](int tb) {
+#pragma unroll
+    for (int u = 0; u < NWR; ++u) {
+      const int e = min(tid + 256 * u, NWI - 1);
+      const int g = e / (K + M + 1), w = e - g * (K + M + 1), t = min(tb + g, t_hi - 1);
+      const double* src = (w < K) ? a.Z + i + (size_t)n * (w + (size_t)K * t)
+                        : (w < K + M) ? a.chi + i + (size_t)n * ((w - K) + (size_t)M * t) : a.sigma + t;
+      wreg[u] = *src;
+    }
+  };
+  request(t_lo);
   for (int tb = t_lo; tb < t_hi; tb += G) {
     __syncthreads();
-    // ---- phase 0: the curve's membership and scores under the tile's draws ----
-    for (int e = tid; e < G * (K + M + 1); e += 256) {
-      const int g = e / (K + M + 1), w = e - g * (K + M + 1), t = min(tb + g, t_hi - 1);
-      double v;
-      if (w < K) v = a.Z[i + (size_t)n * (w + (size_t)K * t)];
-      else if (w < K + M) v = a.chi[i + (size_t)n * ((w - K) + (size_t)M * t)];
-      else { v = a.sigma[t]; sW[g * WMAX + K + M + 1] = v; v = sqrt(v); }
-      sW[g * WMAX + w] = v;
+#pragma unroll
+    for (int u = 0; u < NWR; ++u) {
+      const int e = tid + 256 * u;
+      if (e < NWI) {
+        const int g = e / (K + M + 1), w = e - g * (K + M + 1);
+        if (w < K + M) sW[g * WMAX + w] = wreg[u];
+        else { const double sd = sqrt(wreg[u]); sW[g * WMAX + K + M] = 1.0 / sd; sW[g * WMAX + K + M + 1] = log(sd); }
+      }
     }
+    if (tb + G < t_hi) request(tb + G);
     __syncthreads();
-    // ---- phase 1: coefficient vectors ----
+    // ---- phase 1: coefficient vectors.  The parameter rows of a draw are L2 hits shared by every curve; a thread reads
+    //      them in batches of twelve independent loads (one dependent load per row made
+    //      this phase the whole kernel) ----
     for (int e = tid; e < G * P; e += 256) {
+      constexpr int NB = 12;
       const int g = e / P, p = e - g * P, t = min(tb + g, t_hi - 1);
-      const double* th = a.theta + (size_t)t * R * P + p;
-      const double* thx = a.thetaX ? a.thetaX + (size_t)t * R * D * P + p : nullptr;
+      const unsigned base = (unsigned)((t * R) * P + p);           // element offsets from uniform bases: 32-bit address math
       const double* w = sW + g * WMAX;
       double c = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const double zk = w[k];
-        if (zk != 0.0) {                                           // CalculateLikelihood.h:29, :70
-          double acc = 0.0;
-          for (int mt = 0; mt <= M; ++mt) {
-            const int r = k * (M + 1) + mt;
-            double v = th[(size_t)r * P];
-            for (int dd = 0; dd < D; ++dd) v += sX[dd] * thx[((size_t)r * D + dd) * P];
-            acc += (mt == 0) ? v : w[K + mt - 1] * v;
-          }
-          c += zk * acc;
-        }
-      }
-      sC[g * PMAXP + p] = c;
-    }
-    __syncthreads();
-    // ---- phase 2: fitted values and density terms ----
-    if (gl < G && tb + gl < t_hi) {
-      const int t = tb + gl;
-      const double sd = sW[gl * WMAX + K + M];
-      const double lsd = log(sd);
-      const double* cg = sC + gl * PMAXP;
-      const bool kept = t >= a.first_kept;
+      for (int r0 = 0; r0 < R; r0 += NB) {
+        double v[NB];
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int j = jl + jj * JW;
-        if (j < ni) {
-          double f = 0.0;
-          if (staged) { const double* br = sB + j * PS; for (int p = 0; p < P; ++p) f += br[p] * cg[p]; }
-          else { const double* br = a.B + (size_t)(o + j) * P; for (int p = 0; p < P; ++p) f += br[p] * cg[p]; }
-          const double z = (yv[jj] - f) / sd;
-          sLL[gl * LW + j] = -(0.91893853320467274178 + 0.5 * z * z + lsd);      // R::dnorm(., ., ., log = true)
-          if (kept) { acc_pdf[jj] += exp(-0.5 * z * z) / (sd * 2.50662827463100050242); acc_fit[jj] += f; }
+        for (int u = 0; u < NB; ++u) v[u] = a.theta[base + (unsigned)(min(r0 + u, R - 1) * P)];
+        for (int dd = 0; dd < D; ++dd) {
+          double qv[NB];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) qv[u] = a.thetaX[(base - (unsigned)p) * (unsigned)D + (unsigned)((min(r0 + u, R - 1) * D + dd) * P + p)];
+          const double x = sX[dd];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) v[u] += x * qv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int r = r0 + u;
+          if (r < R) {
+            const int k = r / (M + 1), mt = r - k * (M + 1);
+            const double zk = w[k];
+            const double x = (zk != 0.0) ? v[u] : 0.0;                 // CalculateLikelihood.h:29, :70 (the Z_ik == 0 skip)
+            c += zk * ((mt == 0) ? x : w[K + mt - 1] * x);
+          }
         }
       }
+      sC[g * CS + p] = c;
     }
     __syncthreads();
-    // ---- phase 3: the curve's log-likelihood under each draw of the tile ----
-    if (tid < G && tb + tid < t_hi) {
-      double s = 0.0;
-      for (int j = 0; j < ni; ++j) s += sLL[tid * LW + j];
-      a.llpart[(size_t)i * T + tb + tid] = s;
+    // ---- phase 2: fitted values and density terms, one (observation, draw) pair at a time (the row's non-zero window is
+    //      short; one copy of the exp / log code keeps the kernel at four waves per SIMD) ----
+    if (gl < GT) {
+#pragma unroll 1
+      for (int q = 0; q < NG; ++q) {
+        const int g = gl * NG + q, t = tb + g;
+        const bool on = t < t_hi;
+        const double isd = sW[g * WMAX + K + M], lsd = sW[g * WMAX + K + M + 1];
+        const bool kept = on && t >= a.first_kept;
+        double ll = 0.0;
+#pragma unroll 1
+        for (int j = jl; j < ni; j += JW) {
+          const double yj = (j == jl) ? y0 : a.y[o + j];
+          const int stj = (j == jl) ? st0 : a.bstart[o + j];
+          const double* br = staged ? sB + j * WS : a.Bc + (size_t)(o + j) * W;
+          const double* cg = sC + g * CS + stj;
+          double f = 0.0;
+          for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+          const double z = (yj - f) * isd;
+          const double lt = -(0.91893853320467274178 + 0.5 * z * z + lsd);     // R::dnorm(., ., ., log = true)
+          if (on) ll += lt;
+          if (kept) {
+            if (a.need_pdf) sAccP[gl * LW + j] += exp(lt);
+            sAccF[gl * LW + j] += f;
+          }
+        }
+        // the curve's log-likelihood under draw t: butterfly over the observation lanes (fixed order)
+        for (int off = min(JW, 64) >> 1; off > 0; off >>= 1) ll += __shfl_xor(ll, off);
+        if (JW <= 64) { if (jl == 0 && on) a.llpart[(size_t)i * T + t] = ll; }
+        else if ((tid & 63) == 0) sRed[(tid >> 6) * NG + q] = ll;
+      }
+    }
+    if (JW > 64) {
+      __syncthreads();
+      if (tid < G && tb + tid < t_hi) {
+        const int g2 = tid / NG, q = tid - g2 * NG, wpl = JW >> 6;      // waves per draw lane
+        double s = 0.0;
+        for (int wv = 0; wv < wpl; ++wv) s += sRed[(g2 * wpl + wv) * NG + q];
+        a.llpart[(size_t)i * T + tb + tid] = s;
+      }
     }
   }
-  // ---- per-observation sums of this chunk: the draw lanes meet in LDS, fixed order ----
-  for (int which = 0; which < 2; ++which) {
-    __syncthreads();
-    if (gl < G)
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int j = jl + jj * JW;
-        if (j < ni) sLL[gl * LW + j] = which ? acc_fit[jj] : acc_pdf[jj];
-      }
-    __syncthreads();
-    for (int j = tid; j < ni; j += 256) {
-      double s = 0.0;
-      for (int g = 0; g < G; ++g) s += sLL[g * LW + j];
-      (which ? a.fit_part : a.pdf_part)[(size_t)ch * a.n_obs + o + j] = s;
-    }
+  // ---- per-observation sums of this chunk: the draw lanes' tables, fixed order ----
+  __syncthreads();
+  for (int j = tid; j < ni; j += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < GT; ++g) { s1 += sAccP[g * LW + j]; s2 += sAccF[g * LW + j]; }
+    a.pdf_part[(size_t)ch * a.n_obs + o + j] = s1;
+    a.fit_part[(size_t)ch * a.n_obs + o + j] = s2;
   }
 }
 
@@ -167,6 +205,8 @@ __global__ __launch_bounds__(256) void k_post_reduce(PostDev a, int NCH, double*
     mean_fit[e] = s2 / kept;
   }
 }
+
+float g_last_kernel_ms = 0.f;
 
 struct DevBufs {
   std::vector<void*> p;
@@ -190,6 +230,7 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   const int n = in->n, K = in->K, P = in->P, M = in->M, D = in->X ? in->D : 0, T = in->T;
   if (n < 1 || K < 1 || P < 1 || M < 0 || T < 1 || first_kept < 0 || first_kept >= T)
     return bfmmm_io_fail("bfmmm_post_pointwise: bad dimensions");
+  if ((double)T * K * (M + 1) * P * std::max(D, 1) >= 5.0e8) return bfmmm_io_fail("bfmmm_post_pointwise: too many draws for one call (32-bit offsets into the parameter table): split the draws");
   if (P > 64 || K + M + 2 > WMAX || D > 8) return bfmmm_io_fail("bfmmm_post_pointwise: P <= 64, K + M <= 18 and D <= 8 in this build");
   const long long n_obs = in->offsets[n];
   for (int i = 0; i < n; ++i)
@@ -222,6 +263,22 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
                     in->xi[((size_t)t * K + k) * P * D * M + p + (size_t)P * (dd + (size_t)D * m)];
           }
   }
+  // basis rows as windows of their non-zero columns (a B-spline row has degree + 1 of them): W = the widest window
+  int W = 1;
+  std::vector<int> first((size_t)n_obs, 0);
+  for (long long e = 0; e < n_obs; ++e) {
+    int f = -1, l = -1;
+    for (int p = 0; p < P; ++p)
+      if (in->B[(size_t)e * P + p] != 0.0) { if (f < 0) f = p; l = p; }
+    first[(size_t)e] = std::max(f, 0);
+    if (f >= 0) W = std::max(W, l - f + 1);
+  }
+  std::vector<double> Bc((size_t)n_obs * W);
+  for (long long e = 0; e < n_obs; ++e) {
+    const int st = std::min(first[(size_t)e], P - W);
+    first[(size_t)e] = st;
+    for (int w = 0; w < W; ++w) Bc[(size_t)e * W + w] = in->B[(size_t)e * P + st + w];
+  }
   // chunks of draws: enough workgroups for the 256 CUs, tiles stay whole
   int tchunk = T;
   while ((long long)n * ((T + tchunk - 1) / tchunk) < 2048 && tchunk > GMAX) tchunk = (tchunk + 1) / 2;
@@ -229,11 +286,12 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   const int NCH = (T + tchunk - 1) / tchunk;
   DevBufs db;
   PostDev a{};
+  a.W = W; a.need_pdf = mean_pdf ? 1 : 0;
   a.n = n; a.K = K; a.P = P; a.M = M; a.D = D; a.T = T; a.first_kept = first_kept; a.tchunk = tchunk; a.n_obs = n_obs;
   std::vector<long long> off(in->offsets, in->offsets + n + 1);
   double *d_ll, *d_pdf, *d_fit;
   bool ok = db.put((long long**)&a.off, off.data(), off.size()) && db.put((double**)&a.y, in->y, (size_t)n_obs) &&
-            db.put((double**)&a.B, in->B, (size_t)n_obs * P) && db.put((double**)&a.theta, theta.data(), theta.size()) &&
+            db.put((double**)&a.Bc, Bc.data(), Bc.size()) && db.put((int**)&a.bstart, first.data(), first.size()) && db.put((double**)&a.theta, theta.data(), theta.size()) &&
             db.put((double**)&a.Z, in->Z, (size_t)n * K * T) && db.put((double**)&a.chi, in->chi, (size_t)n * M * T) &&
             db.put((double**)&a.sigma, in->sigma, (size_t)T) && db.put(&a.llpart, (const double*)nullptr, (size_t)n * T) &&
             db.put(&a.pdf_part, (const double*)nullptr, (size_t)NCH * n_obs) && db.put(&a.fit_part, (const double*)nullptr, (size_t)NCH * n_obs) &&
@@ -241,16 +299,25 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
             db.put(&d_fit, (const double*)nullptr, (size_t)n_obs);
   if (ok && D > 0) ok = db.put((double**)&a.X, in->X, (size_t)n * D) && db.put((double**)&a.thetaX, thetaX.data(), thetaX.size());
   if (!ok) { (void)hipGetLastError(); return bfmmm_io_fail("bfmmm_post_pointwise: device allocation or copy failed"); }
-  const size_t lds = ((size_t)GMAX * PMAXP + (size_t)GMAX * WMAX + 2 * 1024 + BL_MAX + 8) * sizeof(double);
+  const size_t lds = ((size_t)GMAX * (P | 1) + (size_t)GMAX * WMAX + 2048 + 64 + BL_MAX + 8) * sizeof(double);
   (void)hipFuncSetAttribute((const void*)k_post_pointwise, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
   hipLaunchKernelGGL(k_post_pointwise, dim3(n, NCH), dim3(256), lds, 0, a);
   const long long tot = std::max<long long>(T, n_obs);
   hipLaunchKernelGGL(k_post_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, a, NCH, d_ll, d_pdf, d_fit);
-  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
-    return bfmmm_io_fail("bfmmm_post_pointwise: kernel launch failed");
+  (void)hipEventRecord(e1, 0);
+  const bool ran = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+  if (ran) (void)hipEventElapsedTime(&g_last_kernel_ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (!ran) return bfmmm_io_fail("bfmmm_post_pointwise: kernel launch failed");
   if ((llik && hipMemcpy(llik, d_ll, sizeof(double) * T, hipMemcpyDeviceToHost) != hipSuccess) ||
       (mean_pdf && hipMemcpy(mean_pdf, d_pdf, sizeof(double) * n_obs, hipMemcpyDeviceToHost) != hipSuccess) ||
       (mean_fit && hipMemcpy(mean_fit, d_fit, sizeof(double) * n_obs, hipMemcpyDeviceToHost) != hipSuccess))
     return bfmmm_io_fail("bfmmm_post_pointwise: copy back failed");
   return 0;
 }
+
+// device time of the last bfmmm_post_pointwise call's two kernels (HIP events on the launch stream), for measurement
+extern "C" double bfmmm_post_last_kernel_ms(void) { return (double)g_last_kernel_ms; }

@@ -45,6 +45,8 @@ typedef struct {
 
 /* llik: T; mean_pdf, mean_fit: offsets[n] (means over the draws t >= first_kept); any of the three may be NULL */
 int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit);
+/* device time (ms, HIP events) of the kernels of the last bfmmm_post_pointwise call of this process: measurement aid */
+double bfmmm_post_last_kernel_ms(void);
 
 typedef struct {
   const char* dir;                 /* as the reference: file = dir + "Nu" + q + ".txt" (end it with "/") */

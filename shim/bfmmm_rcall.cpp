@@ -9,6 +9,7 @@
 //   _BayesFMMM_BFMMM_warm_start        (38,      :438)                  -> bfmmm_BFMMM_warm_start
 //   _BayesFMMM_BMVMMM_Nu_Z_multiple_try (23, :680), _BMVMMM_Theta_est (27, :713), _BMVMMM_warm_start (33, :750)
 //   _BayesFMMM_BHDFMMM_Nu_Z_multiple_try (28, :552), _BHDFMMM_Theta_est (32, :590), _BHDFMMM_warm_start (38, :632)
+//   _BayesFMMM_FDIC / FAIC / FBIC (10 args, :174, :194, :214), _BayesFMMM_FLLik (9, :234)  -> bfmmm_FDIC ... (bfmmm_post.h)
 //   _BayesFMMM_ReadVec / ReadMat / ReadCube / ReadFieldCube / ReadFieldMat / ReadFieldVec (1 arg each, :486-541)
 //
 // It is pure marshalling (no arithmetic): R lists of numeric vectors become CSR arrays, Rcpp::List arguments become
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "bfmmm_entry.h"
+#include "bfmmm_post.h"
 
 namespace {
 
@@ -426,6 +428,56 @@ SEXP _BayesFMMM_BHDFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP tim
   return finish(bfmmm_BHDFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
 }
 
+// ---- likelihood-based post-processing (RcppExports.cpp:174, :194, :214, :234) -------------------------------------
+static void set_post(bfmmm_post_args& a, const Ragged& y, const Ragged& t, SEXP dir, SEXP n_files, SEXP basis_degree,
+                     SEXP boundary_knots, SEXP internal_knots, SEXP X, SEXP cov_adj) {
+  bfmmm_post_defaults(&a);
+  a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files); a.basis_degree = Rf_asInteger(basis_degree);
+  a.boundary_knots = REAL(boundary_knots); a.internal_knots = REAL(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
+  a.n_funct = (int32_t)(y.off.size() - 1); a.t = t.v.data(); a.y = y.v.data(); a.offsets = y.off.data();
+  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+  a.cov_adj = Rf_asLogical(cov_adj) ? 1 : 0;
+}
+
+static SEXP post_scalar(int (*fn)(const bfmmm_post_args*, double*), SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots,
+                        SEXP internal_knots, SEXP time, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_post_args a;
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  double v = 0.0;
+  if (fn(&a, &v)) Rf_error("%s", bfmmm_entry_last_error());
+  return Rf_ScalarReal(v);
+}
+
+SEXP _BayesFMMM_FDIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
+                     SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  return post_scalar(bfmmm_FDIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+}
+SEXP _BayesFMMM_FAIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
+                     SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  return post_scalar(bfmmm_FAIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+}
+SEXP _BayesFMMM_FBIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
+                     SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  return post_scalar(bfmmm_FBIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+}
+SEXP _BayesFMMM_FLLik(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
+                      SEXP X, SEXP cov_adj) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_post_args a;
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  bfmmm_result* r = NULL;
+  if (bfmmm_FLLik(&a, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  const double* d; int64_t cnt; const int64_t* dims; int nd;
+  bfmmm_result_get(r, "value", &d, &cnt, &dims, &nd);
+  SEXP out = PROTECT(Rf_allocVector(REALSXP, cnt));
+  memcpy(REAL(out), d, sizeof(double) * (size_t)cnt);
+  bfmmm_result_free(r);
+  UNPROTECT(1);
+  return out;
+}
+
 // ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
 SEXP _BayesFMMM_ReadVec(SEXP file) { return read_plain(file, true); }
 SEXP _BayesFMMM_ReadMat(SEXP file) { return read_plain(file, false); }
@@ -444,6 +496,10 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_BHDFMMM_Nu_Z_multiple_try", (DL_FUNC)&_BayesFMMM_BHDFMMM_Nu_Z_multiple_try, 28},
     {"_BayesFMMM_BHDFMMM_Theta_est", (DL_FUNC)&_BayesFMMM_BHDFMMM_Theta_est, 32},
     {"_BayesFMMM_BHDFMMM_warm_start", (DL_FUNC)&_BayesFMMM_BHDFMMM_warm_start, 38},
+    {"_BayesFMMM_FDIC", (DL_FUNC)&_BayesFMMM_FDIC, 10},
+    {"_BayesFMMM_FAIC", (DL_FUNC)&_BayesFMMM_FAIC, 10},
+    {"_BayesFMMM_FBIC", (DL_FUNC)&_BayesFMMM_FBIC, 10},
+    {"_BayesFMMM_FLLik", (DL_FUNC)&_BayesFMMM_FLLik, 9},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
