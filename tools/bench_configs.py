@@ -4,7 +4,7 @@ BFMMM_MTT_warm_startMV, BFMMM.h:2597-2650) and configs[4] (BFMMM_Nu_Z_multiple_t
 the reduced Nu_Z sweep -- Z, pi, alpha_3, nu, tau, sigma^2, loglik; Phi = chi = 0; BFMMM.h:1073-1113 -- on the config-2
 data, all on ONE GPU here) on one MI355X.  Not the bench line (bench.py measures configs[1]).
 
-  python tools/bench_configs.py --config 4|5 [--steps N] [--no-graph]
+  python tools/bench_configs.py --config 4|5|6 [--steps N] [--no-graph]      (6: the high-dimensional model at scale)
 """
 import argparse
 import json
@@ -114,6 +114,43 @@ def cpu_chains(w, iters):
             "sample": f"{iters} Nu_Z sweeps per chain of the reference-structure C restatement, gcc -O2"}
 
 
+def config_hd(args):
+    """High-dimensional functional model at scale (not a BASELINE config; the shape of the package's HD example --
+    12 x 12 grid, quadratic splines, 6 x 6 = 36 tensor basis functions, band half-width 14 -- with n = 4096 surfaces,
+    K = 3, M = 4): the wide-band kernel set (BW = 31 instantiations, dense factorisation, general sweep)."""
+    import bayesfmmm_amd as bf
+    from bayesfmmm_amd import api
+    S = bf.sampler
+    rng = np.random.default_rng(6)
+    n, K, M, degs = 4096, 3, 4, [2, 2]
+    iks = [[250.0, 500.0, 750.0]] * 2
+    bks = [[0.0, 990.0]] * 2
+    g = np.arange(12) * 90.0
+    tt = np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)
+    B1 = np.ascontiguousarray(api.TensorBSpline(tt, degs, bks, iks))
+    P = B1.shape[1]
+    nu = rng.standard_normal((K, P)) * 2
+    Phi = np.stack([(M - m) / M * 0.5 * rng.standard_normal((K, P)) for m in range(M)], axis=2)
+    chi = rng.standard_normal((n, M))
+    Z = rng.dirichlet(np.ones(K), size=n)
+    coef = Z @ nu + np.einsum("ik,im,kpm->ip", Z, chi, Phi)
+    Y = [B1 @ coef[i] + 0.1 * rng.standard_normal(len(tt)) for i in range(n)]
+    T = args.steps + args.warmup
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=2, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, Y, basis=[B1] * n, band=2 * 6 + 2, penalty=api.GetP(degs, [3, 3]), penalty_band=6)
+    smp.set_state(nu=nu, Phi=Phi, chi=chi, Z=Z, pi=np.full(K, 1.0 / K), alpha_3=[10.0], delta=np.ones((K, M)),
+                  A=np.ones((K, 2)), gamma=np.ones((K, P, M)), tau=np.ones(K), sigma_sq=[0.01])
+    if args.no_graph:
+        smp.set_profile(True)
+    smp.run(S.SWEEP_WARM, args.warmup, seed=2)
+    t0 = time.perf_counter()
+    smp.run(S.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=2)
+    dt = (time.perf_counter() - t0) / args.steps
+    return {"workload": f"HD functional model: n={n}, 144 points per surface, P={P} (6x6 tensor basis, band 14), K={K}, M={M}",
+            "steps": args.steps, "ms_per_sweep": dt * 1e3, "iterations_per_s": 1.0 / dt,
+            "sigma_sq_last": float(smp.get_chain("sigma_sq")[T - 1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, required=True)
@@ -122,7 +159,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="config 5: also time the CPU restatement, this many sweeps per chain")
     a = ap.parse_args()
-    print(json.dumps(config4(a) if a.config == 4 else config5(a)))
+    print(json.dumps(config4(a) if a.config == 4 else config_hd(a) if a.config == 6 else config5(a)))
 
 
 if __name__ == "__main__":
