@@ -74,7 +74,7 @@ class PostInput(C.Structure):
     _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("P", C.c_int32), ("M", C.c_int32), ("D", C.c_int32),
                 ("offsets", c_int64_p), ("y", c_double_p), ("B", c_double_p), ("X", c_double_p), ("T", C.c_int32),
                 ("nu", c_double_p), ("Phi", c_double_p), ("Z", c_double_p), ("chi", c_double_p), ("sigma", c_double_p),
-                ("eta", c_double_p), ("xi", c_double_p), ("device", C.c_int32)]
+                ("eta", c_double_p), ("xi", c_double_p), ("device", C.c_int32), ("identity_basis", C.c_int32)]
 
 
 class PostArgs(C.Structure):
@@ -82,12 +82,17 @@ class PostArgs(C.Structure):
     _fields_ = [("dir", C.c_char_p), ("n_files", C.c_int32), ("basis_degree", C.c_int32), ("n_internal_knots", C.c_int32),
                 ("boundary_knots", c_double_p), ("internal_knots", c_double_p), ("n_funct", C.c_int32),
                 ("t", c_double_p), ("y", c_double_p), ("offsets", c_int64_p), ("burnin_prop", C.c_double),
-                ("X", c_double_p), ("D", C.c_int32), ("cov_adj", C.c_int32), ("device", C.c_int32)]
+                ("X", c_double_p), ("D", C.c_int32), ("cov_adj", C.c_int32), ("device", C.c_int32), ("P", C.c_int32)]
 
 
 POST_SYMBOLS = {
     "bfmmm_post_pointwise": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_post_pointwise_joint": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
     "bfmmm_post_last_kernel_ms": (C.c_double, []),
+    "bfmmm_MVLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_MVDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
+    "bfmmm_MVAIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
+    "bfmmm_MVBIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
     "bfmmm_post_defaults": (None, [C.POINTER(PostArgs)]),
     "bfmmm_FLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_FDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
@@ -607,3 +612,56 @@ def FAIC(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, bu
 def FBIC(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop=0.1, X=None, cov_adj=False):
     """src/PostProcessing.cpp:4458."""
     return _post_scalar("bfmmm_FBIC", dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)
+
+
+class _PostArgsMV:
+    def __init__(self, dir, n_files, Y, burnin_prop, X, cov_adj, device=0):
+        lib = _lib_entry()
+        self.a = PostArgs()
+        lib.bfmmm_post_defaults(C.byref(self.a))
+        self.Y = np.asfortranarray(Y, dtype=np.float64)
+        self.dir = str(dir).encode()
+        a = self.a
+        a.dir, a.n_files, a.n_funct, a.P = self.dir, n_files, self.Y.shape[0], self.Y.shape[1]
+        a.y = self.Y.ctypes.data_as(c_double_p)
+        if burnin_prop is not None:
+            a.burnin_prop = burnin_prop
+        if X is not None:
+            self.X = np.asfortranarray(X, dtype=np.float64)
+            a.X, a.D = self.X.ctypes.data_as(c_double_p), self.X.shape[1]
+        a.cov_adj, a.device = int(bool(cov_adj)), device
+
+
+def MVLLik(dir, n_files, Y, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:6099."""
+    lib = _lib_entry()
+    args = _PostArgsMV(dir, n_files, Y, None, X, cov_adj)
+    res = C.c_void_p()
+    _check(lib.bfmmm_MVLLik(C.byref(args.a), C.byref(res)))
+    try:
+        return _result_to_dict(lib, res, None, 0)["value"]
+    finally:
+        lib.bfmmm_result_free(res)
+
+
+def _post_scalar_mv(name, dir, n_files, Y, burnin_prop, X, cov_adj):
+    lib = _lib_entry()
+    args = _PostArgsMV(dir, n_files, Y, burnin_prop, X, cov_adj)
+    out = C.c_double()
+    _check(getattr(lib, name)(C.byref(args.a), C.cast(C.byref(out), c_double_p)))
+    return out.value
+
+
+def MVDIC(dir, n_files, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:5789."""
+    return _post_scalar_mv("bfmmm_MVDIC", dir, n_files, Y, burnin_prop, X, cov_adj)
+
+
+def MVAIC(dir, n_files, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:5116."""
+    return _post_scalar_mv("bfmmm_MVAIC", dir, n_files, Y, burnin_prop, X, cov_adj)
+
+
+def MVBIC(dir, n_files, Y, burnin_prop=0.1, X=None, cov_adj=False):
+    """src/PostProcessing.cpp:5452."""
+    return _post_scalar_mv("bfmmm_MVBIC", dir, n_files, Y, burnin_prop, X, cov_adj)

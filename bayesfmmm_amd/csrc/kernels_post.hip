@@ -190,8 +190,13 @@ __global__ __launch_bounds__(256, 3) void k_post_pointwise(PostDev a) {
 }
 
 // llik[t] = sum_i llpart[i][t];  mean_pdf / mean_fit[obs] = sum_ch part[ch][obs] / kept
-__global__ __launch_bounds__(256) void k_post_reduce(PostDev a, int NCH, double* llik, double* mean_pdf, double* mean_fit) {
+__global__ __launch_bounds__(256) void k_post_reduce(PostDev a, int NCH, double* llik, double* mean_pdf, double* mean_fit, double* joint) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (joint && e < a.n) {       // mean over the kept draws of the curve's joint density (calcDIC2MV, CalculateLikelihood.h:172-194)
+    double s = 0.0;
+    for (int t = a.first_kept; t < a.T; ++t) s += exp(a.llpart[(size_t)e * a.T + t]);
+    joint[e] = s / (double)(a.T - a.first_kept);
+  }
   if (e < a.T) {
     double s = 0.0;
     for (int i = 0; i < a.n; ++i) s += a.llpart[(size_t)i * a.T + e];
@@ -224,8 +229,8 @@ struct DevBufs {
 
 }  // namespace
 
-extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit) {
-  if (!in || !in->offsets || !in->y || !in->B || !in->nu || !in->Phi || !in->Z || !in->chi || !in->sigma)
+static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit, double* mean_joint) {
+  if (!in || !in->offsets || !in->y || (!in->B && !in->identity_basis) || !in->nu || !in->Phi || !in->Z || !in->chi || !in->sigma)
     return bfmmm_io_fail("bfmmm_post_pointwise: null argument");
   const int n = in->n, K = in->K, P = in->P, M = in->M, D = in->X ? in->D : 0, T = in->T;
   if (n < 1 || K < 1 || P < 1 || M < 0 || T < 1 || first_kept < 0 || first_kept >= T)
@@ -266,7 +271,13 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   // basis rows as windows of their non-zero columns (a B-spline row has degree + 1 of them): W = the widest window
   int W = 1;
   std::vector<int> first((size_t)n_obs, 0);
-  for (long long e = 0; e < n_obs; ++e) {
+  if (in->identity_basis) {
+    for (int i = 0; i < n; ++i) {
+      if (in->offsets[i + 1] - in->offsets[i] != P) return bfmmm_io_fail("bfmmm_post_pointwise: identity basis needs P observations per row");
+      for (int j = 0; j < P; ++j) first[(size_t)in->offsets[i] + j] = j;
+    }
+  }
+  for (long long e = 0; e < n_obs && !in->identity_basis; ++e) {
     int f = -1, l = -1;
     for (int p = 0; p < P; ++p)
       if (in->B[(size_t)e * P + p] != 0.0) { if (f < 0) f = p; l = p; }
@@ -277,7 +288,7 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   for (long long e = 0; e < n_obs; ++e) {
     const int st = std::min(first[(size_t)e], P - W);
     first[(size_t)e] = st;
-    for (int w = 0; w < W; ++w) Bc[(size_t)e * W + w] = in->B[(size_t)e * P + st + w];
+    for (int w = 0; w < W; ++w) Bc[(size_t)e * W + w] = in->identity_basis ? 1.0 : in->B[(size_t)e * P + st + w];
   }
   // chunks of draws: enough workgroups for the 256 CUs, tiles stay whole
   int tchunk = T;
@@ -289,14 +300,14 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   a.W = W; a.need_pdf = mean_pdf ? 1 : 0;
   a.n = n; a.K = K; a.P = P; a.M = M; a.D = D; a.T = T; a.first_kept = first_kept; a.tchunk = tchunk; a.n_obs = n_obs;
   std::vector<long long> off(in->offsets, in->offsets + n + 1);
-  double *d_ll, *d_pdf, *d_fit;
+  double *d_ll, *d_pdf, *d_fit, *d_joint;
   bool ok = db.put((long long**)&a.off, off.data(), off.size()) && db.put((double**)&a.y, in->y, (size_t)n_obs) &&
             db.put((double**)&a.Bc, Bc.data(), Bc.size()) && db.put((int**)&a.bstart, first.data(), first.size()) && db.put((double**)&a.theta, theta.data(), theta.size()) &&
             db.put((double**)&a.Z, in->Z, (size_t)n * K * T) && db.put((double**)&a.chi, in->chi, (size_t)n * M * T) &&
             db.put((double**)&a.sigma, in->sigma, (size_t)T) && db.put(&a.llpart, (const double*)nullptr, (size_t)n * T) &&
             db.put(&a.pdf_part, (const double*)nullptr, (size_t)NCH * n_obs) && db.put(&a.fit_part, (const double*)nullptr, (size_t)NCH * n_obs) &&
             db.put(&d_ll, (const double*)nullptr, (size_t)T) && db.put(&d_pdf, (const double*)nullptr, (size_t)n_obs) &&
-            db.put(&d_fit, (const double*)nullptr, (size_t)n_obs);
+            db.put(&d_fit, (const double*)nullptr, (size_t)n_obs) && db.put(&d_joint, (const double*)nullptr, (size_t)n);
   if (ok && D > 0) ok = db.put((double**)&a.X, in->X, (size_t)n * D) && db.put((double**)&a.thetaX, thetaX.data(), thetaX.size());
   if (!ok) { (void)hipGetLastError(); return bfmmm_io_fail("bfmmm_post_pointwise: device allocation or copy failed"); }
   const size_t lds = ((size_t)GMAX * (P | 1) + (size_t)GMAX * WMAX + 2048 + 64 + BL_MAX + 8) * sizeof(double);
@@ -305,8 +316,8 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, 0);
   hipLaunchKernelGGL(k_post_pointwise, dim3(n, NCH), dim3(256), lds, 0, a);
-  const long long tot = std::max<long long>(T, n_obs);
-  hipLaunchKernelGGL(k_post_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, a, NCH, d_ll, d_pdf, d_fit);
+  const long long tot = std::max<long long>(std::max<long long>(T, n_obs), n);
+  hipLaunchKernelGGL(k_post_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, a, NCH, d_ll, d_pdf, d_fit, mean_joint ? d_joint : (double*)nullptr);
   (void)hipEventRecord(e1, 0);
   const bool ran = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
   if (ran) (void)hipEventElapsedTime(&g_last_kernel_ms, e0, e1);
@@ -314,9 +325,18 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
   if (!ran) return bfmmm_io_fail("bfmmm_post_pointwise: kernel launch failed");
   if ((llik && hipMemcpy(llik, d_ll, sizeof(double) * T, hipMemcpyDeviceToHost) != hipSuccess) ||
       (mean_pdf && hipMemcpy(mean_pdf, d_pdf, sizeof(double) * n_obs, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (mean_fit && hipMemcpy(mean_fit, d_fit, sizeof(double) * n_obs, hipMemcpyDeviceToHost) != hipSuccess))
+      (mean_fit && hipMemcpy(mean_fit, d_fit, sizeof(double) * n_obs, hipMemcpyDeviceToHost) != hipSuccess) ||
+      (mean_joint && hipMemcpy(mean_joint, d_joint, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess))
     return bfmmm_io_fail("bfmmm_post_pointwise: copy back failed");
   return 0;
+}
+
+extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit) {
+  return post_impl(in, first_kept, llik, mean_pdf, mean_fit, nullptr);
+}
+
+extern "C" int bfmmm_post_pointwise_joint(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_joint_pdf, double* mean_fit) {
+  return post_impl(in, first_kept, llik, nullptr, mean_fit, mean_joint_pdf);
 }
 
 // device time of the last bfmmm_post_pointwise call's two kernels (HIP events on the launch stream), for measurement

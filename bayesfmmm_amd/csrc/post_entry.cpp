@@ -32,7 +32,13 @@ int load_cat(const std::string& dir, const char* name, int n_files, std::vector<
 }
 
 // argument checks in the reference's order and wording (PostProcessing.cpp:3673-3700, :4902-4915)
-int check(const bfmmm_post_args* a, bool with_burnin) {
+int check(const bfmmm_post_args* a, bool with_burnin, bool mv = false) {
+  if (mv) {
+    if (!a || !a->dir || !a->y || a->P < 1 || a->n_funct < 1) return bfmmm_io_fail("null argument");
+    if (with_burnin && (a->burnin_prop < 0 || a->burnin_prop >= 1)) return bfmmm_io_fail("'burnin_prop' must be between 0 and 1");
+    if (a->n_files <= 0) return bfmmm_io_fail("'n_files' must be greater than 0");
+    return 0;
+  }
   if (!a || !a->dir || !a->t || !a->y || !a->offsets || !a->boundary_knots || (a->n_internal_knots > 0 && !a->internal_knots))
     return bfmmm_io_fail("null argument");
   if (a->basis_degree < 1) return bfmmm_io_fail("'basis_degree' must be an integer greater than or equal to 1");
@@ -47,7 +53,7 @@ int check(const bfmmm_post_args* a, bool with_burnin) {
   return 0;
 }
 
-int load_draws(const bfmmm_post_args* a, Draws& dr) {
+int load_draws(const bfmmm_post_args* a, Draws& dr, bool mv = false) {
   const std::string dir = a->dir;
   int64_t d[3], nr, nc;
   if (load_cat(dir, "Nu", a->n_files, dr.nu, d)) return 1;
@@ -84,6 +90,10 @@ int load_draws(const bfmmm_post_args* a, Draws& dr) {
         for (int l = 0; l < per_file; ++l)
           for (int k = 0; k < dr.K; ++k) { const auto& c = objs[(size_t)l + (size_t)nr * k]; dr.xi.insert(dr.xi.end(), c.begin(), c.end()); }
       }
+  }
+  if (mv) {
+    if (dr.P != a->P) return bfmmm_io_fail("the saved draws do not match the number of columns of 'Y'");
+    return 0;
   }
   // basis rows at the observed time points (splines2::BSpline(time, internal_knots, degree, boundary_knots).basis(true))
   const int64_t n_obs = a->offsets[a->n_funct];
@@ -201,5 +211,113 @@ extern "C" int bfmmm_FBIC(const bfmmm_post_args* a, double* out) {
   if (loglik_at_means(a, dr, &ll)) return 1;
   const double tilde_N = (double)a->offsets[a->n_funct];      // PostProcessing.cpp:4591-4594
   *out = 2 * ll - std::log(tilde_N) * n_params(dr, a->X != nullptr, a->cov_adj != 0);
+  return 0;
+}
+
+// ---- multivariate model: the same pass with the identity basis (a row's P coordinates are its observations) ----------
+namespace {
+
+struct MVRun {
+  std::vector<int64_t> off;
+  std::vector<double> y;         // row-major: the observations of row i are contiguous
+  std::vector<double> ll, joint, fit;
+};
+
+int run_mv(const bfmmm_post_args* a, const Draws& dr, int first_kept, bool want_joint, bool want_fit, MVRun& m) {
+  const int n = a->n_funct, P = a->P;
+  m.off.resize((size_t)n + 1);
+  for (int i = 0; i <= n; ++i) m.off[(size_t)i] = (int64_t)i * P;
+  m.y.resize((size_t)n * P);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < P; ++j) m.y[(size_t)i * P + j] = a->y[(size_t)i + (size_t)n * j];
+  bfmmm_post_input in{};
+  in.n = n; in.K = dr.K; in.P = P; in.M = dr.M; in.D = dr.D;
+  in.offsets = m.off.data(); in.y = m.y.data(); in.B = nullptr; in.identity_basis = 1; in.X = a->X;
+  in.T = dr.T; in.nu = dr.nu.data(); in.Phi = dr.Phi.data(); in.Z = dr.Z.data(); in.chi = dr.chi.data(); in.sigma = dr.sigma.data();
+  in.eta = dr.eta.empty() ? nullptr : dr.eta.data();
+  in.xi = dr.xi.empty() ? nullptr : dr.xi.data();
+  in.device = a->device;
+  m.ll.assign((size_t)dr.T, 0.0);
+  if (want_joint) m.joint.assign((size_t)n, 0.0);
+  if (want_fit) m.fit.assign((size_t)n * P, 0.0);
+  if (bfmmm_post_pointwise_joint(&in, first_kept, m.ll.data(), want_joint ? m.joint.data() : nullptr, want_fit ? m.fit.data() : nullptr)) return 1;
+  // calcLikelihoodMV charges (P / 2) log(2 pi sigma) per row with INTEGER division (CalculateLikelihood.h:155): for odd P
+  // the reference's value lacks half a log(2 pi sigma) per row
+  if (P % 2 == 1)
+    for (int t = 0; t < dr.T; ++t) m.ll[(size_t)t] += n * 0.5 * std::log(2 * 3.14159265358979323846 * dr.sigma[(size_t)t]);
+  return 0;
+}
+
+int mv_loglik_at_means(const bfmmm_post_args* a, const Draws& dr, double* out) {
+  const int kept = (int)std::round((1 - a->burnin_prop) * dr.T);
+  if (kept < 1) return bfmmm_io_fail("'burnin_prop' leaves no draws");
+  MVRun m;
+  if (run_mv(a, dr, dr.T - kept, false, true, m)) return 1;
+  double ms = 0.0;
+  for (double s : dr.sigma) ms += s;
+  ms /= (double)dr.sigma.size();
+  const double sd = std::sqrt(ms);
+  double ll = 0.0;
+  for (size_t e = 0; e < m.fit.size(); ++e) {
+    const double z = (m.y[e] - m.fit[e]) / sd;
+    ll += -(0.91893853320467274178 + 0.5 * z * z + std::log(sd));
+  }
+  *out = ll;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bfmmm_MVLLik(const bfmmm_post_args* a, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (check(a, false, true)) return 1;
+  Draws dr;
+  if (load_draws(a, dr, true)) return 1;
+  MVRun m;
+  if (run_mv(a, dr, 0, false, false, m)) return 1;
+  bfmmm_result* r = bfmmm_result_create();
+  const int64_t T = dr.T;
+  bfmmm_result_set(r, "value", m.ll.data(), T, &T, 1);
+  *out = r;
+  return 0;
+}
+
+extern "C" int bfmmm_MVDIC(const bfmmm_post_args* a, double* out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (check(a, true, true)) return 1;
+  Draws dr;
+  if (load_draws(a, dr, true)) return 1;
+  const int kept = (int)std::round((1 - a->burnin_prop) * dr.T);
+  if (kept < 1) return bfmmm_io_fail("'burnin_prop' leaves no draws");
+  MVRun m;
+  if (run_mv(a, dr, dr.T - kept, true, false, m)) return 1;
+  double expected_log_f = 0.0;                               // PostProcessing.cpp:5863-5869
+  for (int t = dr.T - kept; t < dr.T; ++t) expected_log_f += m.ll[(size_t)t];
+  expected_log_f /= kept;
+  double f_hat = 0.0;                                        // :5871-5882 (joint density of a row, calcDIC2MV)
+  for (double v : m.joint) f_hat += std::log(v);
+  *out = 2 * f_hat - 4 * expected_log_f;
+  return 0;
+}
+
+extern "C" int bfmmm_MVAIC(const bfmmm_post_args* a, double* out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (check(a, true, true)) return 1;
+  Draws dr;
+  if (load_draws(a, dr, true)) return 1;
+  double ll;
+  if (mv_loglik_at_means(a, dr, &ll)) return 1;
+  *out = 2 * n_params(dr, a->X != nullptr, a->cov_adj != 0) - 2 * ll;      // PostProcessing.cpp:5225-5227, :5421-5430
+  return 0;
+}
+
+extern "C" int bfmmm_MVBIC(const bfmmm_post_args* a, double* out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (check(a, true, true)) return 1;
+  Draws dr;
+  if (load_draws(a, dr, true)) return 1;
+  double ll;
+  if (mv_loglik_at_means(a, dr, &ll)) return 1;
+  *out = 2 * ll - std::log((double)a->n_funct) * n_params(dr, a->X != nullptr, a->cov_adj != 0);      // :5560 (log(Y.n_rows))
   return 0;
 }

@@ -5,6 +5,7 @@
  *   bfmmm_FDIC   <-  FDIC   src/PostProcessing.cpp:3660-4039  (deviance information criterion)
  *   bfmmm_FAIC   <-  FAIC   src/PostProcessing.cpp:4041-4456
  *   bfmmm_FBIC   <-  FBIC   src/PostProcessing.cpp:4458-4801
+ *   bfmmm_MVLLik / bfmmm_MVDIC / bfmmm_MVAIC / bfmmm_MVBIC  <-  MVLLik :6099, MVDIC :5789, MVAIC :5116, MVBIC :5452
  *
  * All four evaluate the fitted value of every observation under every saved draw
  *   f_ij(t) = B_ij' sum_k Z_ik(t) [ nu_k(t) + eta_k(t) x_i + sum_m chi_im(t) (phi_km(t) + xi_km(t) x_i) ]
@@ -41,10 +42,14 @@ typedef struct {
   const double* eta;               /* T cubes P x D x K, or NULL (zero) */
   const double* xi;                /* T x K cubes P x D x M, cube (t, k) at offset (t * K + k) * P * D * M, or NULL (zero) */
   int32_t device;
+  int32_t identity_basis;          /* multivariate model: B may be NULL, every row has P observations and observation j's basis row is e_j */
 } bfmmm_post_input;
 
 /* llik: T; mean_pdf, mean_fit: offsets[n] (means over the draws t >= first_kept); any of the three may be NULL */
 int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit);
+/* the same pass with, instead of the per-observation mean density, the mean over the kept draws of each curve's JOINT
+ * density prod_j dnorm(y_ij; f_ij, sigma) (calcDIC2MV, CalculateLikelihood.h:172-194): mean_joint_pdf has n entries */
+int bfmmm_post_pointwise_joint(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_joint_pdf, double* mean_fit);
 /* device time (ms, HIP events) of the kernels of the last bfmmm_post_pointwise call of this process: measurement aid */
 double bfmmm_post_last_kernel_ms(void);
 
@@ -63,6 +68,7 @@ typedef struct {
   int32_t D;
   int32_t cov_adj;
   int32_t device;
+  int32_t P;                       /* bfmmm_MV*: y is the n_funct x P data matrix, column-major; t, offsets, knots unused */
 } bfmmm_post_args;
 
 void bfmmm_post_defaults(bfmmm_post_args* a);
@@ -70,6 +76,11 @@ int bfmmm_FLLik(const bfmmm_post_args* a, bfmmm_result** out);      /* result el
 int bfmmm_FDIC(const bfmmm_post_args* a, double* out);
 int bfmmm_FAIC(const bfmmm_post_args* a, double* out);
 int bfmmm_FBIC(const bfmmm_post_args* a, double* out);
+/* multivariate model: MVLLik (src/PostProcessing.cpp:6099), MVDIC (:5789), MVAIC (:5116), MVBIC (:5452) */
+int bfmmm_MVLLik(const bfmmm_post_args* a, bfmmm_result** out);
+int bfmmm_MVDIC(const bfmmm_post_args* a, double* out);
+int bfmmm_MVAIC(const bfmmm_post_args* a, double* out);
+int bfmmm_MVBIC(const bfmmm_post_args* a, double* out);
 
 #ifdef __cplusplus
 }

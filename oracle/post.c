@@ -5,6 +5,7 @@
  *   orc_post_dic   FDIC   :3835-3853 (no covariates), :3922-3944 (covariates)
  *   orc_post_aic   FAIC   :4142-4178, :4318-4364
  *   orc_post_bic   FBIC   :4558-4600, :4738-4792
+ * and, for a multivariate data set (d->mv), MVLLik :6099, MVDIC :5789, MVAIC :5116, MVBIC :5452.
  *
  * Parity unpinned: the reference ships no expected values for these functions (its trace fixtures hold no Z / Chi
  * files); the restatement follows the reference's loops line by line and shares calcLikelihood / the fitted mean with the
@@ -30,6 +31,18 @@ double orc_post_dic(const orc_data* d, const orc_chain* c, int T, double burnin_
   for (int i = T - kept; i < T; ++i) expected_log_f = expected_log_f + orc_calcLikelihood(d, i, c);
   expected_log_f = expected_log_f / kept;
   double f_hat = 0;
+  if (d->mv) {      /* MVDIC, PostProcessing.cpp:5871-5882: the joint density of a row (calcDIC2MV, CalculateLikelihood.h:172-194) */
+    for (int i = 0; i < d->n; ++i) {
+      double f_hat_i = 0;
+      for (int n = T - kept; n < T; ++n) {
+        double lik = 1;
+        for (int j = 0; j < orc_ni(d, i); ++j) lik = lik * dnorm(orc_yobs(d, i, j), orc_fitted(d, c, n, i, j), sqrt(c->sigma[n]), 0);
+        f_hat_i = f_hat_i + lik;
+      }
+      f_hat = f_hat + log(f_hat_i / kept);
+    }
+    return (2 * f_hat) - (4 * expected_log_f);
+  }
   for (int i = 0; i < d->n; ++i) {
     for (int j = 0; j < orc_ni(d, i); ++j) {
       double f_hat_ij = 0;
@@ -76,5 +89,6 @@ double orc_post_aic(const orc_data* d, const orc_chain* c, int T, double burnin_
 double orc_post_bic(const orc_data* d, const orc_chain* c, int T, double burnin_prop, int has_x, int cov_adj) {
   double tilde_N = 0;
   for (int i = 0; i < d->n; ++i) tilde_N = tilde_N + orc_ni(d, i);
+  if (d->mv) tilde_N = d->n;      /* MVBIC: log(Y.n_rows), PostProcessing.cpp:5560, :5717 */
   return (2 * loglik_at_means(d, c, T, burnin_prop)) - (log(tilde_N) * n_params(d, has_x, cov_adj));
 }

@@ -127,3 +127,82 @@ def test_post_many_observations_and_single_observation_curves():
     np.testing.assert_allclose(ll, O.post_llik(model, ch), rtol=1e-11)
     dic = 2 * np.sum(np.log(np.concatenate(pdf))) - 4 * ll[30:].mean()
     assert abs(dic - O.post_dic(model, ch, 1 - 271 / 301)) < 1e-9 * abs(dic)
+
+
+# ---- multivariate model: the reference's own shipped trace (inst/test-data/Multivariate_trace, MVSim_data.RDS) -------
+def _mv_trace_chain(X, cov_adj):
+    import os
+    from bayesfmmm_amd import api
+    from rds_reader import read_rds
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    dirn = os.path.join(gold, "Multivariate_trace") + "/"
+    Y = np.asarray(read_rds(os.path.join(gold, "MVSim_data.RDS")), dtype=np.float64)
+    n, P = Y.shape
+    nu, Z, chi = api.ReadCube(dirn + "Nu0.txt"), api.ReadCube(dirn + "Z0.txt"), api.ReadCube(dirn + "Chi0.txt")
+    sigma = api.ReadVec(dirn + "Sigma0.txt")
+    K, T, M = nu.shape[0], nu.shape[2], chi.shape[1]
+    model = O.Model([Y[i] for i in range(n)], [np.eye(P)] * n, K, M, X=X, mv=True)
+    ch = O.Chain(model, T)
+    ch.nu[:], ch.Z[:], ch.chi[:], ch.sigma[:] = nu, Z, chi, sigma
+    phi = api.ReadFieldCube(dirn + "Phi0.txt")
+    for l in range(T):
+        ch.Phi[..., l] = phi[l, 0]
+    if X is not None:
+        eta = api.ReadFieldCube(dirn + "Eta0.txt")
+        xi = api.ReadFieldCube(dirn + "Xi0.txt")
+        for l in range(T):
+            ch.eta[..., l] = eta[l, 0]
+            if cov_adj:
+                for k in range(K):
+                    ch.xi[..., k, l] = xi[l, k]
+    return dirn, Y, model, ch
+
+
+@pytest.mark.parametrize("with_x,cov_adj", [(False, False), (True, False), (True, True)])
+def test_mv_criteria_on_the_reference_trace(with_x, cov_adj):
+    """The documented examples of MVLLik / MVDIC / MVAIC / MVBIC (src/PostProcessing.cpp:5116, :5452, :5789, :6099:
+    `dir <- .../Multivariate_trace/`, n_files = 1, Y = MVSim_data.RDS, X = matrix(rnorm(20), 20, 1)) on the trace files
+    the package ships, against the oracle's restatement on the same draws."""
+    from bayesfmmm_amd import api
+    X = np.random.default_rng(4).standard_normal((20, 1)) if with_x else None
+    dirn, Y, model, ch = _mv_trace_chain(X, cov_adj)
+    kw = dict(X=X, cov_adj=cov_adj) if with_x else {}
+    ll = api.MVLLik(dirn, 1, Y, **kw)
+    assert ll.shape == (150,)
+    np.testing.assert_allclose(ll, O.post_llik(model, ch), rtol=1e-10)
+    for burn in (0.1, 0.6):
+        dic = api.MVDIC(dirn, 1, Y, burnin_prop=burn, **kw)
+        assert abs(dic - O.post_dic(model, ch, burn)) < 1e-9 * abs(dic)
+        aic_ref, bic_ref = O.post_aic_bic(model, ch, burn, with_x, cov_adj)
+        assert abs(api.MVAIC(dirn, 1, Y, burnin_prop=burn, **kw) - aic_ref) < 1e-10 * abs(aic_ref)
+        assert abs(api.MVBIC(dirn, 1, Y, burnin_prop=burn, **kw) - bic_ref) < 1e-10 * abs(bic_ref)
+
+
+def test_mv_odd_dimension_integer_division_quirk():
+    """calcLikelihoodMV charges (P / 2) log(2 pi sigma) with integer division (CalculateLikelihood.h:155): odd P."""
+    from bayesfmmm_amd import api
+    rng = np.random.default_rng(8)
+    n, P, K, M, T = 13, 7, 2, 2, 40
+    Y = rng.standard_normal((n, P))
+    model = O.Model([Y[i] for i in range(n)], [np.eye(P)] * n, K, M, mv=True)
+    ch = O.Chain(model, T)
+    ch.nu[:] = rng.standard_normal((K, P, T))
+    ch.Phi[:] = 0.3 * rng.standard_normal((K, P, M, T))
+    ch.chi[:] = rng.standard_normal((n, M, T))
+    ch.Z[:] = rng.dirichlet(np.ones(K), size=(n, T)).transpose(0, 2, 1)
+    ch.sigma[:] = rng.gamma(3.0, 0.3, size=T)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        dirn = d + "/"
+        api.write_arma_ascii(dirn + "Nu0.txt", ch.nu)
+        api.write_arma_ascii(dirn + "Z0.txt", ch.Z)
+        api.write_arma_ascii(dirn + "Chi0.txt", ch.chi)
+        api.write_arma_ascii(dirn + "Sigma0.txt", ch.sigma.reshape(-1, 1))
+        fld = np.empty((T, 1), dtype=object)
+        for l in range(T):
+            fld[l, 0] = np.asfortranarray(ch.Phi[..., l])
+        api.write_arma_field(dirn + "Phi0.txt", fld)
+        ll = api.MVLLik(dirn, 1, Y)
+        np.testing.assert_allclose(ll, O.post_llik(model, ch), rtol=1e-11)
+        dic = api.MVDIC(dirn, 1, Y, burnin_prop=0.25)
+        assert abs(dic - O.post_dic(model, ch, 0.25)) < 1e-9 * abs(dic)
