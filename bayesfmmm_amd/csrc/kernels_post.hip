@@ -13,7 +13,9 @@
 // and leaves per-observation sums over its chunk in pdf_part / fit_part.  k_post_reduce sums curves (per draw) and chunks
 // (per observation) in a fixed order: results do not depend on the launch geometry's scheduling.
 //
-// Bound: HBM.  Algorithmic bytes per draw = 8 [ n (K + M) + K (M + 1) P (1 + D) + 1 ] read + 8 n written (llpart); the
+// Algorithmic bytes per draw = 8 [ n (K + M) + K (M + 1) P (1 + D) + 1 ] read + 8 n written (llpart) -- but the pass is not
+// HBM-bound as built: the draw's parameter rows are re-read from L2 by every curve's workgroup and each (observation, kept
+// draw) costs one fp64 exp (DESIGN.md 7b has the measurement and the next step).  The
 // non-zero windows of a curve's basis rows (n_i x W, W = degree + 1 for B-splines) are staged in LDS once per workgroup;
 // the next tile's Z / chi / sigma^2 are requested while the current tile is evaluated.  Draw parameters arrive transposed to the
 // sampler's row layout theta[t][r][p] (host, one pass) so that phase 1 reads are contiguous in p.

@@ -4,7 +4,7 @@ BFMMM_MTT_warm_startMV, BFMMM.h:2597-2650) and configs[4] (BFMMM_Nu_Z_multiple_t
 the reduced Nu_Z sweep -- Z, pi, alpha_3, nu, tau, sigma^2, loglik; Phi = chi = 0; BFMMM.h:1073-1113 -- on the config-2
 data, all on ONE GPU here) on one MI355X.  Not the bench line (bench.py measures configs[1]).
 
-  python tools/bench_configs.py --config 4|5|6 [--steps N] [--no-graph]      (6: the high-dimensional model at scale)
+  python tests/perf/bench_configs.py --config 4|5|6 [--steps N] [--no-graph]      (6: the high-dimensional model at scale)
 """
 import argparse
 import json
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

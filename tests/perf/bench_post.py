@@ -3,7 +3,7 @@
 the shape of BASELINE.json configs[1] (n_funct = 4096, n_i = 100, K = 3, P = 30, M = 6) over --draws saved draws, and the
 oracle's restatement (oracle/post.c, one host core) on a bounded sample of the draws.  Not the bench line.
 
-  python tools/bench_post.py [--draws 500] [--cpu-draws 2]
+  python tests/perf/bench_post.py [--draws 500] [--cpu-draws 2]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
