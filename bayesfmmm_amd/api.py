@@ -88,6 +88,8 @@ class PostArgs(C.Structure):
 POST_SYMBOLS = {
     "bfmmm_post_pointwise": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
     "bfmmm_post_pointwise_joint": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_post_cpo": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p]),
+    "bfmmm_ConditionalPredictiveOrdinates": (C.c_int, [C.POINTER(PostArgs), C.c_int32, C.POINTER(C.c_void_p)]),
     "bfmmm_post_last_kernel_ms": (C.c_double, []),
     "bfmmm_MVLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_MVDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
@@ -665,3 +667,16 @@ def MVAIC(dir, n_files, Y, burnin_prop=0.1, X=None, cov_adj=False):
 def MVBIC(dir, n_files, Y, burnin_prop=0.1, X=None, cov_adj=False):
     """src/PostProcessing.cpp:5452."""
     return _post_scalar_mv("bfmmm_MVBIC", dir, n_files, Y, burnin_prop, X, cov_adj)
+
+
+def ConditionalPredictiveOrdinates(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop=0.1, X=None,
+                                   cov_adj=False, log_CPO=True):
+    """src/PostProcessing.cpp:6339: (log) conditional predictive ordinate of every curve."""
+    lib = _lib_entry()
+    args = _PostArgs(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj)
+    res = C.c_void_p()
+    _check(lib.bfmmm_ConditionalPredictiveOrdinates(C.byref(args.a), int(bool(log_CPO)), C.byref(res)))
+    try:
+        return _result_to_dict(lib, res, None, 0)["value"]
+    finally:
+        lib.bfmmm_result_free(res)

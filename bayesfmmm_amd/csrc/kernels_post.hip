@@ -36,6 +36,7 @@ constexpr int GMAX = 32;         // draws per tile
 constexpr int BL_MAX = 1536;     // doubles of basis-row windows staged per curve
 constexpr int WMAX = 20;         // K + M + 2 <= 20
 constexpr int NG = 8;            // draws per thread in the fitted-value phase
+constexpr int KMAXP = 16;         // K <= 16 in the CPO tile tables
 constexpr int NWR = 3;           // prefetch registers: GMAX (K + M + 1) <= 768 items per tile
 
 struct PostDev {
@@ -213,6 +214,152 @@ __global__ __launch_bounds__(256) void k_post_reduce(PostDev a, int NCH, double*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Conditional predictive ordinates (calcLikelihoodCPO, CalculateLikelihood.h:344-389): per curve and kept draw the
+// MARGINAL log-density of y_i (scores chi integrated out),
+//   y_i ~ N( B_i c,  sigma^2 I + U U' ),   c = sum_k Z_ik (nu_k + eta_k x_i),   U = B_i [v_1 .. v_M],  v_m = sum_k Z_ik (phi_km + xi_km x_i)
+// The reference forms the n_i x n_i covariance and calls log_det_sympd / inv_sympd; the rank-M structure gives the same
+// numbers from an M x M system:  log det = (n_i - M) log sigma^2 + log det(sigma^2 I_M + U'U),
+//   r' Cov^-1 r = ( r'r - (U'r)' (sigma^2 I_M + U'U)^-1 (U'r) ) / sigma^2.
+// One workgroup per curve; tiles of G draws: (1) c, v_m -> LDS; (2) thread (j, draw): residual and the row of U -> LDS;
+// (3) thread (draw, sum q, segment): the sums r'r, U'r, U'U over a quarter of the observations, fixed order; (4) thread
+// (draw): M x M Cholesky, the draw's log-density -> cpo_ll[i][t].  k_post_cpo_reduce then takes the harmonic mean in the
+// reference's stabilised form (:381-386).  No Z_ik == 0 skip here: the reference's loop has none.
+constexpr int CPO_MMAX = 8;
+constexpr int CPO_TILE = 3072;     // doubles of the U tile (draws x (M + 1) x padded observations)
+constexpr int CPO_VT = 1024;       // doubles of the coefficient tile (draws x (M + 1) x P)
+constexpr int CPO_NQ = CPO_MMAX * (CPO_MMAX + 1) / 2 + CPO_MMAX + 1;
+
+__global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const long long o = a.off[i];
+  const int ni = (int)(a.off[i + 1] - o);
+  const int P = a.P, K = a.K, M = a.M, D = a.D, R = K * (M + 1), n = a.n, T = a.T, W = a.W;
+  const int M1 = M + 1, NQ = M * (M + 1) / 2 + M + 1;
+  const int NIP = (ni + 3) & ~3;                       // observations padded to four segments
+  const int CS = P | 1, WS = W | 1;
+  int G = min(min(CPO_TILE / (M1 * max(NIP, 1)), CPO_VT / (M1 * CS)), 16);
+  G = max(G, 1);
+  const bool staged = (size_t)ni * WS <= BL_MAX;
+  double* sV = sm;                          // G x M1 x CS
+  double* sU = sV + CPO_VT;                 // G x M1 x NIP  (row 0: the residual)
+  double* sP = sU + CPO_TILE;               // G x NQ x 4 segment sums
+  double* sW = sP + 16 * CPO_NQ * 4;        // G x (K + 1): Z_i.(t), sigma^2(t)
+  double* sB = sW + 16 * (KMAXP + 1);       // BL_MAX
+  double* sX = sB + BL_MAX;                 // 8
+  if (staged)
+    for (int e = tid; e < ni * W; e += 256) { const int j = e / W, w = e - j * W; sB[j * WS + w] = a.Bc[(size_t)(o + j) * W + w]; }
+  if (tid < D) sX[tid] = a.X[i + (size_t)n * tid];
+  for (int tb = a.first_kept; tb < T; tb += G) {
+    const int gn = min(G, T - tb);
+    __syncthreads();
+    for (int e = tid; e < gn * (K + 1); e += 256) {
+      const int g = e / (K + 1), w = e - g * (K + 1), t = tb + g;
+      sW[g * (KMAXP + 1) + w] = (w < K) ? a.Z[i + (size_t)n * (w + (size_t)K * t)] : a.sigma[t];
+    }
+    __syncthreads();
+    // (1) c and v_m of every draw of the tile
+    for (int e = tid; e < gn * M1 * P; e += 256) {
+      const int g = e / (M1 * P), r2 = e - g * M1 * P, mt = r2 / P, p = r2 - mt * P, t = tb + g;
+      double v = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const int r = k * M1 + mt;
+        double x = a.theta[((size_t)t * R + r) * P + p];
+        for (int dd = 0; dd < D; ++dd) x += sX[dd] * a.thetaX[(((size_t)t * R + r) * D + dd) * P + p];
+        v += sW[g * (KMAXP + 1) + k] * x;
+      }
+      sV[(g * M1 + mt) * CS + p] = v;
+    }
+    __syncthreads();
+    // (2) residual and the row of U for every (observation, draw)
+    for (int e = tid; e < gn * NIP; e += 256) {
+      const int g = e / NIP, j = e - g * NIP;
+      if (j < ni) {
+        const double* br = staged ? sB + j * WS : a.Bc + (size_t)(o + j) * W;
+        const int st = a.bstart[o + j];
+        for (int mt = 0; mt < M1; ++mt) {
+          const double* cg = sV + (g * M1 + mt) * CS + st;
+          double f = 0.0;
+          for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+          sU[(g * M1 + mt) * NIP + j] = (mt == 0) ? a.y[o + j] - f : f;
+        }
+      } else {
+        for (int mt = 0; mt < M1; ++mt) sU[(g * M1 + mt) * NIP + j] = 0.0;
+      }
+    }
+    __syncthreads();
+    // (3) r'r (q = 0), U'r (q = 1 .. M), U'U (upper triangle) over four segments of the observations
+    for (int e = tid; e < gn * NQ * 4; e += 256) {
+      const int g = e / (NQ * 4), r2 = e - g * NQ * 4, q = r2 >> 2, seg = r2 & 3;
+      int ra = 0, rb = 0;
+      if (q >= 1 && q <= M) ra = q;
+      else if (q > M) { int m1 = 0, rem = q - M - 1; while (rem >= M - m1) { rem -= M - m1; ++m1; } ra = m1 + 1; rb = m1 + 1 + rem; }
+      const double* ua = sU + (g * M1 + ra) * NIP + seg * (NIP >> 2);
+      const double* ub = sU + (g * M1 + rb) * NIP + seg * (NIP >> 2);
+      double s_ = 0.0;
+      for (int j = 0; j < (NIP >> 2); ++j) s_ += ua[j] * ub[j];
+      sP[(g * CPO_NQ + q) * 4 + seg] = s_;
+    }
+    __syncthreads();
+    // (4) the draw's marginal log-density from the M x M system
+    if (tid < gn) {
+      const int g = tid, t = tb + g;
+      const double sig = sW[g * (KMAXP + 1) + K];
+      auto sum4 = [&](int q) { const double* p4 = sP + (g * CPO_NQ + q) * 4; return (p4[0] + p4[1]) + (p4[2] + p4[3]); };
+      double A[CPO_MMAX][CPO_MMAX], b[CPO_MMAX];
+      const double rr = sum4(0);
+      int q = M + 1;
+#pragma unroll
+      for (int m1 = 0; m1 < CPO_MMAX; ++m1) {
+        b[m1] = (m1 < M) ? sum4(1 + m1) : 0.0;
+#pragma unroll
+        for (int m2 = 0; m2 < CPO_MMAX; ++m2)
+          if (m2 >= m1) { A[m1][m2] = (m1 < M && m2 < M) ? sum4(q) + ((m1 == m2) ? sig : 0.0) : ((m1 == m2) ? 1.0 : 0.0); if (m1 < M && m2 < M) ++q; }
+      }
+      // Cholesky A = L L' (lower in A[m2][m1], m2 >= m1), forward solve L w = b: log det = 2 sum log L_mm, b' A^-1 b = w'w
+      double logdet = 0.0, ww = 0.0;
+#pragma unroll
+      for (int c = 0; c < CPO_MMAX; ++c) {
+        double dg = A[c][c];
+#pragma unroll
+        for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) dg -= A[c][k2] * A[c][k2];
+        const double l = sqrt(dg);
+        A[c][c] = l;
+        double wv = b[c];
+#pragma unroll
+        for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) wv -= A[c][k2] * b[k2];
+        wv /= l;
+        b[c] = wv;
+        if (c < M) { logdet += 2.0 * log(l); ww += wv * wv; }
+#pragma unroll
+        for (int r3 = 0; r3 < CPO_MMAX; ++r3)
+          if (r3 > c) {
+            double v = A[c][r3];                 // upper entry (c, r3) holds the symmetric value
+#pragma unroll
+            for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) v -= A[r3][k2] * A[c][k2];
+            A[r3][c] = v / l;
+          }
+      }
+      const double ld = (double)(ni - M) * log(sig) + logdet;
+      const double quad = (rr - ww) / sig;
+      cpo_ll[(size_t)i * T + t] = -(0.5 * ni) * 1.83787706640934548356 - 0.5 * ld - 0.5 * quad;
+    }
+  }
+}
+
+// CPO(i) = log(L) + min_l logl - log sum_l exp(min - logl_l) over the L kept draws (CalculateLikelihood.h:381-386)
+__global__ __launch_bounds__(256) void k_post_cpo_reduce(PostDev a, const double* cpo_ll, double* cpo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const double* row = cpo_ll + (size_t)i * a.T;
+  double mn = row[a.first_kept];
+  for (int t = a.first_kept + 1; t < a.T; ++t) mn = fmin(mn, row[t]);
+  double ph = 0.0;
+  for (int t = a.first_kept; t < a.T; ++t) ph += exp(mn - row[t]);
+  cpo[i] = log((double)(a.T - a.first_kept)) + mn - log(ph);
+}
+
 float g_last_kernel_ms = 0.f;
 
 struct DevBufs {
@@ -231,7 +378,8 @@ struct DevBufs {
 
 }  // namespace
 
-static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit, double* mean_joint) {
+static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_pdf, double* mean_fit, double* mean_joint,
+                     double* cpo = nullptr) {
   if (!in || !in->offsets || !in->y || (!in->B && !in->identity_basis) || !in->nu || !in->Phi || !in->Z || !in->chi || !in->sigma)
     return bfmmm_io_fail("bfmmm_post_pointwise: null argument");
   const int n = in->n, K = in->K, P = in->P, M = in->M, D = in->X ? in->D : 0, T = in->T;
@@ -312,6 +460,29 @@ static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* lli
             db.put(&d_fit, (const double*)nullptr, (size_t)n_obs) && db.put(&d_joint, (const double*)nullptr, (size_t)n);
   if (ok && D > 0) ok = db.put((double**)&a.X, in->X, (size_t)n * D) && db.put((double**)&a.thetaX, thetaX.data(), thetaX.size());
   if (!ok) { (void)hipGetLastError(); return bfmmm_io_fail("bfmmm_post_pointwise: device allocation or copy failed"); }
+  if (cpo) {
+    if (M < 1 || M > CPO_MMAX || K > KMAXP) return bfmmm_io_fail("bfmmm_post_cpo: 1 <= M <= 8 and K <= 16 in this build");
+    for (int i = 0; i < n; ++i)
+      if ((M + 1) * ((in->offsets[i + 1] - in->offsets[i] + 3) & ~3LL) > CPO_TILE)
+        return bfmmm_io_fail("bfmmm_post_cpo: (M + 1) x observations of a curve exceed the on-chip tile in this build");
+    double *d_cll, *d_cpo;
+    if (!db.put(&d_cll, (const double*)nullptr, (size_t)n * T) || !db.put(&d_cpo, (const double*)nullptr, (size_t)n))
+      return bfmmm_io_fail("bfmmm_post_cpo: device allocation failed");
+    const size_t lds_c = ((size_t)CPO_VT + CPO_TILE + 16 * CPO_NQ * 4 + 16 * (KMAXP + 1) + BL_MAX + 8) * sizeof(double);
+    (void)hipFuncSetAttribute((const void*)k_post_cpo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+    hipEvent_t c0, c1;
+    (void)hipEventCreate(&c0); (void)hipEventCreate(&c1);
+    (void)hipEventRecord(c0, 0);
+    hipLaunchKernelGGL(k_post_cpo, dim3(n), dim3(256), lds_c, 0, a, d_cll);
+    hipLaunchKernelGGL(k_post_cpo_reduce, dim3((n + 255) / 256), dim3(256), 0, 0, a, d_cll, d_cpo);
+    (void)hipEventRecord(c1, 0);
+    const bool ran_c = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+    if (ran_c) (void)hipEventElapsedTime(&g_last_kernel_ms, c0, c1);
+    (void)hipEventDestroy(c0); (void)hipEventDestroy(c1);
+    if (!ran_c || hipMemcpy(cpo, d_cpo, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess)
+      return bfmmm_io_fail("bfmmm_post_cpo: kernel launch or copy back failed");
+    return 0;
+  }
   const size_t lds = ((size_t)GMAX * (P | 1) + (size_t)GMAX * WMAX + 2048 + 64 + BL_MAX + 8) * sizeof(double);
   (void)hipFuncSetAttribute((const void*)k_post_pointwise, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
@@ -339,6 +510,11 @@ extern "C" int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_ke
 
 extern "C" int bfmmm_post_pointwise_joint(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_joint_pdf, double* mean_fit) {
   return post_impl(in, first_kept, llik, nullptr, mean_fit, mean_joint_pdf);
+}
+
+extern "C" int bfmmm_post_cpo(const bfmmm_post_input* in, int32_t first_kept, double* log_cpo) {
+  if (!log_cpo) return bfmmm_io_fail("bfmmm_post_cpo: null argument");
+  return post_impl(in, first_kept, nullptr, nullptr, nullptr, nullptr, log_cpo);
 }
 
 // device time of the last bfmmm_post_pointwise call's two kernels (HIP events on the launch stream), for measurement

@@ -214,6 +214,32 @@ extern "C" int bfmmm_FBIC(const bfmmm_post_args* a, double* out) {
   return 0;
 }
 
+extern "C" int bfmmm_ConditionalPredictiveOrdinates(const bfmmm_post_args* a, int32_t log_CPO, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  // argument checks in the reference's order (PostProcessing.cpp:6352-6375)
+  if (a && a->n_files <= 0) return bfmmm_io_fail("'n_files' must be greater than 0");
+  if (a && (a->burnin_prop < 0 || a->burnin_prop >= 1)) return bfmmm_io_fail("'burnin_prop' must be between 0 and 1");
+  if (check(a, true)) return 1;
+  Draws dr;
+  if (load_draws(a, dr)) return 1;
+  bfmmm_post_input in{};
+  in.n = dr.n; in.K = dr.K; in.P = dr.P; in.M = dr.M; in.D = dr.D;
+  in.offsets = a->offsets; in.y = a->y; in.B = dr.B.data(); in.X = a->X;
+  in.T = dr.T; in.nu = dr.nu.data(); in.Phi = dr.Phi.data(); in.Z = dr.Z.data(); in.chi = dr.chi.data(); in.sigma = dr.sigma.data();
+  in.eta = dr.eta.empty() ? nullptr : dr.eta.data();
+  in.xi = dr.xi.empty() ? nullptr : dr.xi.data();
+  in.device = a->device;
+  std::vector<double> v((size_t)dr.n);
+  const int first = (int)std::floor(a->burnin_prop * dr.T);      // CalculateLikelihood.h:361
+  if (bfmmm_post_cpo(&in, first, v.data())) return 1;
+  if (!log_CPO) for (double& x : v) x = std::exp(x);
+  bfmmm_result* r = bfmmm_result_create();
+  const int64_t nn = dr.n;
+  bfmmm_result_set(r, "value", v.data(), nn, &nn, 1);
+  *out = r;
+  return 0;
+}
+
 // ---- multivariate model: the same pass with the identity basis (a row's P coordinates are its observations) ----------
 namespace {
 

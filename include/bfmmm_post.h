@@ -5,6 +5,7 @@
  *   bfmmm_FDIC   <-  FDIC   src/PostProcessing.cpp:3660-4039  (deviance information criterion)
  *   bfmmm_FAIC   <-  FAIC   src/PostProcessing.cpp:4041-4456
  *   bfmmm_FBIC   <-  FBIC   src/PostProcessing.cpp:4458-4801
+ *   bfmmm_ConditionalPredictiveOrdinates  <-  ConditionalPredictiveOrdinates  src/PostProcessing.cpp:6339-6516
  *   bfmmm_MVLLik / bfmmm_MVDIC / bfmmm_MVAIC / bfmmm_MVBIC  <-  MVLLik :6099, MVDIC :5789, MVAIC :5116, MVBIC :5452
  *
  * All four evaluate the fitted value of every observation under every saved draw
@@ -50,6 +51,10 @@ int bfmmm_post_pointwise(const bfmmm_post_input* in, int32_t first_kept, double*
 /* the same pass with, instead of the per-observation mean density, the mean over the kept draws of each curve's JOINT
  * density prod_j dnorm(y_ij; f_ij, sigma) (calcDIC2MV, CalculateLikelihood.h:172-194): mean_joint_pdf has n entries */
 int bfmmm_post_pointwise_joint(const bfmmm_post_input* in, int32_t first_kept, double* llik, double* mean_joint_pdf, double* mean_fit);
+/* log CPO_i of every curve over the draws t >= first_kept (calcLikelihoodCPO, CalculateLikelihood.h:344-389): the marginal
+ * log-density of y_i under each kept draw (scores integrated out; the rank-M form of the reference's n_i x n_i
+ * log_det_sympd / inv_sympd) and the harmonic mean in the reference's stabilised form.  log_cpo has n entries. */
+int bfmmm_post_cpo(const bfmmm_post_input* in, int32_t first_kept, double* log_cpo);
 /* device time (ms, HIP events) of the kernels of the last bfmmm_post_pointwise call of this process: measurement aid */
 double bfmmm_post_last_kernel_ms(void);
 
@@ -76,6 +81,9 @@ int bfmmm_FLLik(const bfmmm_post_args* a, bfmmm_result** out);      /* result el
 int bfmmm_FDIC(const bfmmm_post_args* a, double* out);
 int bfmmm_FAIC(const bfmmm_post_args* a, double* out);
 int bfmmm_FBIC(const bfmmm_post_args* a, double* out);
+/* ConditionalPredictiveOrdinates (src/PostProcessing.cpp:6339): result element "value", one entry per curve; log_CPO = 0
+ * returns exp of it */
+int bfmmm_ConditionalPredictiveOrdinates(const bfmmm_post_args* a, int32_t log_CPO, bfmmm_result** out);
 /* multivariate model: MVLLik (src/PostProcessing.cpp:6099), MVDIC (:5789), MVAIC (:5116), MVBIC (:5452) */
 int bfmmm_MVLLik(const bfmmm_post_args* a, bfmmm_result** out);
 int bfmmm_MVDIC(const bfmmm_post_args* a, double* out);

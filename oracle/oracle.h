@@ -146,6 +146,8 @@ double orc_calcLikelihood(const orc_data* d, int iter, const orc_chain* c);
 double orc_fitted(const orc_data* d, const orc_chain* c, int iter, int i, int l);
 double orc_yobs(const orc_data* d, int i, int l);
 int orc_ni(const orc_data* d, int i);
+double orc_row_dot(const orc_data* d, const orc_chain* c, int iter, int i, int l, int k, int mt);
+void orc_post_cpo(const orc_data* d, const orc_chain* c, int T, double burnin_prop, double* out);
 
 /* post.c: likelihood-based post-processing over a chain of T saved draws (src/PostProcessing.cpp) */
 void orc_post_llik(const orc_data* d, const orc_chain* c, int T, double* out);

@@ -92,3 +92,58 @@ double orc_post_bic(const orc_data* d, const orc_chain* c, int T, double burnin_
   if (d->mv) tilde_N = d->n;      /* MVBIC: log(Y.n_rows), PostProcessing.cpp:5560, :5717 */
   return (2 * loglik_at_means(d, c, T, burnin_prop)) - (log(tilde_N) * n_params(d, has_x, cov_adj));
 }
+
+/* ConditionalPredictiveOrdinates -> calcLikelihoodCPO, CalculateLikelihood.h:344-389: the dense n_i x n_i covariance of
+ * every curve under every kept draw, log_det_sympd and inv_sympd through a Cholesky factorisation (what Armadillo's
+ * sympd routines do), then the stabilised harmonic mean of :381-386.  Z entries are used as they are (no zero skip). */
+void orc_post_cpo(const orc_data* d, const orc_chain* c, int T, double burnin_prop, double* out) {
+  const int K = d->K, M = d->M;
+  const int first = (int)floor(burnin_prop * T);
+  const int L = (int)ceil((1 - burnin_prop) * T);
+  double* logl = (double*)malloc(sizeof(double) * (size_t)L);
+  for (int i = 0; i < d->n; ++i) {
+    const int ni = orc_ni(d, i);
+    double* mean = (double*)malloc(sizeof(double) * (size_t)ni);
+    double* cov = (double*)malloc(sizeof(double) * (size_t)ni * ni);
+    double* Lc = (double*)malloc(sizeof(double) * (size_t)ni * ni);
+    double* u = (double*)malloc(sizeof(double) * (size_t)ni * K * M);
+    double* w = (double*)malloc(sizeof(double) * (size_t)ni);
+    const double* Z_i = c->Z + i;
+    for (int l = first; l < T; ++l) {
+      for (int a = 0; a < ni; ++a) mean[a] = 0;
+      for (int a = 0; a < ni * ni; ++a) cov[a] = 0;
+      for (int k = 0; k < K; ++k)
+        for (int m = 0; m < M; ++m)
+          for (int a = 0; a < ni; ++a) u[(k * M + m) * ni + a] = orc_row_dot(d, c, l, i, a, k, m + 1);
+      for (int k = 0; k < K; ++k) {
+        const double zk = Z_i[(size_t)d->n * (k + (size_t)K * l)];
+        for (int a = 0; a < ni; ++a) mean[a] = mean[a] + zk * orc_row_dot(d, c, l, i, a, k, 0);
+        for (int k1 = 0; k1 < K; ++k1) {
+          const double zk1 = Z_i[(size_t)d->n * (k1 + (size_t)K * l)];
+          for (int m = 0; m < M; ++m)
+            for (int a = 0; a < ni; ++a)
+              for (int b = 0; b < ni; ++b)
+                cov[a + (size_t)ni * b] = cov[a + (size_t)ni * b] + zk * zk1 * (u[(k * M + m) * ni + a] * u[(k1 * M + m) * ni + b]);
+        }
+      }
+      for (int a = 0; a < ni; ++a) cov[a + (size_t)ni * a] = cov[a + (size_t)ni * a] + c->sigma[l];
+      orc_chol_lower(ni, cov, Lc);
+      double logdet = 0, quad = 0;
+      for (int a = 0; a < ni; ++a) {          /* L w = (y - mean):  (y - mean)' cov^-1 (y - mean) = w'w */
+        double v = orc_yobs(d, i, a) - mean[a];
+        for (int b = 0; b < a; ++b) v -= Lc[a + (size_t)ni * b] * w[b];
+        w[a] = v / Lc[a + (size_t)ni * a];
+        quad += w[a] * w[a];
+        logdet += 2 * log(Lc[a + (size_t)ni * a]);
+      }
+      logl[l - first] = -(0.5 * ni) * log(2 * 3.14159265358979323846) - 0.5 * logdet - 0.5 * quad;
+    }
+    double mn = logl[0];
+    for (int l = 1; l < L; ++l) if (logl[l] < mn) mn = logl[l];
+    double ph = 0;
+    for (int l = 0; l < L; ++l) ph = ph + exp(mn - logl[l]);
+    out[i] = log((double)L) + mn - log(ph);
+    free(mean); free(cov); free(Lc); free(u); free(w);
+  }
+  free(logl);
+}

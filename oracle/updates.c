@@ -553,6 +553,13 @@ double orc_fitted(const orc_data* d, const orc_chain* c, int iter, int i, int l)
   return fitted_skipzero(d, c, iter, i, BROW(i, l));
 }
 double orc_yobs(const orc_data* d, int i, int l) { return YOBS(i, l); }
+/* B_i.row(l) . (nu.row(k) + eta.slice(k) X.row(i)')  (mt = 0)  or  B_i.row(l) . (Phi.slice(mt-1).row(k) + xi(iter,k).slice(mt-1) X.row(i)') */
+double orc_row_dot(const orc_data* d, const orc_chain* c, int iter, int i, int l, int k, int mt) {
+  DIMS;
+  const double* b = BROW(i, l);
+  if (mt == 0) return dot_nu(SL_NU(c, iter), K, P, k, b) + (D > 0 ? dot_eta(d, SL_ETA(c, iter), k, i, b) : 0.0);
+  return dot_phi(SL_PHI(c, iter), K, P, k, mt - 1, b) + (D > 0 ? dot_xi(d, SL_XI(c, iter, k), mt - 1, i, b) : 0.0);
+}
 int orc_ni(const orc_data* d, int i) { return NI(i); }
 
 /* updateSigma, UpdateSigma.h:22-58: a += n_i / 2 with INTEGER division (:49);

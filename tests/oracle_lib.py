@@ -400,3 +400,12 @@ def post_aic_bic(model, ch, burnin_prop, has_x, cov_adj):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int]
     a = (C.addressof(model.data), C.addressof(ch.c), ch.T, burnin_prop, int(has_x), int(cov_adj))
     return L.orc_post_aic(*a), L.orc_post_bic(*a)
+
+
+def post_cpo(model, ch, burnin_prop):
+    L = lib()
+    L.orc_post_cpo.restype = None
+    L.orc_post_cpo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, c_double_p]
+    out = np.zeros(model.n)
+    L.orc_post_cpo(C.addressof(model.data), C.addressof(ch.c), ch.T, burnin_prop, dp(out))
+    return out

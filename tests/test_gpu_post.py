@@ -88,6 +88,24 @@ def test_llik_dic_aic_bic_match_oracle(tmp_path, D, cov_adj):
     np.testing.assert_allclose(fit[i], fit_ref, rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("D,cov_adj", [(0, False), (1, False), (2, True)])
+def test_conditional_predictive_ordinates_match_oracle(tmp_path, D, cov_adj):
+    """ConditionalPredictiveOrdinates (src/PostProcessing.cpp:6339, calcLikelihoodCPO): the device evaluates the marginal
+    density through the rank-M form, the oracle through the reference's dense n_i x n_i covariance (log det and inverse by
+    Cholesky): the two agree to rounding of the dense factorisation."""
+    from bayesfmmm_amd import api
+    sim, X, dirn = _run_and_save(tmp_path, D, cov_adj)
+    model, ch, B = _oracle_chain(sim, X, dirn, 3, cov_adj)
+    args = (dirn, 3, 3, sim["boundary_knots"], sim["internal_knots"], sim["t"], sim["y"])
+    kw = dict(X=X, cov_adj=cov_adj) if D else {}
+    for burn in (0.1, 0.55):
+        cpo = api.ConditionalPredictiveOrdinates(*args, burnin_prop=burn, **kw)
+        ref = O.post_cpo(model, ch, burn)
+        assert cpo.shape == (sim["n"],)
+        np.testing.assert_allclose(cpo, ref, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(api.ConditionalPredictiveOrdinates(*args, log_CPO=False, **kw), np.exp(O.post_cpo(model, ch, 0.1)), rtol=1e-7)
+
+
 def test_post_argument_checks(tmp_path):
     from bayesfmmm_amd import _lib, api
     sim, X, dirn = _run_and_save(tmp_path, 0, False)
