@@ -85,7 +85,23 @@ class PostArgs(C.Structure):
                 ("X", c_double_p), ("D", C.c_int32), ("cov_adj", C.c_int32), ("device", C.c_int32), ("P", C.c_int32)]
 
 
+class CiArgs(C.Structure):
+    """bfmmm_ci_args of include/bfmmm_post.h."""
+    _fields_ = [("dir", C.c_char_p), ("n_files", C.c_int32), ("time", c_double_p), ("n_time", C.c_int32),
+                ("basis_degree", C.c_int32), ("n_internal_knots", C.c_int32), ("boundary_knots", c_double_p),
+                ("internal_knots", c_double_p), ("k", C.c_int32), ("alpha", C.c_double), ("rescale", C.c_int32),
+                ("simultaneous", C.c_int32), ("burnin_prop", C.c_double), ("X", c_double_p), ("n_x", C.c_int32), ("D", C.c_int32),
+                ("trans_mats", c_double_p), ("device", C.c_int32)]
+
+
 POST_SYMBOLS = {
+    "bfmmm_post_col_quantiles": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
+    "bfmmm_post_bands": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                   c_double_p, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_ci_defaults": (None, [C.POINTER(CiArgs)]),
+    "bfmmm_SigmaCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_ZCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_FMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_post_pointwise": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
     "bfmmm_post_pointwise_joint": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p, c_double_p, c_double_p]),
     "bfmmm_post_cpo": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p]),
@@ -680,3 +696,63 @@ def ConditionalPredictiveOrdinates(dir, n_files, basis_degree, boundary_knots, i
         return _result_to_dict(lib, res, None, 0)["value"]
     finally:
         lib.bfmmm_result_free(res)
+
+
+# ---- credible intervals (src/PostProcessing.cpp:99, :3435, :3505) -------------------------------------------------------
+def _ci_call(fn, a, keep):
+    lib = _lib_entry()
+    res = C.c_void_p()
+    _check(fn(C.byref(a), C.byref(res)))
+    try:
+        return _result_to_dict(lib, res, None, 0)
+    finally:
+        lib.bfmmm_result_free(res)
+
+
+def _ci_args(dir, n_files, alpha, burnin_prop):
+    lib = _lib_entry()
+    a = CiArgs()
+    lib.bfmmm_ci_defaults(C.byref(a))
+    keep = [str(dir).encode()]
+    a.dir, a.n_files, a.alpha, a.burnin_prop = keep[0], n_files, alpha, burnin_prop
+    return a, keep
+
+
+def SigmaCI(dir, n_files, alpha=0.05, burnin_prop=0.1):
+    """src/PostProcessing.cpp:3435 (CI_Lower is the median, as in the reference)."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    d = _ci_call(_lib_entry().bfmmm_SigmaCI, a, keep)
+    return {k: float(v.reshape(-1)[0]) for k, v in d.items()}
+
+
+def ZCI(dir, n_files, alpha=0.05, rescale=True, burnin_prop=0.1):
+    """src/PostProcessing.cpp:3505."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    a.rescale = int(bool(rescale))
+    return _ci_call(_lib_entry().bfmmm_ZCI, a, keep)
+
+
+def FMeanCI(dir, n_files, time, basis_degree, boundary_knots, internal_knots, k, alpha=0.05, rescale=True, simultaneous=False,
+            burnin_prop=0.1, X=None, trans_mats=None):
+    """src/PostProcessing.cpp:99."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    t = np.ascontiguousarray(time, dtype=np.float64).reshape(-1)
+    bk = np.ascontiguousarray(boundary_knots, dtype=np.float64)
+    ik = np.ascontiguousarray(internal_knots, dtype=np.float64)
+    keep += [t, bk, ik]
+    a.time, a.n_time, a.basis_degree, a.n_internal_knots = t.ctypes.data_as(c_double_p), len(t), basis_degree, len(ik)
+    a.boundary_knots, a.internal_knots = bk.ctypes.data_as(c_double_p), ik.ctypes.data_as(c_double_p)
+    a.k, a.rescale, a.simultaneous = k, int(bool(rescale)), int(bool(simultaneous))
+    if X is not None:
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        keep.append(Xf)
+        a.X, a.n_x, a.D = Xf.ctypes.data_as(c_double_p), Xf.shape[0], Xf.shape[1]
+    if trans_mats is not None:
+        tm = np.asfortranarray(trans_mats, dtype=np.float64)
+        keep.append(tm)
+        a.trans_mats = tm.ctypes.data_as(c_double_p)
+    d = _ci_call(_lib_entry().bfmmm_FMeanCI, a, keep)
+    if X is None:
+        for nm in ("CI_Upper", "CI_50", "CI_Lower"):
+            d[nm] = d[nm].reshape(-1)
+    return d

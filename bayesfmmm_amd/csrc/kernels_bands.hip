@@ -1,0 +1,180 @@
+// Credible bands over saved draws on the device (include/bfmmm_post.h): column quantiles and simultaneous bands of a
+// draws x columns table, and the table of mean-function draws f[t][j] = B_j' coef_t itself.
+//
+//   k_bands_fsamp      f[t + T j] = sum_p B[j][p] coef[t][p]                    (grid: columns x chunks of draws)
+//   k_bands_quantiles  one workgroup per column: the column's T draws are sorted in LDS (bitonic network, padded with
+//                      +inf to a power of two) and the requested quantiles read off with Armadillo's rule
+//                      (arma::quantile: Hyndman & Fan definition 5 -- p_k = (k - 0.5) / N, linear in between, the extremes
+//                      outside [0.5 / N, (N - 0.5) / N])
+//   k_bands_moments    per column mean and standard deviation (N - 1), fixed-order tree
+//   k_bands_maxdev     per draw C_t = max_j |f - mean_j| / sd_j                  (simultaneous bands, PostProcessing.cpp:287-296)
+// A column is limited to 8192 draws (64 KiB of LDS).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/bfmmm_post.h"
+
+int bfmmm_io_fail(const std::string& m);
+
+namespace {
+
+constexpr int QT = 256;
+constexpr int TMAX = 8192;
+
+__global__ __launch_bounds__(QT) void k_bands_fsamp(const double* B, const double* coef, int T, int P, double* f) {
+  const int j = blockIdx.x;
+  const double* b = B + (size_t)j * P;
+  for (int t = blockIdx.y * QT + threadIdx.x; t < T; t += gridDim.y * QT) {
+    const double* c = coef + (size_t)t * P;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += b[p] * c[p];
+    f[(size_t)t + (size_t)T * j] = s;
+  }
+}
+
+__device__ inline void sort_lds(double* s, int NP, int tid) {
+  for (int k = 2; k <= NP; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      __syncthreads();
+      for (int e = tid; e < NP; e += QT) {
+        const int partner = e ^ jj;
+        if (partner > e) {
+          const bool up = (e & k) == 0;
+          const double a = s[e], b = s[partner];
+          if ((a > b) == up) { s[e] = b; s[partner] = a; }
+        }
+      }
+    }
+  __syncthreads();
+}
+
+// out[q + nq * col]
+__global__ __launch_bounds__(QT) void k_bands_quantiles(const double* V, int T, const double* probs, int nq, double* out) {
+  extern __shared__ double s[];
+  const int col = blockIdx.x, tid = threadIdx.x;
+  int NP = 1;
+  while (NP < T) NP <<= 1;
+  for (int e = tid; e < NP; e += QT) s[e] = (e < T) ? V[(size_t)e + (size_t)T * col] : INFINITY;
+  sort_lds(s, NP, tid);
+  if (tid < nq) {
+    const double N = (double)T, p = probs[tid];
+    double v;
+    if (p < 0.5 / N) v = (p < 0.0) ? -INFINITY : s[0];
+    else if (p > (N - 0.5) / N) v = (p > 1.0) ? INFINITY : s[T - 1];
+    else {
+      const int k = (int)floor(N * p + 0.5);
+      const double pk = ((double)k - 0.5) / N, w = (p - pk) * N;
+      v = (1.0 - w) * s[k - 1] + w * s[min(k, T - 1)];
+    }
+    out[tid + (size_t)nq * col] = v;
+  }
+}
+
+// fixed-order pairwise sums of a column: mean, then sd with N - 1
+__global__ __launch_bounds__(QT) void k_bands_moments(const double* V, int T, double* mean, double* sd) {
+  __shared__ double red[QT];
+  const int col = blockIdx.x, tid = threadIdx.x;
+  const double* v = V + (size_t)T * col;
+  double a = 0.0;
+  for (int e = tid; e < T; e += QT) a += v[e];
+  red[tid] = a;
+  __syncthreads();
+  for (int h = QT / 2; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+  const double m = red[0] / (double)T;
+  __syncthreads();
+  double q = 0.0;
+  for (int e = tid; e < T; e += QT) { const double dlt = v[e] - m; q += dlt * dlt; }
+  red[tid] = q;
+  __syncthreads();
+  for (int h = QT / 2; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+  if (tid == 0) { mean[col] = m; sd[col] = sqrt(red[0] / (double)(T - 1)); }
+}
+
+__global__ __launch_bounds__(QT) void k_bands_maxdev(const double* V, int T, int ncol, const double* mean, const double* sd, double* C) {
+  const int t = blockIdx.x * QT + threadIdx.x;
+  if (t >= T) return;
+  double mx = -INFINITY;
+  for (int j = 0; j < ncol; ++j) mx = fmax(mx, fabs((V[(size_t)t + (size_t)T * j] - mean[j]) / sd[j]));
+  C[t] = mx;
+}
+
+struct Bufs {
+  std::vector<void*> p;
+  ~Bufs() { for (void* q : p) (void)hipFree(q); }
+  bool put(double** out, const double* host, size_t count) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(double)) != hipSuccess) return false;
+    p.push_back(d);
+    if (host && count && hipMemcpy(d, host, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return false;
+    *out = (double*)d;
+    return true;
+  }
+};
+
+int select_device(int device, const char* who) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bfmmm_io_fail(std::string(who) + ": no HIP device (the MI355X library has no CPU path)");
+  if (hipSetDevice(device) != hipSuccess) return bfmmm_io_fail(std::string(who) + ": cannot select the device");
+  return 0;
+}
+
+size_t sort_lds_bytes(int T) { int NP = 1; while (NP < T) NP <<= 1; return (size_t)NP * sizeof(double); }
+
+}  // namespace
+
+extern "C" int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol, const double* probs, int32_t nq, int32_t device, double* out) {
+  if (!V || !probs || !out || T < 1 || ncol < 1 || nq < 1 || nq > QT) return bfmmm_io_fail("bfmmm_post_col_quantiles: bad arguments");
+  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_col_quantiles: at most 8192 draws per column in this build");
+  if (select_device(device, "bfmmm_post_col_quantiles")) return 1;
+  Bufs b;
+  double *dV, *dp, *dout;
+  if (!b.put(&dV, V, (size_t)T * ncol) || !b.put(&dp, probs, (size_t)nq) || !b.put(&dout, nullptr, (size_t)nq * ncol))
+    return bfmmm_io_fail("bfmmm_post_col_quantiles: device allocation or copy failed");
+  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
+  hipLaunchKernelGGL(k_bands_quantiles, dim3(ncol), dim3(QT), sort_lds_bytes(T), 0, dV, T, dp, nq, dout);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess ||
+      hipMemcpy(out, dout, sizeof(double) * nq * ncol, hipMemcpyDeviceToHost) != hipSuccess)
+    return bfmmm_io_fail("bfmmm_post_col_quantiles: kernel launch or copy back failed");
+  return 0;
+}
+
+// coef: T x P (one row per draw); B: n_t x P row-major.  upper / mid / lower: n_t; trace: T x n_t column-major (draw fastest) or NULL
+extern "C" int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
+                                int32_t device, double* upper, double* mid, double* lower, double* trace) {
+  if (!coef || !B || !upper || !mid || !lower || T < 2 || P < 1 || n_t < 1) return bfmmm_io_fail("bfmmm_post_bands: bad arguments");
+  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_bands: at most 8192 kept draws in this build");
+  if (select_device(device, "bfmmm_post_bands")) return 1;
+  Bufs b;
+  double *dc, *dB, *df, *dp, *dq, *dm, *ds, *dC;
+  const double probs[3] = {alpha / 2, 0.5, 1 - alpha / 2}, p1[1] = {1 - alpha};
+  if (!b.put(&dc, coef, (size_t)T * P) || !b.put(&dB, B, (size_t)n_t * P) || !b.put(&df, nullptr, (size_t)T * n_t) ||
+      !b.put(&dp, simultaneous ? p1 : probs, simultaneous ? 1 : 3) || !b.put(&dq, nullptr, (size_t)3 * n_t) ||
+      !b.put(&dm, nullptr, (size_t)n_t) || !b.put(&ds, nullptr, (size_t)n_t) || !b.put(&dC, nullptr, (size_t)T))
+    return bfmmm_io_fail("bfmmm_post_bands: device allocation or copy failed");
+  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
+  hipLaunchKernelGGL(k_bands_fsamp, dim3(n_t, std::min((T + QT - 1) / QT, 64)), dim3(QT), 0, 0, dB, dc, T, P, df);
+  std::vector<double> q((size_t)3 * n_t), m((size_t)n_t), s((size_t)n_t);
+  if (!simultaneous) {
+    hipLaunchKernelGGL(k_bands_quantiles, dim3(n_t), dim3(QT), sort_lds_bytes(T), 0, df, T, dp, 3, dq);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(q.data(), dq, sizeof(double) * 3 * n_t, hipMemcpyDeviceToHost) != hipSuccess)
+      return bfmmm_io_fail("bfmmm_post_bands: kernel launch or copy back failed");
+    for (int j = 0; j < n_t; ++j) { lower[j] = q[(size_t)3 * j]; mid[j] = q[(size_t)3 * j + 1]; upper[j] = q[(size_t)3 * j + 2]; }
+  } else {
+    hipLaunchKernelGGL(k_bands_moments, dim3(n_t), dim3(QT), 0, 0, df, T, dm, ds);
+    hipLaunchKernelGGL(k_bands_maxdev, dim3((T + QT - 1) / QT), dim3(QT), 0, 0, df, T, n_t, dm, ds, dC);
+    hipLaunchKernelGGL(k_bands_quantiles, dim3(1), dim3(QT), sort_lds_bytes(T), 0, dC, T, dp, 1, dq);
+    double qc = 0.0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&qc, dq, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(m.data(), dm, sizeof(double) * n_t, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(s.data(), ds, sizeof(double) * n_t, hipMemcpyDeviceToHost) != hipSuccess)
+      return bfmmm_io_fail("bfmmm_post_bands: kernel launch or copy back failed");
+    for (int j = 0; j < n_t; ++j) { lower[j] = m[(size_t)j] - qc * s[(size_t)j]; mid[j] = m[(size_t)j]; upper[j] = m[(size_t)j] + qc * s[(size_t)j]; }
+  }
+  if (hipGetLastError() != hipSuccess) return bfmmm_io_fail("bfmmm_post_bands: kernel launch failed");
+  if (trace && hipMemcpy(trace, df, sizeof(double) * (size_t)T * n_t, hipMemcpyDeviceToHost) != hipSuccess)
+    return bfmmm_io_fail("bfmmm_post_bands: copy back failed");
+  return 0;
+}

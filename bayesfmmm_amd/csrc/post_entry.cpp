@@ -347,3 +347,209 @@ extern "C" int bfmmm_MVBIC(const bfmmm_post_args* a, double* out) {
   *out = 2 * ll - std::log((double)a->n_funct) * n_params(dr, a->X != nullptr, a->cov_adj != 0);      // :5560 (log(Y.n_rows))
   return 0;
 }
+
+// ---- credible intervals: SigmaCI, ZCI, FMeanCI -----------------------------------------------------------------------
+namespace {
+
+int ci_check(const bfmmm_ci_args* a, bool basis) {       // order and wording of PostProcessing.cpp:116-141, :3439-3453
+  if (!a || !a->dir) return bfmmm_io_fail("null argument");
+  if (a->n_files <= 0) return bfmmm_io_fail("'n_files' must be greater than 0");
+  if (a->alpha < 0 || a->alpha >= 1) return bfmmm_io_fail("'alpha' must be between 0 and 1");
+  if (a->burnin_prop < 0 || a->burnin_prop >= 1) return bfmmm_io_fail("'burnin_prop' must be between 0 and 1");
+  if (!basis) return 0;
+  if (!a->time || a->n_time < 1 || !a->boundary_knots) return bfmmm_io_fail("null argument");
+  if (a->basis_degree < 1) return bfmmm_io_fail("'basis_degree' must be an integer greater than or equal to 1");
+  for (int i = 0; i < a->n_internal_knots; ++i) {
+    if (a->boundary_knots[0] >= a->internal_knots[i])
+      return bfmmm_io_fail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+    if (a->boundary_knots[1] <= a->internal_knots[i])
+      return bfmmm_io_fail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+  }
+  return 0;
+}
+
+// transform_mat of a draw (K x K, column-major): row i = the Z row of the observation with the largest Z(., i)  (:258-268)
+void transform_of(const double* Zt, int n, int K, std::vector<double>& Tm) {
+  Tm.assign((size_t)K * K, 0.0);
+  for (int i = 0; i < K; ++i) {
+    int mx = 0;
+    for (int l = 1; l < n; ++l) if (Zt[l + (size_t)n * i] > Zt[mx + (size_t)n * i]) mx = l;      // arma::index_max: first maximum
+    for (int c = 0; c < K; ++c) Tm[i + (size_t)K * c] = Zt[mx + (size_t)n * c];
+  }
+}
+
+void put_mat(bfmmm_result* r, const char* name, const std::vector<double>& v, int64_t d0, int64_t d1, int64_t d2 = -1) {
+  const int64_t dims[3] = {d0, d1, d2};
+  bfmmm_result_set(r, name, v.data(), (int64_t)v.size(), dims, d2 < 0 ? (d1 < 0 ? 1 : 2) : 3);
+}
+
+}  // namespace
+
+extern "C" void bfmmm_ci_defaults(bfmmm_ci_args* a) {
+  *a = bfmmm_ci_args{};
+  a->alpha = 0.05; a->rescale = 1; a->burnin_prop = 0.1; a->k = 1;
+}
+
+extern "C" int bfmmm_SigmaCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (ci_check(a, false)) return 1;
+  std::vector<double> sig;
+  int64_t d[3];
+  if (load_cat(a->dir, "Sigma", a->n_files, sig, d)) return 1;
+  const int T = (int)sig.size(), kept = (int)std::round(T * (1 - a->burnin_prop));
+  if (kept < 1) return bfmmm_io_fail("'burnin_prop' leaves no draws");
+  const double probs[3] = {a->alpha / 2, 0.5, 1 - a->alpha / 2};
+  double q[3];
+  if (bfmmm_post_col_quantiles(sig.data() + (T - kept), kept, 1, probs, 3, a->device, q)) return 1;
+  bfmmm_result* r = bfmmm_result_create();
+  const int64_t one = 1;
+  bfmmm_result_set(r, "CI_Upper", &q[2], 1, &one, 1);
+  bfmmm_result_set(r, "CI_50", &q[1], 1, &one, 1);
+  bfmmm_result_set(r, "CI_Lower", &q[1], 1, &one, 1);      // PostProcessing.cpp:3496: the reference returns q(1) here
+  *out = r;
+  return 0;
+}
+
+extern "C" int bfmmm_ZCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!out || !a || !a->dir) return bfmmm_io_fail("null argument");      // (the reference checks nothing here)
+  std::vector<double> Z;
+  int64_t d[3];
+  if (load_cat(a->dir, "Z", a->n_files, Z, d)) return 1;
+  const int n = (int)d[0], K = (int)d[1], T = (int)d[2] * a->n_files;
+  bool rescale = a->rescale != 0;
+  if (rescale && K > 2) rescale = false;                     // "Rescale property cannot be used for K > 2"
+  if (rescale) {      // Z_j <- solve(T', Z_j')' = Z_j T^-1 (:3527-3541), K = 2 (a 1-cluster model never gets here)
+    std::vector<double> Tm;
+    for (int j = 0; j < T; ++j) {
+      double* Zt = Z.data() + (size_t)n * K * j;
+      transform_of(Zt, n, K, Tm);
+      if (K == 1) { for (int l = 0; l < n; ++l) Zt[l] /= Tm[0]; continue; }
+      const double t00 = Tm[0], t10 = Tm[1], t01 = Tm[2], t11 = Tm[3], det = t00 * t11 - t01 * t10;
+      for (int l = 0; l < n; ++l) {
+        const double z0 = Zt[l], z1 = Zt[l + n];
+        Zt[l] = (z0 * t11 - z1 * t10) / det;
+        Zt[l + n] = (z1 * t00 - z0 * t01) / det;
+      }
+    }
+  }
+  const int kept = (int)std::round(T * (1 - a->burnin_prop));
+  if (kept < 1) return bfmmm_io_fail("'burnin_prop' leaves no draws");
+  std::vector<double> V((size_t)kept * n * K);               // column (i, j) = the kept draws of Z(i, j)
+  for (int c = 0; c < n * K; ++c)
+    for (int l = 0; l < kept; ++l) V[(size_t)l + (size_t)kept * c] = Z[(size_t)c + (size_t)n * K * (T - kept + l)];
+  const double probs[3] = {a->alpha / 2, 0.5, 1 - a->alpha / 2};
+  std::vector<double> q((size_t)3 * n * K);
+  if (bfmmm_post_col_quantiles(V.data(), kept, n * K, probs, 3, a->device, q.data())) return 1;
+  std::vector<double> up((size_t)n * K), md((size_t)n * K), lo((size_t)n * K);
+  for (int c = 0; c < n * K; ++c) { lo[(size_t)c] = q[(size_t)3 * c]; md[(size_t)c] = q[(size_t)3 * c + 1]; up[(size_t)c] = q[(size_t)3 * c + 2]; }
+  bfmmm_result* r = bfmmm_result_create();
+  put_mat(r, "CI_Upper", up, n, K); put_mat(r, "CI_50", md, n, K); put_mat(r, "CI_Lower", lo, n, K);
+  const int first = (int)std::round(T * a->burnin_prop);     // :3563: Z_trace starts at round(T * burnin_prop)
+  std::vector<double> tr(Z.begin() + (size_t)n * K * first, Z.end());
+  put_mat(r, "Z_trace", tr, n, K, T - first);
+  *out = r;
+  return 0;
+}
+
+extern "C" int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (ci_check(a, true)) return 1;
+  const std::string dir = a->dir;
+  std::vector<double> nu;
+  int64_t d[3], nr, nc;
+  if (load_cat(dir, "Nu", a->n_files, nu, d)) return 1;
+  const int K = (int)d[0], P = (int)d[1], per_file = (int)d[2], T = per_file * a->n_files;
+  if (a->k <= 0) return bfmmm_io_fail("'k' must be positive");
+  if (a->k > K) return bfmmm_io_fail("'k' must be less than or equal to the number of clusters in the model");
+  if (P != a->n_internal_knots + a->basis_degree + 1) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
+  const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
+  if (kept < 2) return bfmmm_io_fail("'burnin_prop' leaves fewer than two draws");
+  bool rescale = a->rescale != 0;
+  if (rescale && K > 2) rescale = false;                     // "Rescale property cannot be used for K > 2" (:157-162)
+  int D = 0;
+  std::vector<double> eta;                                   // kept cubes P x D x K
+  if (a->X) {
+    for (int q = 0; q < a->n_files; ++q) {
+      std::vector<std::vector<double>> objs;
+      int64_t de[3];
+      if (arma_load_field(dir + "Eta" + std::to_string(q) + ".txt", objs, &nr, &nc, de)) return 1;
+      if (q == 0) {
+        D = (int)de[1];
+        if (a->D != D) return bfmmm_io_fail("The number of columns in 'X' must be equal to the number of covariates in the model");
+      }
+      for (int l = 0; l < per_file; ++l)
+        if (q * per_file + l >= first) eta.insert(eta.end(), objs[(size_t)l].begin(), objs[(size_t)l].end());
+    }
+  }
+  std::vector<double> nuk(nu.begin() + (size_t)K * P * first, nu.end());      // kept slices K x P
+  if (rescale) {
+    std::vector<double> Z, Tm, tmp((size_t)K * P), te((size_t)K);
+    int64_t dz[3];
+    if (load_cat(dir, "Z", a->n_files, Z, dz)) return 1;
+    const int n = (int)dz[0];
+    for (int j = 0; j < kept; ++j) {
+      transform_of(Z.data() + (size_t)n * K * (first + j), n, K, Tm);
+      double* nj = nuk.data() + (size_t)K * P * j;
+      for (int p = 0; p < P; ++p)
+        for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * nj[c + (size_t)K * p]; tmp[i + (size_t)K * p] = s_; }
+      std::copy(tmp.begin(), tmp.end(), nj);
+      for (int dd = 0; dd < D; ++dd)                          // eta_d <- T eta_d over the cluster index (:462-472)
+        for (int p = 0; p < P; ++p) {
+          double* ej = eta.data() + (size_t)P * D * K * j + p + (size_t)P * dd;
+          for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * ej[(size_t)P * D * c]; te[(size_t)i] = s_; }
+          for (int i = 0; i < K; ++i) ej[(size_t)P * D * i] = te[(size_t)i];
+        }
+    }
+  } else if (a->trans_mats) {                                // (:271-279, with X :486-502)
+    std::vector<double> tmp((size_t)K * P), te((size_t)K);
+    const size_t ld = (size_t)kept * K;
+    for (int j = 0; j < kept; ++j) {
+      double* nj = nuk.data() + (size_t)K * P * j;
+      auto tm = [&](int i, int c) { return a->trans_mats[(size_t)j * K + i + ld * c]; };
+      for (int p = 0; p < P; ++p)
+        for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += tm(i, c) * nj[c + (size_t)K * p]; tmp[i + (size_t)K * p] = s_; }
+      std::copy(tmp.begin(), tmp.end(), nj);
+      for (int dd = 0; dd < D; ++dd)
+        for (int p = 0; p < P; ++p) {
+          double* ej = eta.data() + (size_t)P * D * K * j + p + (size_t)P * dd;
+          for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += tm(i, c) * ej[(size_t)P * D * c]; te[(size_t)i] = s_; }
+          for (int i = 0; i < K; ++i) ej[(size_t)P * D * i] = te[(size_t)i];
+        }
+    }
+  }
+  // basis at the band's time points
+  const int nt = a->n_time;
+  std::vector<double> cm((size_t)nt * P), B((size_t)nt * P);
+  const int32_t deg = a->basis_degree, nint = a->n_internal_knots;
+  if (bfmmm_tensor_bspline(nt, 1, a->time, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
+  for (int l = 0; l < nt; ++l)
+    for (int p = 0; p < P; ++p) B[(size_t)l * P + p] = cm[(size_t)l + (size_t)nt * p];
+  const int k0 = a->k - 1, nx = a->X ? a->n_x : 1;
+  std::vector<double> up((size_t)nx * nt), md((size_t)nx * nt), lo((size_t)nx * nt), trace((size_t)nx * nt * kept);
+  std::vector<double> coef((size_t)kept * P), u1((size_t)nt), m1((size_t)nt), l1((size_t)nt), tr1((size_t)kept * nt);
+  for (int x = 0; x < nx; ++x) {
+    for (int j = 0; j < kept; ++j)
+      for (int p = 0; p < P; ++p) {
+        double v = nuk[(size_t)K * P * j + k0 + (size_t)K * p];
+        for (int dd = 0; dd < D; ++dd) v += eta[(size_t)P * D * K * j + p + (size_t)P * (dd + (size_t)D * k0)] * a->X[x + (size_t)nx * dd];
+        coef[(size_t)j * P + p] = v;
+      }
+    if (bfmmm_post_bands(coef.data(), kept, P, B.data(), nt, a->alpha, a->simultaneous, a->device, u1.data(), m1.data(), l1.data(), tr1.data())) return 1;
+    for (int l = 0; l < nt; ++l) {
+      up[x + (size_t)nx * l] = u1[(size_t)l]; md[x + (size_t)nx * l] = m1[(size_t)l]; lo[x + (size_t)nx * l] = l1[(size_t)l];
+      for (int j = 0; j < kept; ++j)
+        if (a->X) trace[x + (size_t)nx * (l + (size_t)nt * j)] = tr1[(size_t)j + (size_t)kept * l];
+        else trace[(size_t)j + (size_t)kept * l] = tr1[(size_t)j + (size_t)kept * l];
+    }
+  }
+  bfmmm_result* r = bfmmm_result_create();
+  if (a->X) {
+    put_mat(r, "CI_Upper", up, nx, nt); put_mat(r, "CI_50", md, nx, nt); put_mat(r, "CI_Lower", lo, nx, nt);
+    put_mat(r, "mean_trace", trace, nx, nt, kept);
+  } else {
+    put_mat(r, "CI_Upper", up, nt, -1); put_mat(r, "CI_50", md, nt, -1); put_mat(r, "CI_Lower", lo, nt, -1);
+    put_mat(r, "mean_trace", trace, kept, nt);
+  }
+  *out = r;
+  return 0;
+}

@@ -5,6 +5,7 @@
  *   bfmmm_FDIC   <-  FDIC   src/PostProcessing.cpp:3660-4039  (deviance information criterion)
  *   bfmmm_FAIC   <-  FAIC   src/PostProcessing.cpp:4041-4456
  *   bfmmm_FBIC   <-  FBIC   src/PostProcessing.cpp:4458-4801
+ *   bfmmm_SigmaCI / bfmmm_ZCI / bfmmm_FMeanCI  <-  SigmaCI :3435, ZCI :3505, FMeanCI :99
  *   bfmmm_ConditionalPredictiveOrdinates  <-  ConditionalPredictiveOrdinates  src/PostProcessing.cpp:6339-6516
  *   bfmmm_MVLLik / bfmmm_MVDIC / bfmmm_MVAIC / bfmmm_MVBIC  <-  MVLLik :6099, MVDIC :5789, MVAIC :5116, MVBIC :5452
  *
@@ -89,6 +90,42 @@ int bfmmm_MVLLik(const bfmmm_post_args* a, bfmmm_result** out);
 int bfmmm_MVDIC(const bfmmm_post_args* a, double* out);
 int bfmmm_MVAIC(const bfmmm_post_args* a, double* out);
 int bfmmm_MVBIC(const bfmmm_post_args* a, double* out);
+
+/* ---- credible intervals over the saved draws (kernels_bands.hip) ---------------------------------------------------
+ * bfmmm_post_col_quantiles: quantiles of every column of a T x ncol table (column-major, draw fastest) with Armadillo's
+ * arma::quantile rule; out[q + nq * col].  bfmmm_post_bands: the table f[t][j] = B_j' coef_t (coef: T x P, one row per
+ * draw; B: n_t x P row-major) and its pointwise (alpha / 2, 0.5, 1 - alpha / 2) or simultaneous bands
+ * (src/PostProcessing.cpp:228-238, :284-302); trace (T x n_t, draw fastest) may be NULL.  At most 8192 draws. */
+int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol, const double* probs, int32_t nq, int32_t device, double* out);
+int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
+                     int32_t device, double* upper, double* mid, double* lower, double* trace);
+
+typedef struct {
+  const char* dir;
+  int32_t n_files;
+  const double* time;              /* FMeanCI: the n_time points of the band */
+  int32_t n_time;
+  int32_t basis_degree, n_internal_knots;
+  const double* boundary_knots;
+  const double* internal_knots;
+  int32_t k;                       /* FMeanCI: cluster, 1-based as in R */
+  double alpha;                    /* default 0.05 */
+  int32_t rescale;                 /* default 1 (ignored with a message for K > 2, as the reference) */
+  int32_t simultaneous;            /* default 0 */
+  double burnin_prop;              /* default 0.1 */
+  const double* X;                 /* FMeanCI: n_x x D covariate settings, column-major, or NULL */
+  int32_t n_x, D;
+  const double* trans_mats;        /* FMeanCI: (kept draws * K) x K, column-major, or NULL */
+  int32_t device;
+} bfmmm_ci_args;
+
+void bfmmm_ci_defaults(bfmmm_ci_args* a);
+/* SigmaCI (src/PostProcessing.cpp:3435): "CI_Upper", "CI_50", "CI_Lower" -- the reference returns the MEDIAN as CI_Lower
+ * (:3496 `CI_Lower = q(1)`), reproduced; ZCI (:3505): n x K matrices and "Z_trace"; FMeanCI (:99): vectors of n_time (n_x x
+ * n_time matrices with X) and "mean_trace" (kept x n_time; with X a cube n_x x n_time x kept). */
+int bfmmm_SigmaCI(const bfmmm_ci_args* a, bfmmm_result** out);
+int bfmmm_ZCI(const bfmmm_ci_args* a, bfmmm_result** out);
+int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY: numpy restatement of the reference's credible-interval functions over saved draws
+(src/PostProcessing.cpp): SigmaCI :3435-3503, ZCI :3505-3572, FMeanCI :99-700 (without and with covariates, pointwise and
+simultaneous, rescale / trans_mats).  arma::quantile is Armadillo's (RcppArmadillo, a dependency that is not vendored in the
+reference): Hyndman & Fan definition 5, restated from its published algorithm (op_quantile).  Parity unpinned: the reference
+ships no expected values for these functions."""
+import numpy as np
+
+
+def arma_quantile(v, probs):
+    y = np.sort(np.asarray(v, dtype=np.float64))
+    N = float(len(y))
+    out = []
+    for p in probs:
+        if p < 0.5 / N:
+            out.append(-np.inf if p < 0 else y[0])
+        elif p > (N - 0.5) / N:
+            out.append(np.inf if p > 1 else y[-1])
+        else:
+            k = int(np.floor(N * p + 0.5))
+            pk = (k - 0.5) / N
+            w = (p - pk) * N
+            out.append((1 - w) * y[k - 1] + w * y[min(k, len(y) - 1)])
+    return np.array(out)
+
+
+def kept_count(T, burnin_prop):
+    return int(np.floor((T * (1 - burnin_prop)) + 0.5))        # std::round of a positive number
+
+
+def sigma_ci(sigma, alpha, burnin_prop):
+    kept = kept_count(len(sigma), burnin_prop)
+    q = arma_quantile(sigma[len(sigma) - kept:], [alpha / 2, 0.5, 1 - alpha / 2])
+    return dict(CI_Upper=q[2], CI_50=q[1], CI_Lower=q[1])     # :3496: CI_Lower = q(1) in the reference
+
+
+def transform_mat(Zj):
+    K = Zj.shape[1]
+    T = np.zeros((K, K))
+    for i in range(K):
+        T[i, :] = Zj[int(np.argmax(Zj[:, i])), :]              # arma::index_max: first maximum
+    return T
+
+
+def z_ci(Z, alpha, rescale, burnin_prop):
+    Z = np.array(Z, dtype=np.float64, copy=True)
+    n, K, T = Z.shape
+    if rescale and K > 2:
+        rescale = False
+    if rescale:
+        for j in range(T):
+            Tm = transform_mat(Z[:, :, j])
+            Z[:, :, j] = np.linalg.solve(Tm.T, Z[:, :, j].T).T
+    kept = kept_count(T, burnin_prop)
+    up, md, lo = np.zeros((n, K)), np.zeros((n, K)), np.zeros((n, K))
+    for i in range(n):
+        for j in range(K):
+            q = arma_quantile(Z[i, j, T - kept:], [alpha / 2, 0.5, 1 - alpha / 2])
+            up[i, j], md[i, j], lo[i, j] = q[2], q[1], q[0]
+    first = int(np.floor(T * burnin_prop + 0.5))
+    return dict(CI_Upper=up, CI_50=md, CI_Lower=lo, Z_trace=Z[:, :, first:])
+
+
+def bands(f, alpha, simultaneous):
+    """f: draws x time points"""
+    nt = f.shape[1]
+    if not simultaneous:
+        q = np.array([arma_quantile(f[:, i], [alpha / 2, 0.5, 1 - alpha / 2]) for i in range(nt)])
+        return q[:, 2], q[:, 1], q[:, 0]
+    mean, sd = f.mean(axis=0), f.std(axis=0, ddof=1)
+    C = np.max(np.abs((f - mean) / sd), axis=1)
+    q = arma_quantile(C, [1 - alpha])[0]
+    return mean + q * sd, mean, mean - q * sd
+
+
+def f_mean_ci(nu, B, k, alpha, rescale, simultaneous, burnin_prop, Z=None, X=None, eta=None, trans_mats=None):
+    """nu (K, P, T); B (n_time, P); eta (P, D, K, T); Z (n, K, T); X (n_x, D)"""
+    K, P, T = nu.shape
+    kept = kept_count(T, burnin_prop)
+    nu = np.array(nu[:, :, T - kept:], copy=True)
+    eta = None if eta is None else np.array(eta[..., T - kept:], copy=True)
+    if rescale and K > 2:
+        rescale = False
+    for j in range(kept):
+        Tm = None
+        if rescale:
+            Tm = transform_mat(Z[:, :, T - kept + j])
+        elif trans_mats is not None:
+            Tm = trans_mats[j * K:(j + 1) * K, :K]
+        if Tm is not None:
+            nu[:, :, j] = Tm @ nu[:, :, j]
+            if eta is not None:
+                for d in range(eta.shape[1]):
+                    eta[:, d, :, j] = (Tm @ eta[:, d, :, j].T).T
+    if X is None:
+        f = np.stack([B @ nu[k - 1, :, j] for j in range(kept)])
+        up, md, lo = bands(f, alpha, simultaneous)
+        return dict(CI_Upper=up, CI_50=md, CI_Lower=lo, mean_trace=f)
+    nx = X.shape[0]
+    nt = B.shape[0]
+    fs = np.zeros((nx, nt, kept))
+    for n_ in range(nx):
+        for j in range(kept):
+            fs[n_, :, j] = B @ (nu[k - 1, :, j] + eta[:, :, k - 1, j] @ X[n_])
+    up, md, lo = np.zeros((nx, nt)), np.zeros((nx, nt)), np.zeros((nx, nt))
+    for n_ in range(nx):
+        up[n_], md[n_], lo[n_] = bands(fs[n_].T, alpha, simultaneous)
+    return dict(CI_Upper=up, CI_50=md, CI_Lower=lo, mean_trace=fs)
