@@ -91,13 +91,17 @@ class CiArgs(C.Structure):
                 ("basis_degree", C.c_int32), ("n_internal_knots", C.c_int32), ("boundary_knots", c_double_p),
                 ("internal_knots", c_double_p), ("k", C.c_int32), ("alpha", C.c_double), ("rescale", C.c_int32),
                 ("simultaneous", C.c_int32), ("burnin_prop", C.c_double), ("X", c_double_p), ("n_x", C.c_int32), ("D", C.c_int32),
-                ("trans_mats", c_double_p), ("device", C.c_int32)]
+                ("trans_mats", c_double_p), ("device", C.c_int32), ("time2", c_double_p), ("n_time2", C.c_int32),
+                ("l", C.c_int32), ("m", C.c_int32)]
 
 
 POST_SYMBOLS = {
     "bfmmm_post_col_quantiles": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
     "bfmmm_post_bands": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                    c_double_p, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_post_cov_bands": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_int32, C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int32,
+                                       C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "bfmmm_FCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ci_defaults": (None, [C.POINTER(CiArgs)]),
     "bfmmm_SigmaCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ZCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
@@ -756,3 +760,23 @@ def FMeanCI(dir, n_files, time, basis_degree, boundary_knots, internal_knots, k,
         for nm in ("CI_Upper", "CI_50", "CI_Lower"):
             d[nm] = d[nm].reshape(-1)
     return d
+
+
+def FCovCI(dir, n_files, time1, time2, basis_degree, boundary_knots, internal_knots, l, m, alpha=0.05, rescale=True,
+           simultaneous=False, burnin_prop=0.1, trans_mats=None):
+    """src/PostProcessing.cpp:1781 (without covariates)."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    t1 = np.ascontiguousarray(time1, dtype=np.float64).reshape(-1)
+    t2 = np.ascontiguousarray(time2, dtype=np.float64).reshape(-1)
+    bk = np.ascontiguousarray(boundary_knots, dtype=np.float64)
+    ik = np.ascontiguousarray(internal_knots, dtype=np.float64)
+    keep += [t1, t2, bk, ik]
+    a.time, a.n_time, a.time2, a.n_time2 = t1.ctypes.data_as(c_double_p), len(t1), t2.ctypes.data_as(c_double_p), len(t2)
+    a.basis_degree, a.n_internal_knots = basis_degree, len(ik)
+    a.boundary_knots, a.internal_knots = bk.ctypes.data_as(c_double_p), ik.ctypes.data_as(c_double_p)
+    a.l, a.m, a.rescale, a.simultaneous = l, m, int(bool(rescale)), int(bool(simultaneous))
+    if trans_mats is not None:
+        tm = np.asfortranarray(trans_mats, dtype=np.float64)
+        keep.append(tm)
+        a.trans_mats = tm.ctypes.data_as(c_double_p)
+    return _ci_call(_lib_entry().bfmmm_FCovCI, a, keep)

@@ -141,6 +141,47 @@ extern "C" int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol
   return 0;
 }
 
+// V[t + T (s1 + n1 s2)] = sum_j A[(t M + j) + T M s1] * Bm[(t M + j) + T M s2]   (covariance surface of a draw, FCovCI)
+__global__ __launch_bounds__(QT) void k_bands_outer(const double* A, const double* Bm, int T, int M, int n1, double* V) {
+  const int cell = blockIdx.x, s1 = cell % n1, s2 = cell / n1;
+  const size_t TM = (size_t)T * M;
+  for (int t = blockIdx.y * QT + threadIdx.x; t < T; t += gridDim.y * QT) {
+    double s = 0.0;
+    for (int j = 0; j < M; ++j) s += A[(size_t)t * M + j + TM * s1] * Bm[(size_t)t * M + j + TM * s2];
+    V[(size_t)t + (size_t)T * cell] = s;
+  }
+}
+
+// pointwise (alpha / 2, 0.5, 1 - alpha / 2) or simultaneous bands of the columns of a device table df (T x ncol)
+static int table_bands(Bufs& b, const double* df, int T, int ncol, double alpha, int simultaneous, double* upper, double* mid, double* lower,
+                       const char* who) {
+  double *dp, *dq, *dm, *ds, *dC;
+  const double probs[3] = {alpha / 2, 0.5, 1 - alpha / 2}, p1[1] = {1 - alpha};
+  if (!b.put(&dp, simultaneous ? p1 : probs, simultaneous ? 1 : 3) || !b.put(&dq, nullptr, (size_t)3 * ncol) ||
+      !b.put(&dm, nullptr, (size_t)ncol) || !b.put(&ds, nullptr, (size_t)ncol) || !b.put(&dC, nullptr, (size_t)T))
+    return bfmmm_io_fail(std::string(who) + ": device allocation or copy failed");
+  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
+  std::vector<double> q((size_t)3 * ncol), m((size_t)ncol), s((size_t)ncol);
+  if (!simultaneous) {
+    hipLaunchKernelGGL(k_bands_quantiles, dim3(ncol), dim3(QT), sort_lds_bytes(T), 0, df, T, dp, 3, dq);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(q.data(), dq, sizeof(double) * 3 * ncol, hipMemcpyDeviceToHost) != hipSuccess)
+      return bfmmm_io_fail(std::string(who) + ": kernel launch or copy back failed");
+    for (int j = 0; j < ncol; ++j) { lower[j] = q[(size_t)3 * j]; mid[j] = q[(size_t)3 * j + 1]; upper[j] = q[(size_t)3 * j + 2]; }
+  } else {
+    hipLaunchKernelGGL(k_bands_moments, dim3(ncol), dim3(QT), 0, 0, df, T, dm, ds);
+    hipLaunchKernelGGL(k_bands_maxdev, dim3((T + QT - 1) / QT), dim3(QT), 0, 0, df, T, ncol, dm, ds, dC);
+    hipLaunchKernelGGL(k_bands_quantiles, dim3(1), dim3(QT), sort_lds_bytes(T), 0, dC, T, dp, 1, dq);
+    double qc = 0.0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&qc, dq, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(m.data(), dm, sizeof(double) * ncol, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(s.data(), ds, sizeof(double) * ncol, hipMemcpyDeviceToHost) != hipSuccess)
+      return bfmmm_io_fail(std::string(who) + ": kernel launch or copy back failed");
+    for (int j = 0; j < ncol; ++j) { lower[j] = m[(size_t)j] - qc * s[(size_t)j]; mid[j] = m[(size_t)j]; upper[j] = m[(size_t)j] + qc * s[(size_t)j]; }
+  }
+  if (hipGetLastError() != hipSuccess) return bfmmm_io_fail(std::string(who) + ": kernel launch failed");
+  return 0;
+}
+
 // coef: T x P (one row per draw); B: n_t x P row-major.  upper / mid / lower: n_t; trace: T x n_t column-major (draw fastest) or NULL
 extern "C" int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
                                 int32_t device, double* upper, double* mid, double* lower, double* trace) {
@@ -148,33 +189,37 @@ extern "C" int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const 
   if (T > TMAX) return bfmmm_io_fail("bfmmm_post_bands: at most 8192 kept draws in this build");
   if (select_device(device, "bfmmm_post_bands")) return 1;
   Bufs b;
-  double *dc, *dB, *df, *dp, *dq, *dm, *ds, *dC;
-  const double probs[3] = {alpha / 2, 0.5, 1 - alpha / 2}, p1[1] = {1 - alpha};
-  if (!b.put(&dc, coef, (size_t)T * P) || !b.put(&dB, B, (size_t)n_t * P) || !b.put(&df, nullptr, (size_t)T * n_t) ||
-      !b.put(&dp, simultaneous ? p1 : probs, simultaneous ? 1 : 3) || !b.put(&dq, nullptr, (size_t)3 * n_t) ||
-      !b.put(&dm, nullptr, (size_t)n_t) || !b.put(&ds, nullptr, (size_t)n_t) || !b.put(&dC, nullptr, (size_t)T))
+  double *dc, *dB, *df;
+  if (!b.put(&dc, coef, (size_t)T * P) || !b.put(&dB, B, (size_t)n_t * P) || !b.put(&df, nullptr, (size_t)T * n_t))
     return bfmmm_io_fail("bfmmm_post_bands: device allocation or copy failed");
-  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
   hipLaunchKernelGGL(k_bands_fsamp, dim3(n_t, std::min((T + QT - 1) / QT, 64)), dim3(QT), 0, 0, dB, dc, T, P, df);
-  std::vector<double> q((size_t)3 * n_t), m((size_t)n_t), s((size_t)n_t);
-  if (!simultaneous) {
-    hipLaunchKernelGGL(k_bands_quantiles, dim3(n_t), dim3(QT), sort_lds_bytes(T), 0, df, T, dp, 3, dq);
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(q.data(), dq, sizeof(double) * 3 * n_t, hipMemcpyDeviceToHost) != hipSuccess)
-      return bfmmm_io_fail("bfmmm_post_bands: kernel launch or copy back failed");
-    for (int j = 0; j < n_t; ++j) { lower[j] = q[(size_t)3 * j]; mid[j] = q[(size_t)3 * j + 1]; upper[j] = q[(size_t)3 * j + 2]; }
-  } else {
-    hipLaunchKernelGGL(k_bands_moments, dim3(n_t), dim3(QT), 0, 0, df, T, dm, ds);
-    hipLaunchKernelGGL(k_bands_maxdev, dim3((T + QT - 1) / QT), dim3(QT), 0, 0, df, T, n_t, dm, ds, dC);
-    hipLaunchKernelGGL(k_bands_quantiles, dim3(1), dim3(QT), sort_lds_bytes(T), 0, dC, T, dp, 1, dq);
-    double qc = 0.0;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&qc, dq, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(m.data(), dm, sizeof(double) * n_t, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(s.data(), ds, sizeof(double) * n_t, hipMemcpyDeviceToHost) != hipSuccess)
-      return bfmmm_io_fail("bfmmm_post_bands: kernel launch or copy back failed");
-    for (int j = 0; j < n_t; ++j) { lower[j] = m[(size_t)j] - qc * s[(size_t)j]; mid[j] = m[(size_t)j]; upper[j] = m[(size_t)j] + qc * s[(size_t)j]; }
-  }
-  if (hipGetLastError() != hipSuccess) return bfmmm_io_fail("bfmmm_post_bands: kernel launch failed");
+  if (table_bands(b, df, T, n_t, alpha, simultaneous, upper, mid, lower, "bfmmm_post_bands")) return 1;
   if (trace && hipMemcpy(trace, df, sizeof(double) * (size_t)T * n_t, hipMemcpyDeviceToHost) != hipSuccess)
     return bfmmm_io_fail("bfmmm_post_bands: copy back failed");
+  return 0;
+}
+
+// coefL, coefM: (T M) x P, row t M + j = the transformed Phi.slice(j).row(l - 1) / row(m - 1) of draw t; B1: n1 x P, B2: n2 x P.
+// upper / mid / lower: n1 x n2 column-major; trace: T x (n1 n2), draw fastest, or NULL
+extern "C" int bfmmm_post_cov_bands(const double* coefL, const double* coefM, int32_t T, int32_t M, int32_t P, const double* B1, int32_t n1,
+                                    const double* B2, int32_t n2, double alpha, int32_t simultaneous, int32_t device, double* upper, double* mid,
+                                    double* lower, double* trace) {
+  if (!coefL || !coefM || !B1 || !B2 || !upper || !mid || !lower || T < 2 || M < 1 || P < 1 || n1 < 1 || n2 < 1)
+    return bfmmm_io_fail("bfmmm_post_cov_bands: bad arguments");
+  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_cov_bands: at most 8192 kept draws in this build");
+  if (select_device(device, "bfmmm_post_cov_bands")) return 1;
+  Bufs b;
+  double *dl, *dm2, *dB1, *dB2, *dA, *dBm, *dV;
+  const size_t TM = (size_t)T * M, nc = (size_t)n1 * n2;
+  if (!b.put(&dl, coefL, TM * P) || !b.put(&dm2, coefM, TM * P) || !b.put(&dB1, B1, (size_t)n1 * P) || !b.put(&dB2, B2, (size_t)n2 * P) ||
+      !b.put(&dA, nullptr, TM * n1) || !b.put(&dBm, nullptr, TM * n2) || !b.put(&dV, nullptr, (size_t)T * nc))
+    return bfmmm_io_fail("bfmmm_post_cov_bands: device allocation or copy failed");
+  const int gy = (int)std::min<size_t>((TM + QT - 1) / QT, 64);
+  hipLaunchKernelGGL(k_bands_fsamp, dim3(n1, gy), dim3(QT), 0, 0, dB1, dl, (int)TM, P, dA);
+  hipLaunchKernelGGL(k_bands_fsamp, dim3(n2, gy), dim3(QT), 0, 0, dB2, dm2, (int)TM, P, dBm);
+  hipLaunchKernelGGL(k_bands_outer, dim3((unsigned)nc, std::min((T + QT - 1) / QT, 64)), dim3(QT), 0, 0, dA, dBm, T, M, n1, dV);
+  if (table_bands(b, dV, T, (int)nc, alpha, simultaneous, upper, mid, lower, "bfmmm_post_cov_bands")) return 1;
+  if (trace && hipMemcpy(trace, dV, sizeof(double) * (size_t)T * nc, hipMemcpyDeviceToHost) != hipSuccess)
+    return bfmmm_io_fail("bfmmm_post_cov_bands: copy back failed");
   return 0;
 }

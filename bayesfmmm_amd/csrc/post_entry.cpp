@@ -553,3 +553,86 @@ extern "C" int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   *out = r;
   return 0;
 }
+
+extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (ci_check(a, true)) return 1;
+  if (!a->time2 || a->n_time2 < 1) return bfmmm_io_fail("null argument");
+  if (a->X) return bfmmm_io_fail("FCovCI with covariates is not built in this library");
+  if (a->n_time > a->n_time2) return bfmmm_io_fail("FCovCI: 'time1' longer than 'time2' overruns the reference's CI_Lower (PostProcessing.cpp:1879); not supported");
+  const std::string dir = a->dir;
+  std::vector<double> sig;
+  int64_t d[3], nr, nc;
+  if (load_cat(dir, "Sigma", a->n_files, sig, d)) return 1;
+  const int T = (int)sig.size(), per_file = T / a->n_files;
+  std::vector<std::vector<double>> phi;                      // T cubes K x P x M
+  int K = 0, P = 0, M = 0;
+  for (int q = 0; q < a->n_files; ++q) {
+    std::vector<std::vector<double>> objs;
+    if (arma_load_field(dir + "Phi" + std::to_string(q) + ".txt", objs, &nr, &nc, d)) return 1;
+    if (q == 0) { K = (int)d[0]; P = (int)d[1]; M = (int)d[2]; }
+    if ((int)nr < per_file) return bfmmm_io_fail("'Phi<q>.txt' holds fewer draws than 'Sigma<q>.txt'");
+    for (int l = 0; l < per_file; ++l) phi.push_back(std::move(objs[(size_t)l]));
+  }
+  if (a->l <= 0) return bfmmm_io_fail("'l' must be positive");
+  if (a->l > K) return bfmmm_io_fail("'l' must be less than or equal to the number of clusters in the model");
+  if (a->m <= 0) return bfmmm_io_fail("'m' must be positive");
+  if (a->m > K) return bfmmm_io_fail("'m' must be less than or equal to the number of clusters in the model");
+  if (P != a->n_internal_knots + a->basis_degree + 1) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
+  const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
+  if (kept < 2) return bfmmm_io_fail("'burnin_prop' leaves fewer than two draws");
+  bool rescale = a->rescale != 0;
+  if (rescale && K > 2) rescale = false;
+  // Phi.slice(b) <- T Phi.slice(b) (rescale, :1884-1904) and then <- trans_mats_j Phi.slice(b) if given (:1905-1915: both apply)
+  std::vector<double> Z, Tm, tmp((size_t)K);
+  int n = 0;
+  if (rescale) {
+    int64_t dz[3];
+    if (load_cat(dir, "Z", a->n_files, Z, dz)) return 1;
+    n = (int)dz[0];
+  }
+  const size_t ld = (size_t)kept * K;
+  for (int j = 0; j < kept; ++j) {
+    double* ph = phi[(size_t)(first + j)].data();
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0) { if (!rescale) continue; transform_of(Z.data() + (size_t)n * K * (first + j), n, K, Tm); }
+      else { if (!a->trans_mats) continue; Tm.assign((size_t)K * K, 0.0); for (int i = 0; i < K; ++i) for (int c = 0; c < K; ++c) Tm[i + (size_t)K * c] = a->trans_mats[(size_t)j * K + i + ld * c]; }
+      for (int b = 0; b < M; ++b)
+        for (int p = 0; p < P; ++p) {
+          double* col = ph + (size_t)K * (p + (size_t)P * b);
+          for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * col[c]; tmp[(size_t)i] = s_; }
+          for (int i = 0; i < K; ++i) col[i] = tmp[(size_t)i];
+        }
+    }
+  }
+  std::vector<double> cl((size_t)kept * M * P), cmv((size_t)kept * M * P);
+  for (int j = 0; j < kept; ++j)
+    for (int b = 0; b < M; ++b)
+      for (int p = 0; p < P; ++p) {
+        const double* ph = phi[(size_t)(first + j)].data();
+        cl[((size_t)j * M + b) * P + p] = ph[(a->l - 1) + (size_t)K * (p + (size_t)P * b)];
+        cmv[((size_t)j * M + b) * P + p] = ph[(a->m - 1) + (size_t)K * (p + (size_t)P * b)];
+      }
+  const int n1 = a->n_time, n2 = a->n_time2;
+  const int32_t deg = a->basis_degree, nint = a->n_internal_knots;
+  auto basis = [&](const double* t, int nt, std::vector<double>& B) {
+    std::vector<double> cm((size_t)nt * P);
+    if (bfmmm_tensor_bspline(nt, 1, t, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
+    B.resize((size_t)nt * P);
+    for (int l = 0; l < nt; ++l)
+      for (int p = 0; p < P; ++p) B[(size_t)l * P + p] = cm[(size_t)l + (size_t)nt * p];
+    return 0;
+  };
+  std::vector<double> B1, B2;
+  if (basis(a->time, n1, B1) || basis(a->time2, n2, B2)) return 1;
+  std::vector<double> up((size_t)n1 * n2), md((size_t)n1 * n2), lo((size_t)n1 * n2), tr((size_t)kept * n1 * n2), cube((size_t)kept * n1 * n2);
+  if (bfmmm_post_cov_bands(cl.data(), cmv.data(), kept, M, P, B1.data(), n1, B2.data(), n2, a->alpha, a->simultaneous, a->device,
+                           up.data(), md.data(), lo.data(), tr.data())) return 1;
+  for (size_t c = 0; c < (size_t)n1 * n2; ++c)
+    for (int j = 0; j < kept; ++j) cube[c + (size_t)n1 * n2 * j] = tr[(size_t)j + (size_t)kept * c];
+  bfmmm_result* r = bfmmm_result_create();
+  put_mat(r, "CI_Upper", up, n1, n2); put_mat(r, "CI_50", md, n1, n2); put_mat(r, "CI_Lower", lo, n1, n2);
+  put_mat(r, "cov_trace", cube, n1, n2, kept);
+  *out = r;
+  return 0;
+}

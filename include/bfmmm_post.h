@@ -100,10 +100,16 @@ int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol, const dou
 int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
                      int32_t device, double* upper, double* mid, double* lower, double* trace);
 
+/* covariance surface between clusters l and m (FCovCI): coefL / coefM are (T M) x P, row t M + j = Phi.slice(j).row(l - 1) /
+ * row(m - 1) of draw t; upper / mid / lower n1 x n2 column-major; trace T x (n1 n2), draw fastest, or NULL */
+int bfmmm_post_cov_bands(const double* coefL, const double* coefM, int32_t T, int32_t M, int32_t P, const double* B1, int32_t n1,
+                         const double* B2, int32_t n2, double alpha, int32_t simultaneous, int32_t device, double* upper, double* mid,
+                         double* lower, double* trace);
+
 typedef struct {
   const char* dir;
   int32_t n_files;
-  const double* time;              /* FMeanCI: the n_time points of the band */
+  const double* time;              /* FMeanCI: the n_time points of the band; FCovCI: time1 */
   int32_t n_time;
   int32_t basis_degree, n_internal_knots;
   const double* boundary_knots;
@@ -117,6 +123,9 @@ typedef struct {
   int32_t n_x, D;
   const double* trans_mats;        /* FMeanCI: (kept draws * K) x K, column-major, or NULL */
   int32_t device;
+  const double* time2;             /* FCovCI: the second axis (n_time2 points) */
+  int32_t n_time2;
+  int32_t l, m;                    /* FCovCI: the two clusters, 1-based */
 } bfmmm_ci_args;
 
 void bfmmm_ci_defaults(bfmmm_ci_args* a);
@@ -126,6 +135,9 @@ void bfmmm_ci_defaults(bfmmm_ci_args* a);
 int bfmmm_SigmaCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_ZCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
+/* FCovCI (src/PostProcessing.cpp:1781) without covariates: "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace"
+ * (n_time x n_time2 x kept).  The reference allocates CI_Lower as n_time2 x n_time2 (:1879): n_time > n_time2 is refused here. */
+int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out);
 
 #ifdef __cplusplus
 }

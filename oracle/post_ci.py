@@ -105,3 +105,29 @@ def f_mean_ci(nu, B, k, alpha, rescale, simultaneous, burnin_prop, Z=None, X=Non
     for n_ in range(nx):
         up[n_], md[n_], lo[n_] = bands(fs[n_].T, alpha, simultaneous)
     return dict(CI_Upper=up, CI_50=md, CI_Lower=lo, mean_trace=fs)
+
+
+def f_cov_ci(Phi, B1, B2, l, m, alpha, rescale, simultaneous, burnin_prop, Z=None, trans_mats=None):
+    """FCovCI :1781-2050 without covariates.  Phi (K, P, M, T); both the rescale transform and trans_mats apply when given."""
+    K, P, M, T = Phi.shape
+    kept = kept_count(T, burnin_prop)
+    Phi = np.array(Phi[..., T - kept:], copy=True)
+    if rescale and K > 2:
+        rescale = False
+    n1, n2 = B1.shape[0], B2.shape[0]
+    cov = np.zeros((n1, n2, kept))
+    for j in range(kept):
+        if rescale:
+            Tm = transform_mat(Z[:, :, T - kept + j])
+            for b in range(M):
+                Phi[:, :, b, j] = Tm @ Phi[:, :, b, j]
+        if trans_mats is not None:
+            Tm = trans_mats[j * K:(j + 1) * K, :K]
+            for b in range(M):
+                Phi[:, :, b, j] = Tm @ Phi[:, :, b, j]
+        for b in range(M):
+            cov[:, :, j] += np.outer(B1 @ Phi[l - 1, :, b, j], B2 @ Phi[m - 1, :, b, j])
+    flat = cov.reshape(n1 * n2, kept, order="F").T             # draws x cells, cell = s1 + n1 s2
+    up, md, lo = bands(flat, alpha, simultaneous)
+    sh = lambda v: v.reshape(n1, n2, order="F")
+    return dict(CI_Upper=sh(up), CI_50=sh(md), CI_Lower=sh(lo), cov_trace=cov)

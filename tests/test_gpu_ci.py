@@ -115,6 +115,44 @@ def test_fmeanci_rescaled(k2_batches, mode, with_x):
             np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-10, atol=1e-12, err_msg=nm)
 
 
+@pytest.mark.parametrize("simultaneous", [False, True])
+def test_fcovci_on_the_reference_trace(simultaneous):
+    """FCovCI's documented example (R/RcppExports.R: time1 = time2 = seq(0, 990, 10), l = m = 1 on Functional_trace), rescale
+    off (no Z files in the shipped trace)."""
+    from bayesfmmm_amd import api
+    f = api.ReadFieldCube(TRACE + "Phi0.txt")
+    Phi = np.stack([f[l, 0] for l in range(f.shape[0])], axis=-1)
+    t1, t2 = np.arange(0.0, 1000.0, 40.0), np.arange(0.0, 1000.0, 30.0)
+    for l, m, burn in ((1, 1, 0.1), (1, 2, 0.4)):
+        got = api.FCovCI(TRACE, 1, t1, t2, 3, BK, IK, l, m, rescale=False, simultaneous=simultaneous, burnin_prop=burn)
+        ref = R.f_cov_ci(Phi, _basis(t1), _basis(t2), l, m, 0.05, False, simultaneous, burn)
+        for nm in ("CI_Upper", "CI_50", "CI_Lower", "cov_trace"):
+            assert got[nm].shape == ref[nm].shape, nm
+            np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-10, atol=1e-13, err_msg=nm)
+
+
+def test_fcovci_rescaled_and_transformed(k2_batches):
+    from bayesfmmm_amd import api
+    dirn, n_files = k2_batches
+    Z = _cat(dirn, n_files, "Z", api.ReadCube)
+    T = Z.shape[2]
+    Phi = np.zeros((2, 7, 3, T))
+    for q in range(n_files):
+        f = api.ReadFieldCube(f"{dirn}Phi{q}.txt")
+        for l in range(T // n_files):
+            Phi[..., q * (T // n_files) + l] = f[l, 0]
+    t1 = np.linspace(10.0, 990.0, 15)
+    kept = R.kept_count(T, 0.3)
+    rng = np.random.default_rng(9)
+    tm = np.concatenate([np.eye(2) + 0.1 * rng.standard_normal((2, 2)) for _ in range(kept)], axis=0)
+    for rescale, tmats, simultaneous in ((True, None, False), (True, tm, True), (False, tm, False)):
+        got = api.FCovCI(dirn, n_files, t1, t1, 3, BK, IK, 2, 1, alpha=0.1, rescale=rescale, simultaneous=simultaneous, burnin_prop=0.3,
+                         trans_mats=tmats)
+        ref = R.f_cov_ci(Phi, _basis(t1), _basis(t1), 2, 1, 0.1, rescale, simultaneous, 0.3, Z=Z, trans_mats=tmats)
+        for nm in ("CI_Upper", "CI_50", "CI_Lower", "cov_trace"):
+            np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-10, atol=1e-13, err_msg=nm)
+
+
 def test_ci_argument_checks_and_quantile_edges():
     from bayesfmmm_amd import _lib, api
     time = np.arange(0.0, 1000.0, 10.0)
