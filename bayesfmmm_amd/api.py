@@ -102,6 +102,7 @@ POST_SYMBOLS = {
     "bfmmm_post_cov_bands": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_int32, C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int32,
                                        C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
     "bfmmm_FCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_MVMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ci_defaults": (None, [C.POINTER(CiArgs)]),
     "bfmmm_SigmaCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ZCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
@@ -780,3 +781,18 @@ def FCovCI(dir, n_files, time1, time2, basis_degree, boundary_knots, internal_kn
         keep.append(tm)
         a.trans_mats = tm.ctypes.data_as(c_double_p)
     return _ci_call(_lib_entry().bfmmm_FCovCI, a, keep)
+
+
+def MVMeanCI(dir, n_files, alpha=0.05, rescale=True, burnin_prop=0.1, X=None):
+    """src/PostProcessing.cpp:1410.  With X the mean_trace is returned as (K, P, kept, n_x)."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    a.rescale = int(bool(rescale))
+    if X is not None:
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        keep.append(Xf)
+        a.X, a.n_x, a.D = Xf.ctypes.data_as(c_double_p), Xf.shape[0], Xf.shape[1]
+    d = _ci_call(_lib_entry().bfmmm_MVMeanCI, a, keep)
+    if X is not None:
+        K, P, tot = d["mean_trace"].shape
+        d["mean_trace"] = d["mean_trace"].reshape((K, P, tot // Xf.shape[0], Xf.shape[0]), order="F")
+    return d

@@ -636,3 +636,74 @@ extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   *out = r;
   return 0;
 }
+
+extern "C" int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!out) return bfmmm_io_fail("null argument");
+  if (ci_check(a, false)) return 1;
+  const std::string dir = a->dir;
+  std::vector<double> nu;
+  int64_t d[3], nr, nc;
+  if (load_cat(dir, "Nu", a->n_files, nu, d)) return 1;
+  const int K = (int)d[0], P = (int)d[1], per_file = (int)d[2], T = per_file * a->n_files;
+  const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
+  if (kept < 1) return bfmmm_io_fail("'burnin_prop' leaves no draws");
+  bool rescale = a->rescale != 0;
+  if (rescale && K > 2) rescale = false;
+  int D = 0;
+  std::vector<double> eta;
+  if (a->X) {
+    for (int q = 0; q < a->n_files; ++q) {
+      std::vector<std::vector<double>> objs;
+      int64_t de[3];
+      if (arma_load_field(dir + "Eta" + std::to_string(q) + ".txt", objs, &nr, &nc, de)) return 1;
+      if (q == 0) {
+        D = (int)de[1];
+        if (a->D != D) return bfmmm_io_fail("The number of columns in 'X' must be equal to the number of covariates in the model");
+      }
+      for (int l = 0; l < per_file; ++l)
+        if (q * per_file + l >= first) eta.insert(eta.end(), objs[(size_t)l].begin(), objs[(size_t)l].end());
+    }
+  }
+  std::vector<double> nuk(nu.begin() + (size_t)K * P * first, nu.end());
+  if (rescale) {
+    std::vector<double> Z, Tm, tmp((size_t)K);
+    int64_t dz[3];
+    if (load_cat(dir, "Z", a->n_files, Z, dz)) return 1;
+    const int n = (int)dz[0];
+    for (int j = 0; j < kept; ++j) {
+      transform_of(Z.data() + (size_t)n * K * (first + j), n, K, Tm);
+      for (int p = 0; p < P; ++p) {
+        double* col = nuk.data() + (size_t)K * P * j + (size_t)K * p;
+        for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * col[c]; tmp[(size_t)i] = s_; }
+        for (int i = 0; i < K; ++i) col[i] = tmp[(size_t)i];
+        for (int dd = 0; dd < D; ++dd) {
+          double* ej = eta.data() + (size_t)P * D * K * j + p + (size_t)P * dd;
+          for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * ej[(size_t)P * D * c]; tmp[(size_t)i] = s_; }
+          for (int i = 0; i < K; ++i) ej[(size_t)P * D * i] = tmp[(size_t)i];
+        }
+      }
+    }
+  }
+  const int nx = a->X ? a->n_x : 1, KP = K * P;
+  std::vector<double> V((size_t)kept * KP * nx), trace((size_t)KP * kept * nx);
+  for (int x = 0; x < nx; ++x)
+    for (int j = 0; j < kept; ++j)
+      for (int p = 0; p < P; ++p)
+        for (int k = 0; k < K; ++k) {
+          double v = nuk[(size_t)KP * j + k + (size_t)K * p];
+          for (int dd = 0; dd < D; ++dd) v += eta[(size_t)P * D * K * j + p + (size_t)P * (dd + (size_t)D * k)] * a->X[x + (size_t)nx * dd];
+          V[(size_t)j + (size_t)kept * (k + (size_t)K * p + (size_t)KP * x)] = v;
+          trace[(size_t)k + (size_t)K * p + (size_t)KP * (j + (size_t)kept * x)] = v;
+        }
+  const double probs[3] = {a->alpha / 2, 0.5, 1 - a->alpha / 2};
+  std::vector<double> q((size_t)3 * KP * nx);
+  if (bfmmm_post_col_quantiles(V.data(), kept, KP * nx, probs, 3, a->device, q.data())) return 1;
+  std::vector<double> up((size_t)KP * nx), md((size_t)KP * nx), lo((size_t)KP * nx);
+  for (size_t c = 0; c < (size_t)KP * nx; ++c) { lo[c] = q[3 * c]; md[c] = q[3 * c + 1]; up[c] = q[3 * c + 2]; }
+  bfmmm_result* r = bfmmm_result_create();
+  if (a->X) { put_mat(r, "CI_Upper", up, K, P, nx); put_mat(r, "CI_50", md, K, P, nx); put_mat(r, "CI_Lower", lo, K, P, nx); }
+  else { put_mat(r, "CI_Upper", up, K, P); put_mat(r, "CI_50", md, K, P); put_mat(r, "CI_Lower", lo, K, P); }
+  put_mat(r, "mean_trace", trace, K, P, (int64_t)kept * nx);
+  *out = r;
+  return 0;
+}

@@ -138,6 +138,9 @@ int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 /* FCovCI (src/PostProcessing.cpp:1781) without covariates: "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace"
  * (n_time x n_time2 x kept).  The reference allocates CI_Lower as n_time2 x n_time2 (:1879): n_time > n_time2 is refused here. */
 int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out);
+/* MVMeanCI (src/PostProcessing.cpp:1410): K x P matrices and "mean_trace" (K x P x kept); with X: K x P x n_x cubes and
+ * "mean_trace" as K x P x (kept n_x), the n_x cubes of the reference's field one after the other */
+int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 
 #ifdef __cplusplus
 }

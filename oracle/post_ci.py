@@ -131,3 +131,32 @@ def f_cov_ci(Phi, B1, B2, l, m, alpha, rescale, simultaneous, burnin_prop, Z=Non
     up, md, lo = bands(flat, alpha, simultaneous)
     sh = lambda v: v.reshape(n1, n2, order="F")
     return dict(CI_Upper=sh(up), CI_50=sh(md), CI_Lower=sh(lo), cov_trace=cov)
+
+
+def mv_mean_ci(nu, alpha, rescale, burnin_prop, Z=None, X=None, eta=None):
+    """MVMeanCI :1410-1660.  nu (K, P, T); eta (P, D, K, T); X (n_x, D)."""
+    K, P, T = nu.shape
+    kept = kept_count(T, burnin_prop)
+    nu = np.array(nu[:, :, T - kept:], copy=True)
+    eta = None if eta is None else np.array(eta[..., T - kept:], copy=True)
+    if rescale and K > 2:
+        rescale = False
+    if rescale:
+        for j in range(kept):
+            Tm = transform_mat(Z[:, :, T - kept + j])
+            nu[:, :, j] = Tm @ nu[:, :, j]
+            if eta is not None:
+                for d in range(eta.shape[1]):
+                    eta[:, d, :, j] = (Tm @ eta[:, d, :, j].T).T
+    probs = [alpha / 2, 0.5, 1 - alpha / 2]
+    if X is None:
+        q = np.array([[arma_quantile(nu[k, i, :], probs) for i in range(P)] for k in range(K)])
+        return dict(CI_Upper=q[..., 2], CI_50=q[..., 1], CI_Lower=q[..., 0], mean_trace=nu)
+    nx = X.shape[0]
+    ms = np.zeros((K, P, kept, nx))
+    for j in range(nx):
+        for i in range(kept):
+            for k in range(K):
+                ms[k, :, i, j] = nu[k, :, i] + eta[:, :, k, i] @ X[j]
+    q = np.array([[[arma_quantile(ms[k, i, :, j], probs) for j in range(nx)] for i in range(P)] for k in range(K)])
+    return dict(CI_Upper=q[..., 2], CI_50=q[..., 1], CI_Lower=q[..., 0], mean_trace=ms)

@@ -153,6 +153,27 @@ def test_fcovci_rescaled_and_transformed(k2_batches):
             np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-10, atol=1e-13, err_msg=nm)
 
 
+@pytest.mark.parametrize("rescale", [True, False])
+@pytest.mark.parametrize("with_x", [False, True])
+def test_mvmeanci_on_the_reference_trace(rescale, with_x):
+    """MVMeanCI's documented examples on the trace the package ships (inst/test-data/Multivariate_trace: K = 2, so the
+    default rescale path runs on the reference's own Z draws)."""
+    from bayesfmmm_amd import api
+    dirn = os.path.join(GOLD, "Multivariate_trace") + "/"
+    nu, Z = api.ReadCube(dirn + "Nu0.txt"), api.ReadCube(dirn + "Z0.txt")
+    X = np.array([[-1.0], [0.0], [2.5]]) if with_x else None
+    eta = None
+    if with_x:
+        f = api.ReadFieldCube(dirn + "Eta0.txt")
+        eta = np.stack([f[l, 0] for l in range(nu.shape[2])], axis=-1)
+    for alpha, burn in ((0.05, 0.1), (0.3, 0.5)):
+        got = api.MVMeanCI(dirn, 1, alpha=alpha, rescale=rescale, burnin_prop=burn, X=X)
+        ref = R.mv_mean_ci(nu, alpha, rescale, burn, Z=Z, X=X, eta=eta)
+        for nm in ("CI_Upper", "CI_50", "CI_Lower", "mean_trace"):
+            assert got[nm].shape == ref[nm].shape, (nm, got[nm].shape, ref[nm].shape)
+            np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-11, atol=1e-13, err_msg=nm)
+
+
 def test_ci_argument_checks_and_quantile_edges():
     from bayesfmmm_amd import _lib, api
     time = np.arange(0.0, 1000.0, 10.0)
