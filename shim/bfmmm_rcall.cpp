@@ -10,6 +10,8 @@
 //   _BayesFMMM_BMVMMM_Nu_Z_multiple_try (23, :680), _BMVMMM_Theta_est (27, :713), _BMVMMM_warm_start (33, :750)
 //   _BayesFMMM_BHDFMMM_Nu_Z_multiple_try (28, :552), _BHDFMMM_Theta_est (32, :590), _BHDFMMM_warm_start (38, :632)
 //   _BayesFMMM_FDIC / FAIC / FBIC (10 args, :174, :194, :214), _BayesFMMM_FLLik (9, :234)  -> bfmmm_FDIC ... (bfmmm_post.h)
+//   _BayesFMMM_ConditionalPredictiveOrdinates (11), MVLLik (5), MVDIC / MVAIC / MVBIC (6), SigmaCI (4), ZCI (5), FMeanCI (13),
+//   FCovCI (15), MVMeanCI (6)                                                          -> bfmmm_post.h
 //   _BayesFMMM_ReadVec / ReadMat / ReadCube / ReadFieldCube / ReadFieldMat / ReadFieldVec (1 arg each, :486-541)
 //
 // It is pure marshalling (no arithmetic): R lists of numeric vectors become CSR arrays, Rcpp::List arguments become
@@ -478,6 +480,110 @@ SEXP _BayesFMMM_FLLik(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_k
   return out;
 }
 
+// ---- CPO, multivariate criteria, credible intervals (RcppExports.cpp:17, :62, :78, :145, :159, :253-316) ---------------
+static SEXP value_vector(bfmmm_result* r) {
+  const double* d; int64_t cnt; const int64_t* dims; int nd;
+  bfmmm_result_get(r, "value", &d, &cnt, &dims, &nd);
+  SEXP out = PROTECT(Rf_allocVector(REALSXP, cnt));
+  memcpy(REAL(out), d, sizeof(double) * (size_t)cnt);
+  bfmmm_result_free(r);
+  UNPROTECT(1);
+  return out;
+}
+
+SEXP _BayesFMMM_ConditionalPredictiveOrdinates(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots,
+                                               SEXP time, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj, SEXP log_CPO) {
+  const Ragged y = flatten(Y), t = flatten(time);
+  bfmmm_post_args a;
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  bfmmm_result* r = NULL;
+  if (bfmmm_ConditionalPredictiveOrdinates(&a, Rf_asLogical(log_CPO) ? 1 : 0, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  return value_vector(r);
+}
+
+static void set_post_mv(bfmmm_post_args& a, SEXP dir, SEXP n_files, SEXP Y, SEXP X, SEXP cov_adj) {
+  bfmmm_post_defaults(&a);
+  a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files);
+  a.y = REAL(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
+  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+  a.cov_adj = Rf_asLogical(cov_adj) ? 1 : 0;
+}
+
+SEXP _BayesFMMM_MVLLik(SEXP dir, SEXP n_files, SEXP Y, SEXP X, SEXP cov_adj) {
+  bfmmm_post_args a;
+  set_post_mv(a, dir, n_files, Y, X, cov_adj);
+  bfmmm_result* r = NULL;
+  if (bfmmm_MVLLik(&a, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  return value_vector(r);
+}
+
+static SEXP mv_scalar(int (*fn)(const bfmmm_post_args*, double*), SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  bfmmm_post_args a;
+  set_post_mv(a, dir, n_files, Y, X, cov_adj);
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  double v = 0.0;
+  if (fn(&a, &v)) Rf_error("%s", bfmmm_entry_last_error());
+  return Rf_ScalarReal(v);
+}
+SEXP _BayesFMMM_MVDIC(SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) { return mv_scalar(bfmmm_MVDIC, dir, n_files, Y, burnin_prop, X, cov_adj); }
+SEXP _BayesFMMM_MVAIC(SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) { return mv_scalar(bfmmm_MVAIC, dir, n_files, Y, burnin_prop, X, cov_adj); }
+SEXP _BayesFMMM_MVBIC(SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) { return mv_scalar(bfmmm_MVBIC, dir, n_files, Y, burnin_prop, X, cov_adj); }
+
+static void set_ci(bfmmm_ci_args& a, SEXP dir, SEXP n_files, SEXP alpha, SEXP burnin_prop) {
+  bfmmm_ci_defaults(&a);
+  a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files); a.alpha = Rf_asReal(alpha); a.burnin_prop = Rf_asReal(burnin_prop);
+}
+static void set_ci_basis(bfmmm_ci_args& a, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP rescale, SEXP simultaneous,
+                         SEXP X, SEXP trans_mats) {
+  a.basis_degree = Rf_asInteger(basis_degree); a.boundary_knots = REAL(boundary_knots);
+  a.internal_knots = REAL(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
+  a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
+  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+  if (trans_mats != R_NilValue) a.trans_mats = REAL(trans_mats);
+}
+
+SEXP _BayesFMMM_SigmaCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP burnin_prop) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_SigmaCI(&a, &r), r, NULL);
+}
+SEXP _BayesFMMM_ZCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP burnin_prop) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  a.rescale = Rf_asLogical(rescale) ? 1 : 0;
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_ZCI(&a, &r), r, NULL);
+}
+SEXP _BayesFMMM_FMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP k, SEXP alpha,
+                        SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats);
+  a.time = REAL(time); a.n_time = Rf_length(time); a.k = Rf_asInteger(k);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_FMeanCI(&a, &r), r, NULL);
+}
+SEXP _BayesFMMM_FCovCI(SEXP dir, SEXP n_files, SEXP time1, SEXP time2, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP l,
+                       SEXP m, SEXP alpha, SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats);
+  a.time = REAL(time1); a.n_time = Rf_length(time1); a.time2 = REAL(time2); a.n_time2 = Rf_length(time2);
+  a.l = Rf_asInteger(l); a.m = Rf_asInteger(m);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_FCovCI(&a, &r), r, NULL);      // (with X the library reports that the covariate form is not built)
+}
+SEXP _BayesFMMM_MVMeanCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP burnin_prop, SEXP X) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  a.rescale = Rf_asLogical(rescale) ? 1 : 0;
+  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_MVMeanCI(&a, &r), r, NULL);    // (with X: mean_trace is one K x P x (kept n_x) cube, see bfmmm_post.h)
+}
+
 // ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
 SEXP _BayesFMMM_ReadVec(SEXP file) { return read_plain(file, true); }
 SEXP _BayesFMMM_ReadMat(SEXP file) { return read_plain(file, false); }
@@ -500,6 +606,16 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_FAIC", (DL_FUNC)&_BayesFMMM_FAIC, 10},
     {"_BayesFMMM_FBIC", (DL_FUNC)&_BayesFMMM_FBIC, 10},
     {"_BayesFMMM_FLLik", (DL_FUNC)&_BayesFMMM_FLLik, 9},
+    {"_BayesFMMM_ConditionalPredictiveOrdinates", (DL_FUNC)&_BayesFMMM_ConditionalPredictiveOrdinates, 11},
+    {"_BayesFMMM_MVLLik", (DL_FUNC)&_BayesFMMM_MVLLik, 5},
+    {"_BayesFMMM_MVDIC", (DL_FUNC)&_BayesFMMM_MVDIC, 6},
+    {"_BayesFMMM_MVAIC", (DL_FUNC)&_BayesFMMM_MVAIC, 6},
+    {"_BayesFMMM_MVBIC", (DL_FUNC)&_BayesFMMM_MVBIC, 6},
+    {"_BayesFMMM_SigmaCI", (DL_FUNC)&_BayesFMMM_SigmaCI, 4},
+    {"_BayesFMMM_ZCI", (DL_FUNC)&_BayesFMMM_ZCI, 5},
+    {"_BayesFMMM_FMeanCI", (DL_FUNC)&_BayesFMMM_FMeanCI, 13},
+    {"_BayesFMMM_FCovCI", (DL_FUNC)&_BayesFMMM_FCovCI, 15},
+    {"_BayesFMMM_MVMeanCI", (DL_FUNC)&_BayesFMMM_MVMeanCI, 6},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
