@@ -35,7 +35,8 @@ class EntryArgs(C.Structure):
                 ("seed", C.c_uint64), ("device", C.c_int32), ("chain_offset", C.c_int32), ("chain_stride", C.c_int32),
                 ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32),
                 ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32), ("dir", C.c_char_p),
-                ("dim", C.c_int32), ("basis_degree_hd", C.POINTER(C.c_int32)), ("n_internal_hd", C.POINTER(C.c_int32))]
+                ("dim", C.c_int32), ("basis_degree_hd", C.POINTER(C.c_int32)), ("n_internal_hd", C.POINTER(C.c_int32)),
+                ("progress_every", C.c_int32), ("progress_cb", C.c_void_p), ("progress_user", C.c_void_p)]
 
 
 ENTRY_SYMBOLS = {
@@ -261,6 +262,16 @@ def BFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_de
     return _call1(lib.bfmmm_BFMMM_Nu_Z_multiple_try, args)
 
 
+PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_double, C.c_void_p)
+
+
+def set_progress(args, every, fn):
+    """Attach a progress callback fn(iteration, loglik) -> truthy to abort (warm start; include/bfmmm_entry.h)."""
+    args._cb = PROGRESS_CB(lambda it, ll, user: 1 if fn(it, ll) else 0)
+    args.a.progress_every = int(every)
+    args.a.progress_cb = C.cast(args._cb, C.c_void_p)
+
+
 def _call1(fn, args, *prev):
     lib = _lib_entry()
     res = C.c_void_p()
@@ -293,7 +304,10 @@ def BFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen,
                      multiple_try, theta_est, X=None, burnin_prop=0.8, dir=None, **kw):
     """src/UserFunctions.cpp:1341.  Full sampler started at the posterior medians of stages 1 and 2."""
     lib = _lib_entry()
+    progress = kw.pop("progress", None)          # (every, fn(iteration, loglik) -> truthy to abort)
     args = _Args(2, tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, X, kw)
+    if progress is not None:
+        set_progress(args, *progress)
     args.a.burnin_prop = burnin_prop
     if dir is not None:      # <dir>Nu<q>.txt, ... are written as the reference does (string concatenation: end it with "/")
         args.dir = str(dir).encode()

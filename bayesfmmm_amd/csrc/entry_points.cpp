@@ -658,10 +658,22 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
     if (!r2 && i0 < i_end) r2 = bfmmm_run(h, mask_ws, i0, i_end - i0, a->seed, (uint32_t)a->chain_offset, 0, 1.0);
     return r2;
   };
-  bool io_failed = false;
+  bool io_failed = false, interrupted = false;
+  // run_range in pieces of progress_every iterations, the caller's callback in between (slot of iteration i: i - base)
+  auto run_reporting = [&](int i_begin, int i_end, int base) -> int {
+    if (!a->progress_cb || a->progress_every <= 0) return run_range(i_begin, i_end);
+    std::vector<double> ll((size_t)(i_end - base));
+    for (int b = i_begin; b < i_end; b += a->progress_every) {
+      const int e = std::min(b + a->progress_every, i_end);
+      if (run_range(b, e)) return 1;
+      if (bfmmm_get_chain(h, "loglik", e - base, ll.data(), (int64_t)ll.size())) return 1;
+      if (a->progress_cb(e - 1, ll[(size_t)(e - 1 - base)], a->progress_user)) { interrupted = true; return 1; }
+    }
+    return 0;
+  };
   if (!rc) {
     if (!batched) {
-      rc = run_range(0, T);
+      rc = run_reporting(0, T, 0);
     } else {
       // BFMMM.h:1680-1746: iteration i lives in slot i % r_stored_iters; whenever a batch is full (and i > 1) it is
       // thinned and saved, and the next batch reuses the slots
@@ -669,7 +681,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
       int q = 0;
       for (int b0 = 0; b0 < T && !rc; b0 += rs) {
         const int b1 = std::min(b0 + rs, T);
-        rc = bfmmm_set_slot_base(h, b0) || run_range(b0, b1);
+        rc = bfmmm_set_slot_base(h, b0) || run_reporting(b0, b1, b0);
         if (!rc && b1 - b0 == rs && b1 - 1 > 1) {
           if (save_batch(h, a, dir, q, rs)) { io_failed = true; rc = 1; }
           q += 1;
@@ -678,6 +690,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
     }
   }
   if (rc && io_failed) { bfmmm_destroy(h); return 1; }
+  if (rc && interrupted) { bfmmm_destroy(h); return efail("the run was interrupted by the progress callback"); }
   if (rc) { efail_lib(); bfmmm_destroy(h); return 1; }
   bfmmm_result* r = bfmmm_result_create();
   if (!batched) {

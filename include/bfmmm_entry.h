@@ -87,10 +87,16 @@ typedef struct {
    * curve after curve, the n_i x dim matrix of time points (column-major, as R stores each element of the `time` list);
    * basis_degree_hd / n_internal_hd have dim entries (the arma::vec `basis_degree` and the lengths of the
    * `internal_knots` list); internal_knots holds the dimensions' knots one after the other; boundary_knots is dim x 2
-   * row-major (lower, upper per dimension); basis_degree / n_internal_knots are ignored.  No covariates in this build. */
+   * row-major (lower, upper per dimension); basis_degree / n_internal_knots are ignored. */
   int32_t dim;
   const int32_t* basis_degree_hd;
   const int32_t* n_internal_hd;
+  /* warm start: every `progress_every` iterations (0: never) progress_cb(last iteration, its log-likelihood, progress_user)
+   * is called on the calling thread between device batches -- the counterpart of the reference's Rcpp::checkUserInterrupt() /
+   * Rcout progress lines (BFMMM.h:1674-1678); a non-zero return aborts the run with an error */
+  int32_t progress_every;
+  int (*progress_cb)(int32_t iter, double loglik, void* user);
+  void* progress_user;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:

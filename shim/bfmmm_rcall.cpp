@@ -214,10 +214,15 @@ void set_multivariate(bfmmm_entry_args& a, SEXP Y, SEXP n_eigen) {
   a.n_eigen = Rf_asInteger(n_eigen);
 }
 
+// R's interrupt check between device batches (the reference calls Rcpp::checkUserInterrupt() in its loop)
+static void check_interrupt_fn(void*) { R_CheckUserInterrupt(); }
+static int progress_from_R(int32_t, double, void*) { return R_ToplevelExec(check_interrupt_fn, NULL) ? 0 : 1; }
+
 void set_warm(bfmmm_entry_args& a, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans, SEXP r_stored_iters) {
   a.dir = (dir == R_NilValue) ? NULL : CHAR(STRING_ELT(dir, 0));
   a.thinning_num = Rf_asReal(thinning_num); a.beta_N_t = Rf_asReal(beta_N_t);
   a.N_t = Rf_asInteger(N_t); a.n_temp_trans = Rf_asInteger(n_temp_trans); a.r_stored_iters = Rf_asInteger(r_stored_iters);
+  a.progress_every = 100; a.progress_cb = progress_from_R;
 }
 
 SEXP finish(int rc, bfmmm_result* r, const std::vector<int64_t>* offsets, bfmmm_result* p1 = NULL, bfmmm_result* p2 = NULL) {

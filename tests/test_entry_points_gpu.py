@@ -141,3 +141,22 @@ def test_three_stage_pipeline_covariate_adjusted(example, covariance_adj):
     np.testing.assert_array_equal(tt["eta"][..., :40], mcmc["eta"][..., :40])
     with pytest.raises(Exception, match="'X' must be have 'n_funct' number of rows"):
         api.BFMMM_Nu_Z_multiple_try(T, 1, K, *common, X=X[:10])
+
+
+def test_warm_start_progress_callback(example):
+    """The ABI's counterpart of Rcpp::checkUserInterrupt() / the Rcout progress lines: called between device batches with the
+    last iteration and its log-likelihood; it changes nothing about the draws; a non-zero return aborts the run."""
+    from bayesfmmm_amd import _lib, api
+    e = example
+    T = 120
+    common = (e["K"], e["Y"], e["time"], e["n_funct"], e["basis_degree"], e["n_eigen"], e["boundary_knots"], e["internal_knots"])
+    est1 = api.BFMMM_Nu_Z_multiple_try(T, 1, *common, seed=3)
+    est2 = api.BFMMM_Theta_est(T, 1, *common, est1, seed=4)
+    plain = api.BFMMM_warm_start(T, *common, est1, est2, seed=5)
+    seen = []
+    rep = api.BFMMM_warm_start(T, *common, est1, est2, seed=5, progress=(50, lambda it, ll: seen.append((it, ll)) or False))
+    assert [it for it, _ in seen] == [49, 99, 119]
+    assert all(ll == plain["loglik"][it] for it, ll in seen)
+    np.testing.assert_array_equal(rep["nu"], plain["nu"])
+    with pytest.raises(_lib.BfmmmError, match="interrupted by the progress callback"):
+        api.BFMMM_warm_start(T, *common, est1, est2, seed=5, progress=(40, lambda it, ll: it >= 79))
