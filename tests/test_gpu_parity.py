@@ -168,3 +168,27 @@ def test_create_error_messages(bf):
     with pytest.raises(bf._lib.BfmmmError, match="less than or equal to first boundary knot"):
         cfg = bf.default_config(model=0, K=3, n_eigen=2, basis_degree=3, tot_mcmc_iters=10)
         bf.Sampler(cfg, sim["y"], sim["t"], [-5.0, 300.0], sim["boundary_knots"])
+
+
+def test_committed_oracle_fixture():
+    """The device against COMMITTED numbers: inputs, start state and expected chains of tests/golden/oracle_warm_sweep.npz
+    (n = 8 ragged curves, K = 2, P = 8, M = 3, two covariates, mean and covariance adjusted, 5 warm-start iterations, seed 17)."""
+    import os
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_warm_sweep.npz"))
+    n, K, P, M, D, T, seed = (int(x) for x in g["dims"])
+    off = g["offsets"]
+    y = [g["y"][off[i]:off[i + 1]] for i in range(n)]
+    t = [g["t"][off[i]:off[i + 1]] for i in range(n)]
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=3, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, y, t, g["internal_knots"], g["boundary_knots"])
+    smp.set_covariates(g["X"], True)
+    names = {"nu": "nu", "Phi": "Phi", "chi": "chi", "Z": "Z", "pi": "pi", "alpha_3": "alpha3", "delta": "delta", "A": "A",
+             "gamma": "gamma", "tau": "tau", "sigma_sq": "sigma", "eta": "eta", "xi": "xi", "tau_eta": "tau_eta",
+             "gamma_xi": "gamma_xi", "delta_xi": "delta_xi", "A_xi": "A_xi"}
+    smp.set_state(**{k: g["init_" + v] for k, v in names.items()})
+    smp.run(S.SWEEP_WARM | S.COV_MEAN | S.COV_XI, T, seed=seed)
+    for k, v in dict(names, loglik="loglik").items():
+        err = rel_err(smp.get_chain(k), g["chain_" + v])
+        assert err < 2e-6, (k, err)
