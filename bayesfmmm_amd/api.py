@@ -555,11 +555,8 @@ def BHDFMMM_warm_start(tot_mcmc_iters, K, Y, time, n_funct, basis_degree, n_eige
 
 
 # ---- likelihood-based post-processing (src/PostProcessing.cpp:3660-5114; include/bfmmm_post.h) ----------------------
-def post_pointwise(Y, B, nu, Phi, Z, chi, sigma, first_kept=0, X=None, eta=None, xi=None, device=0):
-    """bfmmm_post_pointwise on in-memory draws in the reference's shapes: nu (K, P, T), Phi (K, P, M, T), Z (n, K, T),
-    chi (n, M, T), sigma (T,), eta (P, D, K, T), xi (P, D, M, K, T).  Returns (llik (T,), mean_pdf, mean_fit) with the
-    per-observation arrays as lists shaped like Y."""
-    lib = _lib_entry()
+def _post_input(Y, B, nu, Phi, Z, chi, sigma, X=None, eta=None, xi=None, device=0):
+    """bfmmm_post_input over in-memory draws in the reference's shapes; returns (struct, arrays to keep alive)."""
     n = len(Y)
     off = np.zeros(n + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(v) for v in Y])
@@ -582,8 +579,19 @@ def post_pointwise(Y, B, nu, Phi, Z, chi, sigma, first_kept=0, X=None, eta=None,
         inp.X, inp.D = fa(X), np.asarray(X).shape[1]
         if eta is not None:
             inp.eta = fa(eta)
-        if xi is not None:      # (P, D, M, K, T) -> T x K cubes P x D x M
-            inp.xi = fa(np.transpose(np.asarray(xi), (0, 1, 2, 3, 4)))
+        if xi is not None:      # (P, D, M, K, T) in Fortran order is T x K cubes P x D x M
+            inp.xi = fa(xi)
+    return inp, keep
+
+
+def post_pointwise(Y, B, nu, Phi, Z, chi, sigma, first_kept=0, X=None, eta=None, xi=None, device=0):
+    """bfmmm_post_pointwise on in-memory draws in the reference's shapes: nu (K, P, T), Phi (K, P, M, T), Z (n, K, T),
+    chi (n, M, T), sigma (T,), eta (P, D, K, T), xi (P, D, M, K, T).  Returns (llik (T,), mean_pdf, mean_fit) with the
+    per-observation arrays as lists shaped like Y."""
+    lib = _lib_entry()
+    inp, keep = _post_input(Y, B, nu, Phi, Z, chi, sigma, X, eta, xi, device)
+    off, y = keep[0], keep[1]
+    n, T = len(Y), nu.shape[2]
     ll, pdf, fit = np.zeros(T), np.zeros(len(y)), np.zeros(len(y))
     _check(lib.bfmmm_post_pointwise(C.byref(inp), int(first_kept), ll.ctypes.data_as(c_double_p), pdf.ctypes.data_as(c_double_p),
                                     fit.ctypes.data_as(c_double_p)))

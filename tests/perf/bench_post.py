@@ -63,6 +63,25 @@ def main():
         out["cpu_port_draws_per_s"] = Tc / dt
         out["cpu_sample"] = f"{Tc} draws, FLLik only, 1 core"
         out["llik_rel_err_vs_port"] = float(np.max(np.abs(ll[:Tc] - ref) / np.abs(ref)))
+    # conditional predictive ordinates over the same draws (kept: the last 90 %)
+    inp, keep = api._post_input(w["y"], B, nu, Phi, Z, chi, sigma)
+    cpo = np.zeros(n)
+    t0 = time.perf_counter()
+    api._check(lib.bfmmm_post_cpo(api.C.byref(inp), T // 10, cpo.ctypes.data_as(api.c_double_p)))
+    out["cpo_call_wall_s"] = time.perf_counter() - t0
+    out["cpo_kernel_ms"] = lib.bfmmm_post_last_kernel_ms()
+    out["cpo_curve_draws_per_s_kernel"] = n * (T - T // 10) / out["cpo_kernel_ms"] * 1e3
+    # credible bands: 4096 kept draws x 1000 time points (column sort in LDS), wall time including the upload of the draws
+    Tb, nt = 4096, 1000
+    coef = np.ascontiguousarray(rng.standard_normal((Tb, P)))
+    tt = np.linspace(w["boundary_knots"][0], w["boundary_knots"][1], nt)
+    Bt = np.ascontiguousarray(api.TensorBSpline(tt.reshape(-1, 1), [3], [w["boundary_knots"]], [w["internal_knots"]]))
+    up, md, lo = np.zeros(nt), np.zeros(nt), np.zeros(nt)
+    for sim in (0, 1):
+        t0 = time.perf_counter()
+        api._check(lib.bfmmm_post_bands(coef.ctypes.data_as(api.c_double_p), Tb, P, Bt.ctypes.data_as(api.c_double_p), nt, 0.05, sim, 0,
+                                        up.ctypes.data_as(api.c_double_p), md.ctypes.data_as(api.c_double_p), lo.ctypes.data_as(api.c_double_p), None))
+        out["bands_simultaneous_wall_s" if sim else "bands_pointwise_wall_s"] = time.perf_counter() - t0
     print(json.dumps(out))
 
 
