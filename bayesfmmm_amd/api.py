@@ -93,7 +93,8 @@ class CiArgs(C.Structure):
                 ("internal_knots", c_double_p), ("k", C.c_int32), ("alpha", C.c_double), ("rescale", C.c_int32),
                 ("simultaneous", C.c_int32), ("burnin_prop", C.c_double), ("X", c_double_p), ("n_x", C.c_int32), ("D", C.c_int32),
                 ("trans_mats", c_double_p), ("device", C.c_int32), ("time2", c_double_p), ("n_time2", C.c_int32),
-                ("l", C.c_int32), ("m", C.c_int32)]
+                ("l", C.c_int32), ("m", C.c_int32), ("dim", C.c_int32), ("basis_degree_hd", C.POINTER(C.c_int32)),
+                ("n_internal_hd", C.POINTER(C.c_int32))]
 
 
 POST_SYMBOLS = {
@@ -104,6 +105,7 @@ POST_SYMBOLS = {
                                        C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
     "bfmmm_FCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_MVMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_HDFMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ci_defaults": (None, [C.POINTER(CiArgs)]),
     "bfmmm_SigmaCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ZCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
@@ -817,4 +819,33 @@ def MVMeanCI(dir, n_files, alpha=0.05, rescale=True, burnin_prop=0.1, X=None):
     if X is not None:
         K, P, tot = d["mean_trace"].shape
         d["mean_trace"] = d["mean_trace"].reshape((K, P, tot // Xf.shape[0], Xf.shape[0]), order="F")
+    return d
+
+
+def HDFMeanCI(dir, n_files, time, basis_degree, boundary_knots, internal_knots, k, alpha=0.05, rescale=True, simultaneous=False,
+              burnin_prop=0.1, X=None, trans_mats=None):
+    """src/PostProcessing.cpp:806: `time` n_time x dim, `basis_degree` a vector, `boundary_knots` dim x 2, `internal_knots` a list."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    dim = len(basis_degree)
+    t = np.asfortranarray(np.asarray(time, dtype=np.float64).reshape(-1, dim))
+    bk = np.ascontiguousarray(np.asarray(boundary_knots, dtype=np.float64).reshape(dim, 2))
+    ik = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for v in internal_knots]))
+    deg = (C.c_int32 * dim)(*[int(x) for x in basis_degree])
+    nint = (C.c_int32 * dim)(*[len(v) for v in internal_knots])
+    keep += [t, bk, ik, deg, nint]
+    a.time, a.n_time, a.dim, a.basis_degree_hd, a.n_internal_hd = t.ctypes.data_as(c_double_p), t.shape[0], dim, deg, nint
+    a.boundary_knots, a.internal_knots = bk.ctypes.data_as(c_double_p), ik.ctypes.data_as(c_double_p)
+    a.k, a.rescale, a.simultaneous = k, int(bool(rescale)), int(bool(simultaneous))
+    if X is not None:
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        keep.append(Xf)
+        a.X, a.n_x, a.D = Xf.ctypes.data_as(c_double_p), Xf.shape[0], Xf.shape[1]
+    if trans_mats is not None:
+        tm = np.asfortranarray(trans_mats, dtype=np.float64)
+        keep.append(tm)
+        a.trans_mats = tm.ctypes.data_as(c_double_p)
+    d = _ci_call(_lib_entry().bfmmm_HDFMeanCI, a, keep)
+    if X is None:
+        for nm in ("CI_Upper", "CI_50", "CI_Lower"):
+            d[nm] = d[nm].reshape(-1)
     return d

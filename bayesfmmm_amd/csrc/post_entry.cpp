@@ -358,6 +358,21 @@ int ci_check(const bfmmm_ci_args* a, bool basis) {       // order and wording of
   if (a->burnin_prop < 0 || a->burnin_prop >= 1) return bfmmm_io_fail("'burnin_prop' must be between 0 and 1");
   if (!basis) return 0;
   if (!a->time || a->n_time < 1 || !a->boundary_knots) return bfmmm_io_fail("null argument");
+  if (a->dim > 0) {      // HDFMeanCI, PostProcessing.cpp:836-852
+    if (!a->basis_degree_hd || !a->n_internal_hd) return bfmmm_io_fail("null argument");
+    size_t ko = 0;
+    for (int j = 0; j < a->dim; ++j) {
+      if (a->basis_degree_hd[j] < 1) return bfmmm_io_fail("'basis_degree' must be an integer greater than or equal to 1");
+      for (int i = 0; i < a->n_internal_hd[j]; ++i) {
+        if (a->boundary_knots[2 * j] >= a->internal_knots[ko + i])
+          return bfmmm_io_fail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+        if (a->boundary_knots[2 * j + 1] <= a->internal_knots[ko + i])
+          return bfmmm_io_fail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+      }
+      ko += (size_t)a->n_internal_hd[j];
+    }
+    return 0;
+  }
   if (a->basis_degree < 1) return bfmmm_io_fail("'basis_degree' must be an integer greater than or equal to 1");
   for (int i = 0; i < a->n_internal_knots; ++i) {
     if (a->boundary_knots[0] >= a->internal_knots[i])
@@ -461,7 +476,9 @@ extern "C" int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   const int K = (int)d[0], P = (int)d[1], per_file = (int)d[2], T = per_file * a->n_files;
   if (a->k <= 0) return bfmmm_io_fail("'k' must be positive");
   if (a->k > K) return bfmmm_io_fail("'k' must be less than or equal to the number of clusters in the model");
-  if (P != a->n_internal_knots + a->basis_degree + 1) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
+  int Pb = a->n_internal_knots + a->basis_degree + 1;
+  if (a->dim > 0) { Pb = 1; for (int j = 0; j < a->dim; ++j) Pb *= a->n_internal_hd[j] + a->basis_degree_hd[j] + 1; }
+  if (P != Pb) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
   const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
   if (kept < 2) return bfmmm_io_fail("'burnin_prop' leaves fewer than two draws");
   bool rescale = a->rescale != 0;
@@ -521,7 +538,8 @@ extern "C" int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   const int nt = a->n_time;
   std::vector<double> cm((size_t)nt * P), B((size_t)nt * P);
   const int32_t deg = a->basis_degree, nint = a->n_internal_knots;
-  if (bfmmm_tensor_bspline(nt, 1, a->time, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
+  if (a->dim > 0 ? bfmmm_tensor_bspline(nt, a->dim, a->time, a->basis_degree_hd, a->boundary_knots, a->n_internal_hd, a->internal_knots, cm.data())
+                 : bfmmm_tensor_bspline(nt, 1, a->time, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
   for (int l = 0; l < nt; ++l)
     for (int p = 0; p < P; ++p) B[(size_t)l * P + p] = cm[(size_t)l + (size_t)nt * p];
   const int k0 = a->k - 1, nx = a->X ? a->n_x : 1;
@@ -706,4 +724,9 @@ extern "C" int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   put_mat(r, "mean_trace", trace, K, P, (int64_t)kept * nx);
   *out = r;
   return 0;
+}
+
+extern "C" int bfmmm_HDFMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+  if (!a || a->dim <= 0) return bfmmm_io_fail("bfmmm_HDFMeanCI: args.dim must be positive");
+  return bfmmm_FMeanCI(a, out);
 }

@@ -126,6 +126,11 @@ typedef struct {
   const double* time2;             /* FCovCI: the second axis (n_time2 points) */
   int32_t n_time2;
   int32_t l, m;                    /* FCovCI: the two clusters, 1-based */
+  /* HDFMeanCI (dim > 0): `time` is n_time x dim column-major, boundary_knots dim x 2 row-major, internal_knots the dimensions'
+   * knots one after the other (as in bfmmm_entry_args); basis_degree / n_internal_knots are ignored */
+  int32_t dim;
+  const int32_t* basis_degree_hd;
+  const int32_t* n_internal_hd;
 } bfmmm_ci_args;
 
 void bfmmm_ci_defaults(bfmmm_ci_args* a);
@@ -135,6 +140,8 @@ void bfmmm_ci_defaults(bfmmm_ci_args* a);
 int bfmmm_SigmaCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_ZCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
+/* HDFMeanCI (src/PostProcessing.cpp:806): FMeanCI over the tensor-product basis (args.dim > 0) */
+int bfmmm_HDFMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 /* FCovCI (src/PostProcessing.cpp:1781) without covariates: "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace"
  * (n_time x n_time2 x kept).  The reference allocates CI_Lower as n_time2 x n_time2 (:1879): n_time > n_time2 is refused here. */
 int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out);

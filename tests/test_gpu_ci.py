@@ -174,6 +174,28 @@ def test_mvmeanci_on_the_reference_trace(rescale, with_x):
             np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-11, atol=1e-13, err_msg=nm)
 
 
+@pytest.mark.parametrize("rescale,simultaneous,with_x", [(True, False, False), (True, True, True), (False, False, True)])
+def test_hdfmeanci_on_the_reference_trace(rescale, simultaneous, with_x):
+    """HDFMeanCI's documented example (R/RcppExports.R:147-159: HDFunctional_trace, time = HDtime.RDS[[1]], quadratic splines with
+    knots 250/500/750 on (0, 990) in both dimensions, K = 2) on the trace the package ships, default rescale path included."""
+    from bayesfmmm_amd import api
+    dirn = os.path.join(GOLD, "HDFunctional_trace") + "/"
+    time = np.asarray(read_rds(os.path.join(GOLD, "HDtime.RDS"))[0], dtype=np.float64)
+    degs, bks, iks = [2, 2], [[0.0, 990.0], [0.0, 990.0]], [[250.0, 500.0, 750.0]] * 2
+    nu, Z = api.ReadCube(dirn + "Nu0.txt"), api.ReadCube(dirn + "Z0.txt")
+    B = np.ascontiguousarray(api.TensorBSpline(time, degs, bks, iks))
+    X = np.array([[-0.5], [1.0]]) if with_x else None
+    eta = None
+    if with_x:
+        f = api.ReadFieldCube(dirn + "Eta0.txt")
+        eta = np.stack([f[l, 0] for l in range(nu.shape[2])], axis=-1)
+    got = api.HDFMeanCI(dirn, 1, time, degs, bks, iks, 2, rescale=rescale, simultaneous=simultaneous, burnin_prop=0.2, X=X)
+    ref = R.f_mean_ci(nu, B, 2, 0.05, rescale, simultaneous, 0.2, Z=Z, X=X, eta=eta)
+    for nm in ("CI_Upper", "CI_50", "CI_Lower", "mean_trace"):
+        assert got[nm].shape == np.asarray(ref[nm]).shape, nm
+        np.testing.assert_allclose(got[nm], ref[nm], rtol=1e-10, atol=1e-12, err_msg=nm)
+
+
 def test_ci_argument_checks_and_quantile_edges():
     from bayesfmmm_amd import _lib, api
     time = np.arange(0.0, 1000.0, 10.0)
