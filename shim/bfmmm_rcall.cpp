@@ -589,6 +589,30 @@ SEXP _BayesFMMM_MVMeanCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP 
   return finish(bfmmm_MVMeanCI(&a, &r), r, NULL);    // (with X: mean_trace is one K x P x (kept n_x) cube, see bfmmm_post.h)
 }
 
+// HDFMeanCI (RcppExports.cpp: 13 arguments): time n_time x dim matrix, basis_degree a vector, boundary_knots dim x 2, internal_knots a list
+SEXP _BayesFMMM_HDFMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP k, SEXP alpha,
+                          SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  const int dim = Rf_length(basis_degree);
+  std::vector<int32_t> deg, nint;
+  std::vector<double> bk;
+  const Ragged ik = flatten(internal_knots);
+  for (int j = 0; j < dim; ++j) {
+    deg.push_back((int32_t)REAL(basis_degree)[j]);
+    nint.push_back((int32_t)(ik.off[j + 1] - ik.off[j]));
+    bk.push_back(REAL(boundary_knots)[j]); bk.push_back(REAL(boundary_knots)[j + dim]);
+  }
+  a.dim = dim; a.basis_degree_hd = deg.data(); a.n_internal_hd = nint.data();
+  a.boundary_knots = bk.data(); a.internal_knots = ik.v.data();
+  a.time = REAL(time); a.n_time = Rf_nrows(time); a.k = Rf_asInteger(k);
+  a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
+  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+  if (trans_mats != R_NilValue) a.trans_mats = REAL(trans_mats);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_HDFMeanCI(&a, &r), r, NULL);
+}
+
 // ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
 SEXP _BayesFMMM_ReadVec(SEXP file) { return read_plain(file, true); }
 SEXP _BayesFMMM_ReadMat(SEXP file) { return read_plain(file, false); }
@@ -621,6 +645,7 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_FMeanCI", (DL_FUNC)&_BayesFMMM_FMeanCI, 13},
     {"_BayesFMMM_FCovCI", (DL_FUNC)&_BayesFMMM_FCovCI, 15},
     {"_BayesFMMM_MVMeanCI", (DL_FUNC)&_BayesFMMM_MVMeanCI, 6},
+    {"_BayesFMMM_HDFMeanCI", (DL_FUNC)&_BayesFMMM_HDFMeanCI, 13},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
