@@ -140,7 +140,8 @@ void bfmmm_ci_defaults(bfmmm_ci_args* a);
 int bfmmm_SigmaCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_ZCI(const bfmmm_ci_args* a, bfmmm_result** out);
 int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
-/* HDFMeanCI (src/PostProcessing.cpp:806): FMeanCI over the tensor-product basis (args.dim > 0) */
+/* HDFMeanCI (src/PostProcessing.cpp:806): FMeanCI over the tensor-product basis (args.dim > 0).  The reference's function has no
+ * trans_mats argument (RcppExports.cpp:40); the field is honoured here if set. */
 int bfmmm_HDFMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 /* FCovCI (src/PostProcessing.cpp:1781) without covariates: "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace"
  * (n_time x n_time2 x kept).  The reference allocates CI_Lower as n_time2 x n_time2 (:1879): n_time > n_time2 is refused here. */

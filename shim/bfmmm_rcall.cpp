@@ -589,9 +589,9 @@ SEXP _BayesFMMM_MVMeanCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP 
   return finish(bfmmm_MVMeanCI(&a, &r), r, NULL);    // (with X: mean_trace is one K x P x (kept n_x) cube, see bfmmm_post.h)
 }
 
-// HDFMeanCI (RcppExports.cpp: 13 arguments): time n_time x dim matrix, basis_degree a vector, boundary_knots dim x 2, internal_knots a list
+// HDFMeanCI (RcppExports.cpp:40, 12 arguments -- no trans_mats): time n_time x dim matrix, basis_degree a vector, boundary_knots dim x 2, internal_knots a list
 SEXP _BayesFMMM_HDFMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP k, SEXP alpha,
-                          SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+                          SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X) {
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
   const int dim = Rf_length(basis_degree);
@@ -608,7 +608,6 @@ SEXP _BayesFMMM_HDFMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, 
   a.time = REAL(time); a.n_time = Rf_nrows(time); a.k = Rf_asInteger(k);
   a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
   if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
-  if (trans_mats != R_NilValue) a.trans_mats = REAL(trans_mats);
   bfmmm_result* r = NULL;
   return finish(bfmmm_HDFMeanCI(&a, &r), r, NULL);
 }
@@ -645,7 +644,7 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_FMeanCI", (DL_FUNC)&_BayesFMMM_FMeanCI, 13},
     {"_BayesFMMM_FCovCI", (DL_FUNC)&_BayesFMMM_FCovCI, 15},
     {"_BayesFMMM_MVMeanCI", (DL_FUNC)&_BayesFMMM_MVMeanCI, 6},
-    {"_BayesFMMM_HDFMeanCI", (DL_FUNC)&_BayesFMMM_HDFMeanCI, 13},
+    {"_BayesFMMM_HDFMeanCI", (DL_FUNC)&_BayesFMMM_HDFMeanCI, 12},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
