@@ -37,6 +37,7 @@ SYMBOLS = {
     "bfmmm_get_state": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int64]),
     "bfmmm_init_state": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]),
     "bfmmm_run": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_double]),
+    "bfmmm_prepare_run": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int]),
     "bfmmm_set_slot_base": (C.c_int, [C.c_void_p, C.c_int]),
     "bfmmm_create_from_basis": (C.c_int, [C.POINTER(BfmmmConfig), C.c_int, c_double_p, c_double_p, c_int64_p, C.c_int, C.c_int,
                                           c_double_p, C.c_int, C.POINTER(C.c_void_p)]),

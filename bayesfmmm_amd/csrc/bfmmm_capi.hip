@@ -27,7 +27,6 @@ void prepare_sweep_kernels();
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
-bool sweep_uses_lag(const Dims& d);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_loglik_flush(const Ctx& c, hipStream_t st);
 void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
@@ -82,6 +81,9 @@ struct bfmmm_handle {
   // fused runs (k_curve_chi of iteration i also does the Z update of iteration i + 1): k_curve_z once, then bodies
   // [pair_gram .. chi + Z] (gexecF one, gexecFN GRAPH_UNROLL of them), then the last iteration without Z (gexecL)
   hipGraphExec_t gexecF = nullptr, gexecFN = nullptr, gexecL = nullptr;
+  // the remainder of a run after the GRAPH_UNROLL-iteration graphs, as ONE graph of g_rem (fused: g_remF) iterations
+  hipGraphExec_t gexecR = nullptr, gexecFR = nullptr;
+  int g_rem = 0, g_remF = 0;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
@@ -273,7 +275,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
       dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) || dalloc(h, &c.Mmat, (size_t)d.A * 256 * 8) || dalloc(h, &c.Cperm, (size_t)d.A * 128 * 8) ||
+      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
       dalloc(h, &c.Lmat, (size_t)d.A * P * P))
     return 1;
   double* pm;
@@ -403,7 +405,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   HIPCHK(copy_sync(h, c.gamma_xi, ones.data(), sizeof(double) * K * P * D * M, hipMemcpyHostToDevice));
   HIPCHK(copy_sync(h, c.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
   HIPCHK(copy_sync(h, c.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
-  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL})
+  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR})
     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   h->g_valid = false;
   return 0;
@@ -413,7 +415,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL})
+  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL, h->gexecR, h->gexecFR})
     if (g) (void)hipGraphExecDestroy(g);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -688,7 +690,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
 }
 
 static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
-                    int phi_chi_zero, double beta, uint32_t tt_step) {
+                    int phi_chi_zero, double beta, uint32_t tt_step, bool prepare_only = false) {
   if (!h) return fail("bfmmm_run: null handle");
   if (n_iters < 0 || first_iter < h->slot_base || first_iter - h->slot_base + n_iters > h->T)
     return fail("bfmmm_run: iterations exceed the allocated chain");
@@ -705,19 +707,21 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   // without covariates the iteration ends with k_curve_chi: its scalar-job workgroup advances the counters and the
   // log-likelihood is reduced by the next iteration's k_pair_gram job (one kernel boundary less per iteration)
   c.defer_loglik = (c.d.D == 0) ? 1 : 0;
-  c.use_lag = sweep_uses_lag(c.d) ? 1 : 0;
   c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
   Dyn dyn;
-  if (dyn_get(h, dyn)) return 1;
-  dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
-  dyn.pend_dir = -1;
-  dyn.ll_pending = 0;
-  if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; h->state_dirty = false; }
-  dyn.znorm_valid = 0;
-  if (dyn_put(h, dyn)) return 1;
-  for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
-  HIPCHK(hipEventRecord(h->ev0, h->st));
+  if (!prepare_only) {
+    if (dyn_get(h, dyn)) return 1;
+    dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
+    dyn.pend_dir = -1;
+    dyn.ll_pending = 0;
+    if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; h->state_dirty = false; }
+    dyn.znorm_valid = 0;
+    if (dyn_put(h, dyn)) return 1;
+    for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
+    HIPCHK(hipEventRecord(h->ev0, h->st));
+  }
+  if (h->profile && prepare_only) return 0;
   if (h->profile) {
     // the same kernels as the graph path (including the fused chi + next-Z launches), bracketed by events
     const bool pfuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
@@ -738,7 +742,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   } else if (n_iters > 0) {
     const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
     if (!reuse) {
-      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL})
+      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR})
         if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
       h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_valid = true;
     }
@@ -750,33 +754,42 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
       for (int r = 0; r < reps; ++r) launch_iteration(h, c, plan, NKS, KS, h->st, nullptr, kind != 0, kind == 1);
-      HIPCHK(hipStreamEndCapture(h->st, &graph));
-      HIPCHK(hipGraphInstantiate(g, graph, nullptr, nullptr, 0));
+      const hipError_t ec = hipStreamEndCapture(h->st, &graph);      // always leaves capture mode, also after a failed launch
+      if (ec != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(ec); }
+      const hipError_t ei = hipGraphInstantiate(g, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
+      HIPCHK(ei);
       return 0;
     };
+    // a run of nrep repetitions = nrep / GRAPH_UNROLL replays of the unrolled graph + ONE graph holding the remainder
+    // (re-captured only when the remainder changes), so that a short run costs two or three graph launches, not one per iteration
+    auto ensure_rem = [&](hipGraphExec_t* g, int* have, int kind, int rem) -> int {
+      if (rem <= 0) return 0;
+      if (*g && *have != rem) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+      *have = rem;
+      return ensure(g, kind, rem);
+    };
     const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
+    const int nrep = fuse ? n_iters - 1 : n_iters;                  // fused run: n_iters - 1 bodies + the closing iteration
+    const int nfull = nrep / GRAPH_UNROLL, rem = nrep % GRAPH_UNROLL;
     if (!fuse) {
-      if (ensure(&h->gexec, 0, 1)) return 1;
-      int it = 0;
-      if (n_iters >= 2 * GRAPH_UNROLL) {
-        if (ensure(&h->gexecN, 0, GRAPH_UNROLL)) return 1;
-        for (; it + GRAPH_UNROLL <= n_iters; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
-      }
-      for (; it < n_iters; ++it) HIPCHK(hipGraphLaunch(h->gexec, h->st));
+      if ((nfull > 0 && ensure(&h->gexecN, 0, GRAPH_UNROLL)) || ensure_rem(&h->gexecR, &h->g_rem, 0, rem)) return 1;
     } else {
-      if (ensure(&h->gexecF, 1, 1) || ensure(&h->gexecL, 2, 1)) return 1;
+      if ((nfull > 0 && ensure(&h->gexecFN, 1, GRAPH_UNROLL)) || ensure_rem(&h->gexecFR, &h->g_remF, 1, rem) || ensure(&h->gexecL, 2, 1)) return 1;
+    }
+    if (prepare_only) return 0;
+    HIPCHK(hipEventRecord(h->ev0, h->st));
+    if (!fuse) {
+      for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
+      if (rem > 0) HIPCHK(hipGraphLaunch(h->gexecR, h->st));
+    } else {
       launch_curve(c, 0, plan.z_update, h->st);              // Z of the first iteration
-      int it = 0;
-      const int nb = n_iters - 1;                             // fused bodies
-      if (nb >= 2 * GRAPH_UNROLL) {
-        if (ensure(&h->gexecFN, 1, GRAPH_UNROLL)) return 1;
-        for (; it + GRAPH_UNROLL <= nb; it += GRAPH_UNROLL) HIPCHK(hipGraphLaunch(h->gexecFN, h->st));
-      }
-      for (; it < nb; ++it) HIPCHK(hipGraphLaunch(h->gexecF, h->st));
+      for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(h->gexecFN, h->st));
+      if (rem > 0) HIPCHK(hipGraphLaunch(h->gexecFR, h->st));
       HIPCHK(hipGraphLaunch(h->gexecL, h->st));
     }
   }
+  if (prepare_only) return 0;
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
@@ -806,6 +819,13 @@ extern "C" int bfmmm_set_slot_base(bfmmm_handle* h, int base) {
 extern "C" int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
                          int phi_chi_zero, double beta) {
   return run_impl(h, mask, first_iter, n_iters, seed, chain, phi_chi_zero, beta, 0);
+}
+
+// Captures and instantiates the HIP graphs a bfmmm_run with the same arguments replays (set-up, launches nothing): a caller
+// that times a run, or wants its first call to return quickly, pays the capture here instead.
+extern "C" int bfmmm_prepare_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+                                 int phi_chi_zero) {
+  return run_impl(h, mask, first_iter, n_iters, seed, chain, phi_chi_zero, 1.0, 0, true);
 }
 
 // Tempered-transition block of BFMMM_MTT_warm_start (BFMMM.h:1556-1657) for chain iteration `iter`, whose regular

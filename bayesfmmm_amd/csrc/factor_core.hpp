@@ -103,7 +103,7 @@ __device__ inline bool factor_wave(double* S, double* X, const double* zv, int P
     lzacc += xi * cur[BWT + 1];
 #pragma unroll
     for (int t = BWT; t >= 2; --t) xw[t] = xw[t - 1];
-    xw[1] = xi;
+    if constexpr (BWT >= 1) xw[1] = xi;
   }
   FCT(1);
   if (lane < P) Lz_out[lane] = lzacc;

@@ -409,20 +409,11 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   double* part = thp + A * PS;      // A x P  : (H_ab theta_b)[p]
   double* zv = part + AP;           // PP
   double* hb2 = zv + PP;            // P x W  : rows of H_aa
-  double* hbp = hb2 + P * W;        // 2 x P x W : rows of H_{a, p1}, H_{a, p2} (the two directions drawn before a; k_sweep_lag only)
-  double* dsc = hbp + (c.use_lag ? 2 * P * W : 0);    // 16     : delta(j, .)
+  double* dsc = hb2 + P * W;        // 16     : delta(j, .)
   const bool upd_nu = (mt == 0) && (c.mask & U_NU);
   const bool upd_phi = (mt > 0) && (c.mask & U_PHI);
   const bool upd = upd_nu || upd_phi;
   const Dyn* dyn = c.dyn;
-  // the directions drawn one and two steps before a in the sweep's order (-1: none)
-  int p1 = -1, p2 = -1;
-  if (c.use_lag) {
-    const int n_phi_s = ((c.mask & U_PHI) && MD > 1) ? K * M : 0;
-    const int rank = (mt >= 1) ? j * M + mt - 1 : n_phi_s + j;
-    if (rank >= 1) p1 = step_dir(d, rank - 1, n_phi_s);
-    if (rank >= 2) p2 = step_dir(d, rank - 2, n_phi_s);
-  }
   // ---- everything this workgroup needs from global memory is requested up front, in one batch ----
   constexpr int MAXI = (BW > 5) ? 1 : 4;          // (b, p) items per thread and pass (wide band: a row is 64 doubles)
   v2d hreg[MAXI][BW + 1];
@@ -501,11 +492,6 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
 #pragma unroll
           for (int k = 0; k <= BW; ++k) { hb2[p * W + 2 * k] = hreg[it][k].x; hb2[p * W + 2 * k + 1] = hreg[it][k].y; }
         }
-        if (b == p1 || b == p2) {
-          double* hp = hbp + ((b == p1) ? 0 : P * W);
-#pragma unroll
-          for (int k = 0; k <= BW; ++k) { hp[p * W + 2 * k] = hreg[it][k].x; hp[p * W + 2 * k + 1] = hreg[it][k].y; }
-        }
       }
     }
   }
@@ -551,38 +537,9 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c) {
   FST(5);
   __syncthreads();
   const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
-                                   c.Lz + (size_t)a * P, tid, c.use_lag ? S : nullptr);
+                                   c.Lz + (size_t)a * P, tid, nullptr);
   FST(6);
   if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
-  if (c.use_lag) {
-    // k_sweep_lag: M1_a = f C_a H_{a,p1}, M2_a = f C_a H_{a,p2} fold the two most recent draws of the sweep into
-    // direction a's draw, theta_a = base_a - M1_a delta_{p1} - M2_a delta_{p2}.  Stored thread-major for the sweep's
-    // row groups: chain thread t = 8 row + q owns [M1(row, q + 8u), u < 4 | M2(row, q + 8u), u < 4] (Mmat, 8 doubles),
-    // base thread t = 4 row + q owns C(row, q + 4u), u < 8 (Cperm, 8 doubles): every set is four 16-byte loads.
-    __syncthreads();
-    double* Mg = c.Mmat + (size_t)a * 256 * 8;
-    for (int e = tid; e < 256 * 8; e += 256) {
-      const int t = e >> 3, j8 = e & 7, which = j8 >> 2, u = j8 & 3;
-      const int r = t >> 3, col = (t & 7) + 8 * u;
-      double acc = 0.0;
-      if (r < P && col < P && (which == 0 ? p1 : p2) >= 0) {
-        const double* hp = hbp + which * P * W;
-#pragma unroll
-        for (int k2 = 0; k2 <= 2 * BW; ++k2) {
-          const int k = col - BW + k2;                 // H(k, col) = row k, entry BW + col - k
-          if (k >= 0 && k < P) acc += S[r + PP * k] * hp[k * W + 2 * BW - k2];
-        }
-        acc *= f;
-      }
-      Mg[e] = acc;
-    }
-    double* Cp = c.Cperm + (size_t)a * 128 * 8;
-    for (int e = tid; e < 128 * 8; e += 256) {
-      const int t = e >> 3, u = e & 7;
-      const int r = t >> 2, col = (t & 3) + 4 * u;
-      Cp[e] = (r < P && col < P) ? S[r + PP * col] : 0.0;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1271,287 +1228,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sweep_lag: the sweep of k_sweep_fast with the dependent chain cut down to ONE small matrix-vector product per
-// direction.  In k_sweep_fast a step is a round trip between two sets of waves (delta_a -> the rows of direction a+1
-// fold H_{a+1,a} delta_a into their residual and publish the next right-hand side -> C_{a+1} rhs), about 1750 clk.
-// Here the two most recent draws enter a direction's draw through matrices prepared by k_factor,
-//     theta_s = base_s - M1_s delta_{s-1} - M2_s delta_{s-2},     M1_s = f C_s H_{s,s-1},  M2_s = f C_s H_{s,s-2},
-//     base_s  = C_s f (r_s + H_ss theta_s) + L_s z_s   with r_s holding every draw up to s-3,
-// so that everything but the M products has at least one full step of slack:
-//   waves 0-1   (chain)  theta_s from base_s, M1_s, M2_s and the last two deltas; publishes delta_s
-//   waves 2-3   (base)   base_{s+1} = C_{s+1} rhs_{s+1} + L z           (rhs_{s+1} was published during step s-1)
-//   waves 4-15  (rows)   r_b -= H_{b,s-1} delta_{s-1} for EVERY row (one step late); the owner of step s+2 publishes
-//                        rhs_{s+2} = f (r + H theta)
-// Every role keeps its operands of the NEXT step (rows of M1 / M2, of C, of H) in the same 16 registers, requested
-// one step ahead with plain loads; one LDS barrier per step.  r follows the general kernel's definition
-// (r_a = t_a - sum_b H_ab theta_b over all b), so sigma^2's residual sum of squares is YY - sum_a theta_a'(t_a + r_a).
-// Requires P <= 32, A * P <= 640 and a band half-width <= 3.
-// STATUS (round 1): parity-green but NOT the default (opt in with the environment variable BFMMM_SWEEP_LAG): at
-// config 2 it takes 32 us against k_sweep_fast's 22 us, and k_factor pays 6 us for M1 / M2 / Cperm.  Measured on the
-// way: 55 us with column-major 8-byte operand loads; 63 us when the operand sets spilled to scratch (arrays passed by
-// reference); 37 us with thread-major 16-byte loads and compile-time indexed sets; 32 us with three sets (prefetch
-// distance two steps) and the chain on 8 lanes per row.  Phase clocks (tools/lag_stamps.py, -DLAG_STAMPS): L2 warm-up
-// 8-15 k, prologue 6-12 k, loop 43.7 k = 2080 clk per step, tail 3 k.  So the step is no shorter than k_sweep_fast's
-// 1750 clk although its dependent chain is: with 16 waves on one CU the fixed costs of a step -- a dozen dependent LDS
-// round trips for indices, deltas and hand-offs, the barrier, instruction issue at four waves per SIMD -- dominate
-// either formulation.  What it would take: the per-step indices in SGPRs ahead of time, deltas kept in registers of
-// the chain waves (DPP broadcast) instead of LDS, rows retiring after their step (incremental RSS) so that late steps
-// run with fewer waves, and a cheaper M product in k_factor.
-// ---------------------------------------------------------------------------------------------
-constexpr int LAG_THREADS = 1024, LAG_ROW0 = 384, LAG_ROWS = LAG_THREADS - LAG_ROW0;
-
-__device__ inline double dpp_quad_sum(double v) {     // sum over the 4 lanes of a quad
-  v = dpp_add<0xB1>(v);
-  v = dpp_add<0x4E>(v);
-  return v;
-}
-
-template <int BW>
-__global__ __launch_bounds__(LAG_THREADS) void k_sweep_lag(Ctx c) {
-  TIMELINE(c, 4);
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const Dims& d = c.d;
-  const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;
-  constexpr int W = 2 * BW + 2;
-  constexpr int DLS = 32 + 2 * BW + 2;
-  const int tid = threadIdx.x;
-  Dyn* dyn = c.dyn;
-  const int AP = A * P, PP2 = P * P;
-  double* th = smem;                         // A x P
-  double* lz = th + AP;                      // A x P
-  double* dlb = lz + AP;                     // 3 x DLS   deltas by step mod 3 (zero pads)
-  double* rhsb = dlb + 3 * DLS;              // 2 x 32    rhs by target step parity
-  double* baseb = rhsb + 64;                 // 2 x 32    base by target step parity
-  double* red = baseb + 64;                  // 16
-  int* sdir = (int*)(red + 16);              // step -> direction (+ 4 clamped entries)
-  int* brank = sdir + K * (M + 1) + 8;       // rank -> direction
-  const uint32_t slot = dyn->slot;
-  const uint32_t mask = c.mask;
-  const double beta = dyn->beta;
-  const double f = beta / dyn->sigma2;
-  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
-  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
-  const int n_nu = (mask & U_NU) ? K : 0;
-  const int n_steps = n_phi + n_nu;
-  {   // ranks follow the order of the steps (directions that are not updated come last), as in k_sweep_fast
-    const bool none_phi = (n_phi == 0 && MD > 1), none_nu = (n_nu == 0);
-    const int per_j = (none_phi ? MD - 1 : 0) + (none_nu ? 1 : 0);
-    for (int x = tid; x < A; x += LAG_THREADS) {
-      const int jx = x / MD, mx = x - jx * MD;
-      int rk;
-      if (mx >= 1 && !none_phi) rk = jx * M + mx - 1;
-      else if (mx == 0 && !none_nu) rk = n_phi + jx;
-      else rk = n_steps + jx * per_j + ((mx >= 1) ? (none_nu ? 1 : 0) + mx - 1 : 0);
-      brank[rk] = x;
-    }
-    for (int x = tid; x < n_steps + 4; x += LAG_THREADS) sdir[x] = step_dir(d, min(x, max(n_steps - 1, 0)), n_phi);
-    for (int x = tid; x < 3 * DLS + 128; x += LAG_THREADS) dlb[x] = 0.0;       // deltas, rhs and base buffers
-  }
-  __syncthreads();
-  // roles (wave-uniform)
-  const bool isChain = tid < 256, isBase = tid >= 256 && tid < LAG_ROW0;
-  const bool isRowW = tid >= LAG_ROW0;
-  // chain: 8 lanes per row (row = tid / 8); base: 4 lanes per row (row = (tid - 256) / 4)
-  const int mrow_raw = isChain ? (tid >> 3) : ((tid - 256) >> 2);
-  const int mrow = min(max(mrow_raw, 0), P - 1), mq = isChain ? (tid & 7) : (tid & 3);
-  const bool mrow_ok = mrow_raw >= 0 && mrow_raw < P;
-  const int e = min(max(tid - LAG_ROW0, 0), AP - 1);
-  const bool isRow = isRowW && tid - LAG_ROW0 < AP;
-  const int rk = e / P, p = e - rk * P;
-  const int b = brank[rk];
-  const int fd = full_dir(d, b);
-  const int eb = b * P + p;
-  double r_e = 0.0, hq_e = 0.0, tv_e = 0.0;
-  if (isRowW) {
-    r_e = c.rvec[eb]; hq_e = c.hq[eb]; tv_e = c.tvec[eb];
-    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[eb];
-    if (isRow) { th[eb] = t0; lz[eb] = l0; }
-  }
-  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
-  // the operands of a step, one set of registers for all roles (two sets, used alternately: the set of step t + 1 is
-  // requested at the start of step t and first touched at the start of step t + 1):
-  //   chain: [M1(mrow, mq + 4u) | M2(mrow, mq + 4u)] of the direction of step t      (thread-major, 16-byte loads)
-  //   base : C(mrow, mq + 4u) of the direction of step t + 1
-  //   rows : H2 row p of block (b, direction of step t - 1)
-  v2d ops[3][4];       // three sets (prefetch distance two steps), always indexed with compile-time constants
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { ops[0][u] = v2d{0.0, 0.0}; ops[1][u] = v2d{0.0, 0.0}; ops[2][u] = v2d{0.0, 0.0}; }
-  int* htab = brank + K * (M + 1);           // A x A : 16-byte offset of row p = 0 of block (b, a) in H2
-  for (int x = tid; x < A * A; x += LAG_THREADS) htab[x] = hrow(d, x / A, x % A) * P * W / 2;
-  __syncthreads();
-  static_assert(BW <= 3, "an operand set is four 16-byte values: band half-width <= 3");
-  // per-thread bases, so that a step's request is one scalar multiply away from its address
-  const v2d* Mthr = (const v2d*)(c.Mmat + (size_t)(tid & 255) * 8);
-  const v2d* Cthr = (const v2d*)(c.Cperm + (size_t)max(min(tid - 256, 127), 0) * 8);
-  const v2d* Hthr = (const v2d*)c.H2 + p * (W / 2);
-  const int* hrowb = htab + b * A;
-  auto sdir_at = [&](int t) { return __builtin_amdgcn_readfirstlane(sdir[min(max(t, 0), n_steps + 3)]); };   // wave-uniform
-  auto fetch = [&](auto which, int t) {       // operands used DURING step t, into set `which`
-    constexpr int Q = decltype(which)::value;
-    if (isChain) {
-      const v2d* Mg = Mthr + (size_t)sdir_at(t) * (256 * 4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ops[Q][u] = Mg[u];
-    } else if (isBase) {
-      const v2d* Cg = Cthr + (size_t)sdir_at(t + 1) * (128 * 4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ops[Q][u] = Cg[u];
-    } else {
-      const v2d* row = Hthr + hrowb[sdir_at(t - 1)];
-#pragma unroll
-      for (int k = 0; k <= BW && k < 4; ++k) ops[Q][k] = row[k];
-    }
-  };
-  // chain: sum over u < 4 of m(u) v[mq + 8u], m = 2 v2d; 8-lane sum
-  auto row_dot8 = [&](const v2d* m, const double* v) {
-    double acc = (m[0].x * v[mq] + m[0].y * v[mq + 8]) + (m[1].x * v[mq + 16] + m[1].y * v[mq + 24]);
-    acc = dpp_add<0xB1>(acc);
-    acc = dpp_add<0x4E>(acc);
-    return dpp_add<0x141>(acc);
-  };
-  // base: sum over u < 8 of m(u) v[mq + 4u], m = 4 v2d; 4-lane sum
-  auto row_dot4 = [&](const v2d* m, const double* v) {
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc += m[u].x * v[min(mq + 8 * u, 31)] + m[u].y * v[min(mq + 8 * u + 4, 31)];
-    return dpp_quad_sum(acc);
-  };
-  auto band_dot = [&](const v2d* h, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k <= BW && k < 4; ++k) v += h[k].x * dl[2 * k] + h[k].y * dl[2 * k + 1];
-    return v;
-  };
-  // one step with the operand set Q; set (Q + 2) % 3 receives the operands of step s + 2
-  auto step = [&](int s, auto which) {
-    constexpr int Q = decltype(which)::value;
-    const v2d* cur = ops[Q];
-    const int a = sdir_at(s);
-    fetch(std::integral_constant<int, (Q + 2) % 3>{}, s + 2);
-    if (isChain) {
-      const double* d1 = dlb + ((s + 2) % 3) * DLS + BW;           // delta_{s-1}
-      const double* d2 = dlb + ((s + 1) % 3) * DLS + BW;           // delta_{s-2}
-      const double acc = row_dot8(cur, d1) + row_dot8(cur + 2, d2);
-      if (mq == 0 && mrow_ok) {
-        const double nw = baseb[(s & 1) * 32 + mrow] - acc;
-        dlb[(s % 3) * DLS + BW + mrow] = nw - th[a * P + mrow];
-        th[a * P + mrow] = nw;
-      }
-    } else if (isBase) {
-      if (s + 1 < n_steps) {
-        const int an = sdir_at(s + 1);
-        const double v = row_dot4(cur, rhsb + ((s + 1) & 1) * 32);
-        if (mq == 0 && mrow_ok) baseb[((s + 1) & 1) * 32 + mrow] = v + lz[an * P + mrow];
-      }
-    } else {
-      // rows: the previous step's delta, one step late
-      if (s > 0) {
-        const double v = band_dot(cur, dlb + ((s + 2) % 3) * DLS + p);
-        r_e -= v;
-        if (b == sdir_at(s - 1)) hq_e += v;
-      }
-      if (isRow && s + 2 < n_steps && b == sdir_at(s + 2)) rhsb[((s + 2) & 1) * 32 + p] = f * (r_e + hq_e);
-    }
-    lds_barrier();
-  };
-#ifdef LAG_STAMPS
-#define LST(k) do { if (tid == 0 || tid == 640) dyn->stamps[40 + (k) + (tid ? 8 : 0)] = clock64(); } while (0)
-#else
-#define LST(k) do { } while (0)
-#endif
-  LST(0);
-  if (n_steps > 0) {
-    // H2, C and M were written by other XCDs (k_pg_reduce, k_factor): a first touch is a trip to memory, several times
-    // a step of the chain.  Touch them once with fire-and-forget loads (one 4-byte load per 128-byte line) so that the
-    // per-step requests only see L2 hits.
-    {
-      int w0 = 0;
-      auto touch = [&](const double* src, size_t count) {
-        const size_t nl = (count * 8 + 127) / 128;
-        for (size_t x = tid; x < nl; x += LAG_THREADS) {
-          const uint32_t o = (uint32_t)(x * 128);
-          asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
-        }
-      };
-      touch(c.H2, (size_t)d.R * P * W);
-      touch(c.Cperm, (size_t)A * 128 * 8);
-      touch(c.Mmat, (size_t)A * 256 * 8);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0) :: "memory");
-    }
-    // ---- prologue: rhs_0, rhs_1; base_0; the operands of step 0 ----
-    if (isRow) {
-      if (b == sdir[0]) rhsb[p] = f * (r_e + hq_e);
-      if (n_steps > 1 && b == sdir[1]) rhsb[32 + p] = f * (r_e + hq_e);
-    }
-    LST(1);
-    using Q0 = std::integral_constant<int, 0>;
-    using Q1 = std::integral_constant<int, 1>;
-    using Q2 = std::integral_constant<int, 2>;
-    if (isBase) fetch(Q2{}, -1);            // C of step 0's direction (set 2 is free until step 0 refills it)
-    fetch(Q0{}, 0);
-    fetch(Q1{}, 1);
-    __syncthreads();
-    if (isBase) {
-      const double v = row_dot4(ops[2], rhsb);
-      if (mq == 0 && mrow_ok) baseb[mrow] = v + lz[sdir[0] * P + mrow];
-    }
-    lds_barrier();
-    LST(2);
-    int s = 0;
-    for (; s + 2 < n_steps; s += 3) { step(s, Q0{}); step(s + 1, Q1{}); step(s + 2, Q2{}); }
-    if (s < n_steps) { step(s, Q0{}); ++s; }
-    if (s < n_steps) { step(s, Q1{}); ++s; }
-    LST(3);
-    // the last delta: the rows' operands "of step n_steps" (block (b, direction of the last step)) are in set n_steps % 3
-    if (isRowW) {
-      const double* dl = dlb + ((n_steps - 1) % 3) * DLS + p;
-      const int q3 = n_steps % 3;
-      const double v = (q3 == 0) ? band_dot(ops[0], dl) : ((q3 == 1) ? band_dot(ops[1], dl) : band_dot(ops[2], dl));
-      r_e -= v;
-      if (b == sdir[n_steps - 1]) hq_e += v;
-    }
-  }
-  __syncthreads();
-  // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
-  const double th_e = th[eb];
-  if (mask & U_SIGMA) {
-    double acc = isRow ? th_e * (tv_e + r_e) : 0.0;          // RSS = YY - sum_a theta_a'(t_a + r_a)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-      double qs = 0.0;
-      for (int w = 0; w < LAG_THREADS / 64; ++w) qs += red[w];
-      const double rss = c.YY - qs;
-      const bool tempered = (dyn->tt_step != 0);
-      const double bb = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
-      const double s2 = 1.0 / (sig_g * (1.0 / bb));
-      dyn->sigma2 = s2;
-      dyn->rss = rss;
-      c.c_sigma[slot] = s2;
-    }
-  } else if (tid == 0) {
-    c.c_sigma[slot] = dyn->sigma2;
-  }
-  LST(4);
-  // ---------------- publish theta and its chain slots -------------------------------------------
-  double* s_nu = c.c_nu + (size_t)slot * K * P;
-  double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
-  if (isRow) {
-    const int jj = b / MD, mt = b - jj * MD;
-    c.theta[(size_t)fd * P + p] = th_e;
-    if (mt == 0) s_nu[jj + (size_t)K * p] = th_e;
-    else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = th_e;
-  }
-  if (MD == 1)
-    for (int x = tid; x < K * P * M; x += LAG_THREADS) {
-      const int k = x % K, pm = x / K, pp = pm % P, m = pm / P;
-      s_phi[x] = c.theta[(size_t)(k * (M + 1) + m + 1) * P + pp];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_loglik: calcLikelihood = sum_il dnorm(y_il; mean_il, sqrt(sigma2), log)  and end-of-iteration
 // bookkeeping (advance the iteration counter / slot for graph replay).
 // ---------------------------------------------------------------------------------------------
@@ -1621,7 +1297,7 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
-  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (c.use_lag ? 3 : 1) * (size_t)c.d.P * W + 16) * sizeof(double);
+  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
@@ -1631,21 +1307,8 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   else launch_factor_pp<64>(c, grid, lds, st);
 }
 
-bool sweep_uses_lag(const Dims& d) { return d.P <= 32 && d.A * d.P <= LAG_ROWS && d.BW <= 3 && d.D == 0 && getenv("BFMMM_SWEEP_LAG") != nullptr; }
-
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
-  if (c.use_lag) {
-    const size_t lds = (2 * (size_t)d.A * d.P + 3 * (32 + 2 * d.BW + 2) + 128 + 16) * sizeof(double) +
-                       (2 * (size_t)d.K * (d.M + 1) + 16 + (size_t)d.A * d.A) * sizeof(int) + 16;
-    switch (d.BW) {
-      case 0: hipLaunchKernelGGL(k_sweep_lag<0>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      case 1: hipLaunchKernelGGL(k_sweep_lag<1>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      case 2: hipLaunchKernelGGL(k_sweep_lag<2>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-      default: hipLaunchKernelGGL(k_sweep_lag<3>, dim3(1), dim3(LAG_THREADS), lds, st, c); break;
-    }
-    return 0;
-  }
   if (d.BW == 0 && d.BWP == 0 && d.A <= 8 * DG_RPL && d.P <= 64) {        // diagonal model: independent scalar chains per coordinate
     const size_t lds = 16 * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
     hipLaunchKernelGGL(k_sweep_diag, dim3(1), dim3((8 * d.P + 63) / 64 * 64), lds, st, c);
@@ -1686,8 +1349,6 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
-  set_max_lds((const void*)k_sweep_lag<0>); set_max_lds((const void*)k_sweep_lag<1>); set_max_lds((const void*)k_sweep_lag<2>);
-  set_max_lds((const void*)k_sweep_lag<3>);
   set_max_lds((const void*)k_pair_gram);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);

@@ -116,9 +116,6 @@ struct Ctx {
   double* chi_norm;             // n x M  standard normals of this iteration's chi update (z_proposal.hpp)
   double* piprep;               // tables of the next iteration's pi / alpha_3 job (scalar_jobs.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
-  double* Mmat;                 // A x 256 x 8      M1_a, M2_a of k_sweep_lag, thread-major (kernels_sweep.hip)
-  double* Cperm;                // A x 128 x 8      C_a in the same thread-major order
-  int use_lag;                  // the sweep runs as k_sweep_lag (k_factor then prepares Mmat)
   double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty
   // ---- covariate adjustment (D > 0): eta_j[:,d] is direction (j, 0, d), xi_jm[:,d] is (j, m+1, d), weight

@@ -124,6 +124,10 @@ class Sampler:
     def run(self, mask, n_iters, first_iter=0, seed=1, chain=0, phi_chi_zero=False, beta=1.0):
         _lib.check(self.lib.bfmmm_run(self.h, mask, first_iter, n_iters, seed, chain, int(phi_chi_zero), beta))
 
+    def prepare_run(self, mask, n_iters, first_iter=0, seed=1, chain=0, phi_chi_zero=False):
+        """Captures the HIP graphs `run` with the same arguments replays (set-up only, launches nothing)."""
+        _lib.check(self.lib.bfmmm_prepare_run(self.h, mask, first_iter, n_iters, seed, chain, int(phi_chi_zero)))
+
     def set_slot_base(self, base):
         """Chain iteration i is written to slot i - base (on-disk batches reuse the slots, include/bfmmm.h)."""
         _lib.check(self.lib.bfmmm_set_slot_base(self.h, int(base)))

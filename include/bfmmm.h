@@ -124,6 +124,11 @@ int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain);
 int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
               int phi_chi_zero, double beta);
 
+/* Set-up half of bfmmm_run: captures and instantiates the HIP graphs a run with the same arguments replays and launches
+ * nothing (a caller that times bfmmm_run, or needs its first call to return quickly, pays the capture here). */
+int bfmmm_prepare_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
+                      int phi_chi_zero);
+
 /* Chain iteration i is written to slot i - base (default 0).  The reference keeps r_stored_iters draws in memory and
  * reuses the slots for every on-disk batch (`i % r_stored_iters`, BFMMM.h:1500-1746): a driver that saves batches
  * moves the base to the first iteration of the next batch; the RNG counter word stays the iteration index, so a

@@ -66,6 +66,7 @@ double orc_rtruncnorm(const orc_rng* r, uint32_t upd, uint32_t idx, double mu, d
 double orc_dtruncnorm_log(double x, double mu, double sd, double lo, double hi);
 double orc_pnorm(double x);
 /* test hooks */
+void   orc_rgamma_hook(int arm, uint32_t upd, const double* inject, double* rec_shape_scale, int cap);
 void   orc_test_fill(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t upd, int kind,
                      double p1, double p2, int count, double* out);
 

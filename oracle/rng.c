@@ -106,7 +106,21 @@ double orc_rnorm(const orc_rng* r, uint32_t upd, uint32_t idx) {
 /* R::rgamma(shape, scale) -- distribution only; algorithm = Marsaglia & Tsang (2000).
  * Call sites: Distributions.h:34, UpdateSigma.h:53, UpdateTau.h:31, UpdateGamma.h:29,
  * UpdateDelta.h:42,57. */
+/* Test hook (tests/test_oracle_pit_traces.py): while armed for update id `upd`, every gamma draw of that update records
+ * the (shape, scale) it was asked for and returns the caller's value for that index instead of sampling.  Feeding an
+ * update the reference package's own saved draws makes the restatement walk the reference's sequence of conditionals,
+ * so each recorded pair is the conditional law the restatement assigns to the reference's draw. */
+static struct { int armed; uint32_t upd; const double* inject; double* rec; int cap; } g_gamma_hook;
+void orc_rgamma_hook(int arm, uint32_t upd, const double* inject, double* rec_shape_scale, int cap) {
+  g_gamma_hook.armed = arm; g_gamma_hook.upd = upd; g_gamma_hook.inject = inject;
+  g_gamma_hook.rec = rec_shape_scale; g_gamma_hook.cap = cap;
+}
+
 double orc_rgamma(const orc_rng* r, uint32_t upd, uint32_t idx, double shape, double scale) {
+  if (g_gamma_hook.armed && upd == g_gamma_hook.upd && (int)idx < g_gamma_hook.cap) {
+    g_gamma_hook.rec[2 * idx] = shape; g_gamma_hook.rec[2 * idx + 1] = scale;
+    return g_gamma_hook.inject[idx];
+  }
   double a = shape, boost = 1.0, u0, u1;
   if (a < 1.0) {
     orc_block(r, upd, idx, ORC_BOOST_ATTEMPT, &u0, &u1);

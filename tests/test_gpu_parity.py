@@ -110,14 +110,6 @@ def test_single_update_matches_oracle(bf, which):
 
 
 @pytest.mark.parametrize("sweep", ["nu_z", "theta", "warm"])
-def test_lagged_sweep_kernel_matches_oracle(bf, sweep, monkeypatch):
-    """k_sweep_lag (kernels_sweep.hip; experimental, enabled with BFMMM_SWEEP_LAG): the same draws as the default sweep
-    kernel -- the two most recent directions enter a draw through the M1 / M2 matrices k_factor prepares."""
-    monkeypatch.setenv("BFMMM_SWEEP_LAG", "1")
-    test_short_trajectory_matches_oracle(bf, sweep)
-
-
-@pytest.mark.parametrize("sweep", ["nu_z", "theta", "warm"])
 def test_short_trajectory_matches_oracle(bf, sweep):
     S = bf.sampler
     T = 6
