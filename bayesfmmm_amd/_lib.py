@@ -31,6 +31,13 @@ SYMBOLS = {
     "bfmmm_create": (C.c_int, [C.POINTER(BfmmmConfig), C.c_int, c_double_p, c_double_p, c_int64_p, c_double_p,
                                c_double_p, C.POINTER(C.c_void_p)]),
     "bfmmm_destroy": (None, [C.c_void_p]),
+    "bfmmm_create_batch": (C.c_int, [C.POINTER(BfmmmConfig), C.c_int, c_double_p, c_double_p, c_int64_p, c_double_p,
+                                     c_double_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfmmm_create_from_basis_batch": (C.c_int, [C.POINTER(BfmmmConfig), C.c_int, c_double_p, c_double_p, c_int64_p, C.c_int,
+                                                C.c_int, c_double_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfmmm_select_chain": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfmmm_n_chains": (C.c_int, [C.c_void_p]),
+    "bfmmm_set_chain_id_stride": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bfmmm_set_covariates": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int]),
     "bfmmm_get_basis": (C.c_int, [C.c_void_p, c_double_p, C.c_int64]),
     "bfmmm_set_state": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int64]),

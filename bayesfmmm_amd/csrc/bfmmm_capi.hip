@@ -29,7 +29,7 @@ void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_loglik_flush(const Ctx& c, hipStream_t st);
-void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
+void launch_fill_slots(const Ctx& c, double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 void launch_cov_block(const Ctx& c, hipStream_t st);
 int cov_step_blocks(int nblk_curve);
 int cov_w2_chunks(int n);
@@ -68,7 +68,9 @@ struct bfmmm_handle {
   int device = 0;
   hipStream_t st = nullptr, st2 = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr, evD = nullptr;
-  Ctx c;                       // template context (full MD)
+  Ctx c;                       // template context (full MD); its per-chain pointers are those of chain 0 of the batch
+  int nch = 1;                 // chains in the batch (bfmmm_create_batch), all advanced in lockstep by bfmmm_run
+  int sel = 0;                 // the chain the state / chain accessors address (bfmmm_select_chain)
   int T = 0;
   int64_t n_obs = 0;
   // raw inputs kept on the device for bfmmm_get_basis
@@ -116,6 +118,27 @@ static int dalloc(bfmmm_handle* h, T** p, size_t count) {
   *p = (T*)q;
   return 0;
 }
+
+// Per-chain buffers come out of one arena per chain: the requests are collected first, then ONE allocation of
+// nch * stride bytes is made and the pointers of chain 0 are handed out; chain q's copy of every buffer sits q * stride
+// bytes further (Ctx::chain_bytes, chain_ctx in model.hpp).
+struct ArenaReq { void* slot; size_t bytes; };
+template <typename T>
+static void areq(std::vector<ArenaReq>& v, T** p, size_t count) { v.push_back({(void*)p, std::max<size_t>(count, 1) * sizeof(T)}); }
+static int arena_commit(bfmmm_handle* h, const std::vector<ArenaReq>& v, int nch, size_t* stride_out) {
+  size_t off = 0;
+  std::vector<size_t> offs;
+  for (const ArenaReq& r : v) { offs.push_back(off); off += (r.bytes + 255) & ~(size_t)255; }
+  char* base = nullptr;
+  HIPCHK(hipMalloc((void**)&base, off * (size_t)nch));
+  h->allocs.push_back(base);
+  HIPCHK(hipMemsetAsync(base, 0, off * (size_t)nch, h->st));
+  for (size_t i = 0; i < v.size(); ++i) { void* q = base + offs[i]; memcpy(v[i].slot, &q, sizeof q); }
+  *stride_out = off;
+  return 0;
+}
+// the context of the selected chain (host view)
+static Ctx selc(const bfmmm_handle* h) { return chain_ctx(h->c, (unsigned)h->sel); }
 
 extern "C" void bfmmm_config_defaults(bfmmm_config* cfg) {
   // defaults of BFMMM_Nu_Z_multiple_try / BFMMM_Theta_est / BFMMM_warm_start
@@ -168,26 +191,45 @@ struct BasisSpec {
 };
 
 static int create_impl(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
-                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, bfmmm_handle** out);
+                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, int n_chains,
+                       bfmmm_handle** out);
 
 extern "C" int bfmmm_create(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
                             const double* internal_knots, const double* boundary_knots, bfmmm_handle** out) {
-  return create_impl(cfg, device, y, t, offsets, internal_knots, boundary_knots, nullptr, out);
+  return create_impl(cfg, device, y, t, offsets, internal_knots, boundary_knots, nullptr, 1, out);
+}
+
+extern "C" int bfmmm_create_batch(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                                  const double* internal_knots, const double* boundary_knots, int n_chains, bfmmm_handle** out) {
+  return create_impl(cfg, device, y, t, offsets, internal_knots, boundary_knots, nullptr, n_chains, out);
 }
 
 extern "C" int bfmmm_create_from_basis(const bfmmm_config* cfg, int device, const double* y, const double* B, const int64_t* offsets,
                                        int P, int band, const double* Pmat, int pen_band, bfmmm_handle** out) {
+  return bfmmm_create_from_basis_batch(cfg, device, y, B, offsets, P, band, Pmat, pen_band, 1, out);
+}
+
+extern "C" int bfmmm_create_from_basis_batch(const bfmmm_config* cfg, int device, const double* y, const double* B, const int64_t* offsets,
+                                             int P, int band, const double* Pmat, int pen_band, int n_chains, bfmmm_handle** out) {
   if (!cfg || !y || !B || !offsets || !Pmat || !out) return fail("bfmmm_create_from_basis: null argument");
   if (cfg->model != BFMMM_MODEL_FUNCTIONAL) return fail("bfmmm_create_from_basis: functional model only");
   if (P < 1 || band < 0 || pen_band < 0) return fail("bfmmm_create_from_basis: bad dimensions");
   if (band > BWWIDE) return fail("bfmmm_create_from_basis: the band half-width of B'B must not exceed 31 in this build");
   BasisSpec bs = {P, band, pen_band, B, Pmat};
-  return create_impl(cfg, device, y, nullptr, offsets, nullptr, nullptr, &bs, out);
+  return create_impl(cfg, device, y, nullptr, offsets, nullptr, nullptr, &bs, n_chains, out);
 }
 
+// frees the handle on every early return of create_impl / bfmmm_set_covariates' callers (released on success)
+struct HandleGuard {
+  bfmmm_handle* h;
+  ~HandleGuard() { if (h) bfmmm_destroy(h); }
+};
+
 static int create_impl(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
-                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, bfmmm_handle** out) {
+                       const double* internal_knots, const double* boundary_knots, const BasisSpec* bs, int n_chains,
+                       bfmmm_handle** out) {
   if (!cfg || !out || !y) return fail("bfmmm_create: null argument");
+  if (n_chains < 1 || n_chains > 4096) return fail("bfmmm_create_batch: n_chains must be between 1 and 4096");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail("bfmmm_create: no HIP device available (the sampler has no CPU fallback)");
@@ -229,9 +271,11 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   prepare_cov_kernels();
   { hipError_t e0 = hipGetLastError(); if (e0 != hipSuccess) fprintf(stderr, "[bfmmm] note: kernel attribute setup reported %s\n", hipGetErrorString(e0)); }
   bfmmm_handle* h = new bfmmm_handle();
+  HandleGuard guard{h};        // every early return below frees the handle, its streams, events and device memory
   h->cfg = *cfg;
   h->device = device;
   h->T = cfg->tot_mcmc_iters;
+  h->nch = n_chains;
   HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->evA));
@@ -266,18 +310,28 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   double* rec; int* ni;
   if (dalloc(h, &rec, (size_t)n * d.LREC) || dalloc(h, &ni, n)) return 1;
   c.rec = rec; c.ni = ni;
-  if (dalloc(h, &c.dyn, 1)) return 1;
-  if (dalloc(h, &c.Z, (size_t)n * K) || dalloc(h, &c.chi, (size_t)n * M) || dalloc(h, &c.theta, (size_t)K * (M + 1) * P) ||
-      dalloc(h, &c.delta, (size_t)K * M) || dalloc(h, &c.Aa, (size_t)K * 2) || dalloc(h, &c.gamma, (size_t)K * P * M))
-    return 1;
+  // per-chain buffers (one arena per chain of the batch): state, work space, chain storage
+  std::vector<ArenaReq> ar;
+  areq(ar, &c.dyn, 1);
+  areq(ar, &c.Z, (size_t)n * K); areq(ar, &c.chi, (size_t)n * M); areq(ar, &c.theta, (size_t)K * (M + 1) * P);
+  areq(ar, &c.delta, (size_t)K * M); areq(ar, &c.Aa, (size_t)K * 2); areq(ar, &c.gamma, (size_t)K * P * M);
   int NTG, NKS, KS;
   pg_geometry(d, NTG, NKS, KS);
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
-  if (dalloc(h, &c.logz_part, (size_t)c.nblk_curve * K) || dalloc(h, &c.rss_part, c.nblk_curve) ||
-      dalloc(h, &c.pg_part, h->pg_part_doubles) || dalloc(h, &c.H, (size_t)d.R * d.LG) || dalloc(h, &c.H2, (size_t)d.R * P * (2 * d.BW + 2)) ||
-      dalloc(h, &c.tvec, (size_t)d.A * P) || dalloc(h, &c.rvec, (size_t)d.A * P) || dalloc(h, &c.hq, (size_t)d.A * P) || dalloc(h, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8) || dalloc(h, &c.zprep, (size_t)(3 * K + 5) * n) || dalloc(h, &c.chi_norm, (size_t)n * M) || dalloc(h, &c.piprep, 9 * KMAX + 16) || dalloc(h, &c.Lz, (size_t)d.A * P) || dalloc(h, &c.Cmat, (size_t)d.A * P * P) ||
-      dalloc(h, &c.Lmat, (size_t)d.A * P * P))
-    return 1;
+  areq(ar, &c.logz_part, (size_t)c.nblk_curve * K); areq(ar, &c.rss_part, c.nblk_curve);
+  areq(ar, &c.pg_part, h->pg_part_doubles); areq(ar, &c.H, (size_t)d.R * d.LG); areq(ar, &c.H2, (size_t)d.R * P * (2 * d.BW + 2));
+  areq(ar, &c.tvec, (size_t)d.A * P); areq(ar, &c.rvec, (size_t)d.A * P); areq(ar, &c.hq, (size_t)d.A * P);
+  areq(ar, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8); areq(ar, &c.zprep, (size_t)(3 * K + 5) * n);
+  areq(ar, &c.chi_norm, (size_t)n * M); areq(ar, &c.piprep, 9 * KMAX + 16); areq(ar, &c.Lz, (size_t)d.A * P);
+  areq(ar, &c.Cmat, (size_t)d.A * P * P); areq(ar, &c.Lmat, (size_t)d.A * P * P);
+  {
+    const size_t T = (size_t)h->T;
+    areq(ar, &c.c_nu, T * K * P); areq(ar, &c.c_chi, T * n * M); areq(ar, &c.c_Z, T * n * K); areq(ar, &c.c_pi, T * K);
+    areq(ar, &c.c_alpha3, T); areq(ar, &c.c_delta, T * K * M); areq(ar, &c.c_A, T * K * 2); areq(ar, &c.c_sigma, T);
+    areq(ar, &c.c_tau, T * K); areq(ar, &c.c_gamma, T * K * P * M); areq(ar, &c.c_Phi, T * K * P * M); areq(ar, &c.c_loglik, T);
+  }
+  if (arena_commit(h, ar, n_chains, &c.chain_bytes)) return 1;
+  c.chain_bytes_cov = 0; c.chain_id_stride = 1; c.nch = n_chains;
   double* pm;
   if (dalloc(h, &pm, (size_t)P * P)) return 1;
   c.Pmat = pm;
@@ -293,12 +347,6 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
     }
     HIPCHK(copy_sync(h, pm, Pm.data(), sizeof(double) * Pm.size(), hipMemcpyHostToDevice));
   }
-  const size_t T = (size_t)h->T;
-  if (dalloc(h, &c.c_nu, T * K * P) || dalloc(h, &c.c_chi, T * n * M) || dalloc(h, &c.c_Z, T * n * K) ||
-      dalloc(h, &c.c_pi, T * K) || dalloc(h, &c.c_alpha3, T) || dalloc(h, &c.c_delta, T * K * M) ||
-      dalloc(h, &c.c_A, T * K * 2) || dalloc(h, &c.c_sigma, T) || dalloc(h, &c.c_tau, T * K) ||
-      dalloc(h, &c.c_gamma, T * K * P * M) || dalloc(h, &c.c_Phi, T * K * P * M) || dalloc(h, &c.c_loglik, T))
-    return 1;
 
   // ---- upload data, compute statistics on the device ----
   if (dalloc(h, &h->d_y, (size_t)n_obs)) return 1;
@@ -353,7 +401,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   HIPCHK(copy_sync(h, &herr, d_err, sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(copy_sync(h, &c.YY, d_yy, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(copy_sync(h, cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
-  if (herr) { bfmmm_destroy(h); return fail("at least one time point lies outside 'boundary_knots'"); }
+  if (herr) return fail("at least one time point lies outside 'boundary_knots'");
   d.n_obs_total = cnt[0];
   d.half_sum = cnt[1];
   // neutral starting state (everything 1 / 0) so that a run before set_state is well defined
@@ -361,7 +409,9 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   memset(&dyn0, 0, sizeof dyn0);
   dyn0.beta = 1; dyn0.sigma2 = 1; dyn0.alpha3 = 1;
   for (int k = 0; k < KMAX; ++k) { dyn0.pi[k] = 1.0 / K; dyn0.tau[k] = 1; }
-  HIPCHK(copy_sync(h, c.dyn, &dyn0, sizeof dyn0, hipMemcpyHostToDevice));
+  for (int q = 0; q < n_chains; ++q)
+    HIPCHK(copy_sync(h, chain_ctx(c, (unsigned)q).dyn, &dyn0, sizeof dyn0, hipMemcpyHostToDevice));
+  guard.h = nullptr;
   *out = h;
   return 0;
 }
@@ -389,22 +439,27 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   if (dalloc(h, &Xd, n * D)) return 1;
   HIPCHK(copy_sync(h, Xd, X, sizeof(double) * n * D, hipMemcpyHostToDevice));
   c.X = Xd;
-  if (dalloc(h, &c.thetaX, K * (M + 1) * D * P) || dalloc(h, &c.tau_eta, K * D) || dalloc(h, &c.gamma_xi, K * P * D * M) ||
-      dalloc(h, &c.delta_xi, K * M * D) || dalloc(h, &c.A_xi, K * 2 * D) || dalloc(h, &c.stil, n * P) ||
-      dalloc(h, &c.yyp_part, (size_t)c.nblk_curve) || dalloc(h, &c.cfull, n * P) || dalloc(h, &c.gfull, n * P) ||
-      dalloc(h, &c.w2_part, (size_t)c.NPAIR * c.NB2 * d.LG) || dalloc(h, &c.H2aa, (size_t)c.NPAIR * d.LG) ||
-      dalloc(h, &c.Wdir, n * (size_t)c.A2) || dalloc(h, &c.gstd2, K * D + K * M * D + K * D * P * M) ||
-      dalloc(h, &c.C2, (size_t)c.A2 * P * P + 2) || dalloc(h, &c.Lz2, (size_t)c.A2 * P) ||
-      dalloc(h, &c.step_part, 2 * (size_t)c.NBS * (D * P + 1)) || dalloc(h, &c.thetaN, K * (M + 1) * D * P) || dalloc(h, &c.delta_cur, P + 2) ||
-      dalloc(h, &c.c_eta, T * P * D * K) || dalloc(h, &c.c_xi, T * K * P * D * M) || dalloc(h, &c.c_tau_eta, T * K * D) ||
-      dalloc(h, &c.c_gamma_xi, T * K * P * D * M) || dalloc(h, &c.c_delta_xi, T * K * M * D) || dalloc(h, &c.c_A_xi, T * K * 2 * D))
-    return 1;
+  // per-chain buffers of the covariate blocks: a second arena per chain (Ctx::chain_bytes_cov)
+  std::vector<ArenaReq> ar;
+  areq(ar, &c.thetaX, K * (M + 1) * D * P); areq(ar, &c.tau_eta, K * D); areq(ar, &c.gamma_xi, K * P * D * M);
+  areq(ar, &c.delta_xi, K * M * D); areq(ar, &c.A_xi, K * 2 * D); areq(ar, &c.stil, n * P);
+  areq(ar, &c.yyp_part, (size_t)c.nblk_curve); areq(ar, &c.cfull, n * P); areq(ar, &c.gfull, n * P);
+  areq(ar, &c.w2_part, (size_t)c.NPAIR * c.NB2 * d.LG); areq(ar, &c.H2aa, (size_t)c.NPAIR * d.LG);
+  areq(ar, &c.Wdir, n * (size_t)c.A2); areq(ar, &c.gstd2, K * D + K * M * D + K * D * P * M);
+  areq(ar, &c.C2, (size_t)c.A2 * P * P + 2); areq(ar, &c.Lz2, (size_t)c.A2 * P);
+  areq(ar, &c.step_part, 2 * (size_t)c.NBS * (D * P + 1)); areq(ar, &c.thetaN, K * (M + 1) * D * P); areq(ar, &c.delta_cur, P + 2);
+  areq(ar, &c.c_eta, T * P * D * K); areq(ar, &c.c_xi, T * K * P * D * M); areq(ar, &c.c_tau_eta, T * K * D);
+  areq(ar, &c.c_gamma_xi, T * K * P * D * M); areq(ar, &c.c_delta_xi, T * K * M * D); areq(ar, &c.c_A_xi, T * K * 2 * D);
+  if (arena_commit(h, ar, h->nch, &c.chain_bytes_cov)) { d.D = 0; return 1; }
   // neutral state: eta = xi = 0, tau_eta = gamma_xi = delta_xi = A_xi = 1 (BFMMM.h:3705-3722, 3896-3915)
   std::vector<double> ones(std::max({K * D, K * P * D * M, K * M * D, K * 2 * D}), 1.0);
-  HIPCHK(copy_sync(h, c.tau_eta, ones.data(), sizeof(double) * K * D, hipMemcpyHostToDevice));
-  HIPCHK(copy_sync(h, c.gamma_xi, ones.data(), sizeof(double) * K * P * D * M, hipMemcpyHostToDevice));
-  HIPCHK(copy_sync(h, c.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
-  HIPCHK(copy_sync(h, c.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
+  for (int q = 0; q < h->nch; ++q) {
+    const Ctx cq = chain_ctx(c, (unsigned)q);
+    HIPCHK(copy_sync(h, cq.tau_eta, ones.data(), sizeof(double) * K * D, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, cq.gamma_xi, ones.data(), sizeof(double) * K * P * D * M, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, cq.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, cq.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
+  }
   for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR})
     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   h->g_valid = false;
@@ -438,27 +493,42 @@ extern "C" int bfmmm_get_basis(bfmmm_handle* h, double* out, int64_t capacity) {
   if (!h->B_host.empty()) { std::copy(h->B_host.begin(), h->B_host.end(), out); return 0; }
   HIPCHK(hipSetDevice(h->device));
   double* dB = nullptr; double* rec_tmp = nullptr; int* ni_tmp = nullptr; int* err = nullptr;
-  HIPCHK(hipMalloc((void**)&dB, sizeof(double) * (size_t)need));
-  HIPCHK(hipMalloc((void**)&rec_tmp, sizeof(double) * (size_t)d.n * d.LREC));
-  HIPCHK(hipMalloc((void**)&ni_tmp, sizeof(int) * (size_t)d.n));
-  HIPCHK(hipMalloc((void**)&err, sizeof(int)));
-  HIPCHK(hipMemset(err, 0, sizeof(int)));
+  struct Tmp { void* p[4] = {nullptr, nullptr, nullptr, nullptr}; ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); } } tmp;   // freed on every path
+  HIPCHK(hipMalloc((void**)&dB, sizeof(double) * (size_t)need)); tmp.p[0] = dB;
+  HIPCHK(hipMalloc((void**)&rec_tmp, sizeof(double) * (size_t)d.n * d.LREC)); tmp.p[1] = rec_tmp;
+  HIPCHK(hipMalloc((void**)&ni_tmp, sizeof(int) * (size_t)d.n)); tmp.p[2] = ni_tmp;
+  HIPCHK(hipMalloc((void**)&err, sizeof(int))); tmp.p[3] = err;
+  HIPCHK(hipMemsetAsync(err, 0, sizeof(int), h->st));
   launch_stats_functional(h->cfg.basis_degree, d.n, d.P, d.LREC, h->d_off, h->d_t, h->d_y, h->d_knots, h->n_knots,
                           rec_tmp, ni_tmp, dB, err, h->st);
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(copy_sync(h, out, dB, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
-  (void)hipFree(dB); (void)hipFree(rec_tmp); (void)hipFree(ni_tmp); (void)hipFree(err);
   return 0;
 }
 
 // ---- state marshalling ----------------------------------------------------------------------
-static int dyn_get(bfmmm_handle* h, Dyn& dyn) {
+// q < 0: the selected chain
+static int dyn_get(bfmmm_handle* h, Dyn& dyn, int q = -1) {
   HIPCHK(hipStreamSynchronize(h->st));
-  HIPCHK(copy_sync(h, &dyn, h->c.dyn, sizeof dyn, hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(h, &dyn, chain_ctx(h->c, (unsigned)(q < 0 ? h->sel : q)).dyn, sizeof dyn, hipMemcpyDeviceToHost));
   return 0;
 }
-static int dyn_put(bfmmm_handle* h, const Dyn& dyn) {
-  HIPCHK(copy_sync(h, h->c.dyn, &dyn, sizeof dyn, hipMemcpyHostToDevice));
+static int dyn_put(bfmmm_handle* h, const Dyn& dyn, int q = -1) {
+  HIPCHK(copy_sync(h, chain_ctx(h->c, (unsigned)(q < 0 ? h->sel : q)).dyn, &dyn, sizeof dyn, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int bfmmm_select_chain(bfmmm_handle* h, int q) {
+  if (!h) return fail("bfmmm_select_chain: null handle");
+  if (q < 0 || q >= h->nch) return fail("bfmmm_select_chain: chain index outside the batch");
+  h->sel = q;
+  return 0;
+}
+extern "C" int bfmmm_n_chains(const bfmmm_handle* h) { return h ? h->nch : 0; }
+extern "C" int bfmmm_set_chain_id_stride(bfmmm_handle* h, uint32_t stride) {
+  if (!h || stride < 1) return fail("bfmmm_set_chain_id_stride: bad arguments");
+  h->c.chain_id_stride = stride;
+  h->g_valid = false;
   return 0;
 }
 
@@ -466,14 +536,15 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
   if (!h || !name || !v) return fail("bfmmm_set_state: null argument");
   h->state_dirty = true;
   HIPCHK(hipSetDevice(h->device));
-  const Dims& d = h->c.d;
+  const Ctx cs = selc(h);       // the selected chain of the batch
+  const Dims& d = cs.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M;
   const std::string s(name);
   auto need = [&](int64_t want) { return count == want ? 0 : fail("bfmmm_set_state(" + s + "): wrong element count"); };
   HIPCHK(hipStreamSynchronize(h->st));
   if (s == "nu" || s == "Phi") {
     std::vector<double> th((size_t)K * (M + 1) * P);
-    HIPCHK(copy_sync(h, th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, th.data(), cs.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
     if (s == "nu") {
       if (need((int64_t)K * P)) return 1;
       for (int j = 0; j < K; ++j)
@@ -484,13 +555,13 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
         for (int m = 0; m < M; ++m)
           for (int p = 0; p < P; ++p) th[((size_t)j * (M + 1) + m + 1) * P + p] = v[j + (size_t)K * (p + (size_t)P * m)];
     }
-    HIPCHK(copy_sync(h, h->c.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, cs.theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
     return 0;
   }
   const int D = d.D;
   if ((s == "eta" || s == "xi") && D > 0) {
     std::vector<double> tx((size_t)K * (M + 1) * D * P);
-    HIPCHK(copy_sync(h, tx.data(), h->c.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, tx.data(), cs.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
     if (s == "eta") {        // P x D x K
       if (need((int64_t)P * D * K)) return 1;
       for (int k = 0; k < K; ++k)
@@ -504,14 +575,14 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
             for (int p = 0; p < P; ++p)
               tx[((size_t)(k * (M + 1) + m + 1) * D + dd) * P + p] = v[(size_t)k * P * D * M + p + (size_t)P * (dd + (size_t)D * m)];
     }
-    HIPCHK(copy_sync(h, h->c.thetaX, tx.data(), sizeof(double) * tx.size(), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h, cs.thetaX, tx.data(), sizeof(double) * tx.size(), hipMemcpyHostToDevice));
     return 0;
   }
   struct Arr { const char* nm; double* p; int64_t len; };
-  const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
-                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M},
-                      {"tau_eta", h->c.tau_eta, (int64_t)K * D}, {"gamma_xi", h->c.gamma_xi, (int64_t)K * P * D * M},
-                      {"delta_xi", h->c.delta_xi, (int64_t)K * M * D}, {"A_xi", h->c.A_xi, (int64_t)K * 2 * D}};
+  const Arr arrs[] = {{"chi", cs.chi, (int64_t)n * M}, {"Z", cs.Z, (int64_t)n * K}, {"delta", cs.delta, (int64_t)K * M},
+                      {"A", cs.Aa, (int64_t)K * 2}, {"gamma", cs.gamma, (int64_t)K * P * M},
+                      {"tau_eta", cs.tau_eta, (int64_t)K * D}, {"gamma_xi", cs.gamma_xi, (int64_t)K * P * D * M},
+                      {"delta_xi", cs.delta_xi, (int64_t)K * M * D}, {"A_xi", cs.A_xi, (int64_t)K * 2 * D}};
   for (const Arr& a : arrs)
     if (s == a.nm && a.p) {
       if (need(a.len)) return 1;
@@ -531,14 +602,15 @@ extern "C" int bfmmm_set_state(bfmmm_handle* h, const char* name, const double* 
 extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, int64_t capacity) {
   if (!h || !name || !out) return fail("bfmmm_get_state: null argument");
   HIPCHK(hipSetDevice(h->device));
-  const Dims& d = h->c.d;
+  const Ctx cs = selc(h);       // the selected chain of the batch
+  const Dims& d = cs.d;
   const int n = d.n, K = d.K, P = d.P, M = d.M;
   const std::string s(name);
   auto need = [&](int64_t want) { return capacity >= want ? 0 : fail("bfmmm_get_state(" + s + "): buffer too small"); };
   HIPCHK(hipStreamSynchronize(h->st));
   if (s == "nu" || s == "Phi") {
     std::vector<double> th((size_t)K * (M + 1) * P);
-    HIPCHK(copy_sync(h, th.data(), h->c.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, th.data(), cs.theta, sizeof(double) * th.size(), hipMemcpyDeviceToHost));
     if (s == "nu") {
       if (need((int64_t)K * P)) return 1;
       for (int j = 0; j < K; ++j)
@@ -554,7 +626,7 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   const int D = d.D;
   if ((s == "eta" || s == "xi") && D > 0) {
     std::vector<double> tx((size_t)K * (M + 1) * D * P);
-    HIPCHK(copy_sync(h, tx.data(), h->c.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h, tx.data(), cs.thetaX, sizeof(double) * tx.size(), hipMemcpyDeviceToHost));
     if (s == "eta") {
       if (need((int64_t)P * D * K)) return 1;
       for (int k = 0; k < K; ++k)
@@ -571,10 +643,10 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
     return 0;
   }
   struct Arr { const char* nm; double* p; int64_t len; };
-  const Arr arrs[] = {{"chi", h->c.chi, (int64_t)n * M}, {"Z", h->c.Z, (int64_t)n * K}, {"delta", h->c.delta, (int64_t)K * M},
-                      {"A", h->c.Aa, (int64_t)K * 2}, {"gamma", h->c.gamma, (int64_t)K * P * M},
-                      {"tau_eta", h->c.tau_eta, (int64_t)K * D}, {"gamma_xi", h->c.gamma_xi, (int64_t)K * P * D * M},
-                      {"delta_xi", h->c.delta_xi, (int64_t)K * M * D}, {"A_xi", h->c.A_xi, (int64_t)K * 2 * D}};
+  const Arr arrs[] = {{"chi", cs.chi, (int64_t)n * M}, {"Z", cs.Z, (int64_t)n * K}, {"delta", cs.delta, (int64_t)K * M},
+                      {"A", cs.Aa, (int64_t)K * 2}, {"gamma", cs.gamma, (int64_t)K * P * M},
+                      {"tau_eta", cs.tau_eta, (int64_t)K * D}, {"gamma_xi", cs.gamma_xi, (int64_t)K * P * D * M},
+                      {"delta_xi", cs.delta_xi, (int64_t)K * M * D}, {"A_xi", cs.A_xi, (int64_t)K * 2 * D}};
   for (const Arr& a : arrs)
     if (s == a.nm && a.p) {
       if (need(a.len)) return 1;
@@ -711,13 +783,16 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->last_md = MD;
   Dyn dyn;
   if (!prepare_only) {
-    if (dyn_get(h, dyn)) return 1;
-    dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
-    dyn.pend_dir = -1;
-    dyn.ll_pending = 0;
-    if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; h->state_dirty = false; }
-    dyn.znorm_valid = 0;
-    if (dyn_put(h, dyn)) return 1;
+    for (int q = 0; q < h->nch; ++q) {          // every chain of the batch starts the run at the same iteration
+      if (dyn_get(h, dyn, q)) return 1;
+      dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
+      dyn.pend_dir = -1;
+      dyn.ll_pending = 0;
+      if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; }
+      dyn.znorm_valid = 0;
+      if (dyn_put(h, dyn, q)) return 1;
+    }
+    h->state_dirty = false;
     for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
     HIPCHK(hipEventRecord(h->ev0, h->st));
   }
@@ -792,8 +867,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if (prepare_only) return 0;
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
-  if (!(mask & U_Z)) launch_fill_slots(c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
-  if (!plan.chi_update) launch_fill_slots(c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
+  if (!(mask & U_Z)) launch_fill_slots(c, c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
+  if (!plan.chi_update) launch_fill_slots(c, c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS (5 A P doubles + A^2 ints must fit 160 KB)"); }
@@ -802,11 +877,13 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->fam_ms[FAM_TOTAL] = ms;
   h->fam_launches[FAM_TOTAL] = n_iters;
-  if (dyn_get(h, dyn)) return 1;
-  if (dyn.status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
-  if (dyn.status & 1u)
-    return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
-                "eigen-decomposition fallback here; not supported on the device)");
+  for (int q = 0; q < h->nch; ++q) {
+    if (dyn_get(h, dyn, q)) return 1;
+    if (dyn.status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
+    if (dyn.status & 1u)
+      return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
+                  "eigen-decomposition fallback here; not supported on the device)");
+  }
   return 0;
 }
 
@@ -839,6 +916,7 @@ extern "C" int bfmmm_tempered_transition(bfmmm_handle* h, uint32_t mask, int ite
                                          uint64_t seed, uint32_t chain, double* logA_out, int* accepted_out) {
   if (!h) return fail("bfmmm_tempered_transition: null handle");
   if (N_t < 1 || iter < h->slot_base || iter - h->slot_base >= h->T) return fail("bfmmm_tempered_transition: bad arguments");
+  if (h->nch != 1) return fail("bfmmm_tempered_transition: a tempered transition accepts or rejects one chain: not available on a chain batch");
   HIPCHK(hipSetDevice(h->device));
   const Ctx& c = h->c;
   const Dims& d = c.d;
@@ -922,7 +1000,7 @@ extern "C" int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, d
   if (!h || !name || !out) return fail("bfmmm_get_chain: null argument");
   if (n_slots < 0 || n_slots > h->T) return fail("bfmmm_get_chain: n_slots out of range");
   HIPCHK(hipSetDevice(h->device));
-  const Ctx& c = h->c;
+  const Ctx c = selc(h);        // the selected chain of the batch
   const Dims& d = c.d;
   const int64_t n = d.n, K = d.K, P = d.P, M = d.M;
   const std::string s(name);
@@ -956,7 +1034,7 @@ extern "C" int bfmmm_get_chain(bfmmm_handle* h, const char* name, int n_slots, d
 extern "C" int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, int64_t capacity, int64_t* count) {
   if (!h || !name || !out || !count) return fail("bfmmm_debug_get: null argument");
   HIPCHK(hipSetDevice(h->device));
-  const Ctx& c = h->c;
+  const Ctx c = selc(h);        // the selected chain of the batch
   Dims d = c.d;
   if (h->last_md > 0) set_md(d, h->last_md);
   const std::string s(name);

@@ -63,7 +63,8 @@ __host__ __device__ inline void pair_uv(int q, int& u, int& v) {
 //      Wdir[i][a];  (b) the standard gamma variates of tau_eta, delta_xi, gamma_xi -- their shapes do not depend on
 //      anything this iteration samples (delta_xi's uses A_xi, which is updated after it), so k_cov_hyper only scales
 //      them: rgamma(shape, scale) == rgamma(shape, 1) * scale bit for bit (rng.hpp).  gstd2 = [K*D | K*M*D | K*D*P*M].
-__global__ __launch_bounds__(256) void k_cov_prep(Ctx c, int n_wblocks) {
+__global__ __launch_bounds__(256) void k_cov_prep(Ctx c0, int n_wblocks) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   const Dims& d = c.d;
   if ((int)blockIdx.x < n_wblocks) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void k_cov_prep(Ctx c, int n_wblocks) {
 constexpr int NPG_MAX = DMAX_COV * (DMAX_COV + 1) / 2;
 constexpr int W2_CH = 128;       // curves per chunk (NB2 = ceil(n / W2_CH))
 
-__global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
+__global__ __launch_bounds__(256) void k_cov_w2(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const Dims& d = c.d;
   const int g = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c) {
 
 // ---- H_ab for every in-group pair; C_a, L_a z_a for every eta / Xi direction: grid NPAIR -----------------
 template <int PP>
-__global__ __launch_bounds__(256) void k_cov_factor(Ctx c) {
+__global__ __launch_bounds__(256) void k_cov_factor(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, D = d.D, tid = threadIdx.x;
@@ -276,7 +279,8 @@ constexpr int GT = 1024;       // threads of k_cov_group
 typedef double dbl2 __attribute__((ext_vector_type(2)));     // one 16-byte memory instruction
 
 template <int BW, int LPC>
-__global__ __launch_bounds__(GT) void k_cov_group(Ctx c, int g_prev, int g_next, int par_prev) {
+__global__ __launch_bounds__(GT) void k_cov_group(Ctx c0, int g_prev, int g_next, int par_prev) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   constexpr int GPB = GT / LPC;           // lane groups
   constexpr int CPB = GPB * COV_CPG;      // curves per workgroup
   constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR, tid < 256)
@@ -577,7 +581,8 @@ __global__ __launch_bounds__(GT) void k_cov_group(Ctx c, int g_prev, int g_next,
 // ---- tau_eta, delta_xi, A_xi, gamma_xi and the chain slots of the covariate blocks: one workgroup ----
 // (the gamma variates arrive as standard draws from k_cov_prep; what is left is sums, products and the A_xi step)
 constexpr int HT = 1024;       // threads of k_cov_hyper: its loops are chains of dependent global round trips, so more lanes = fewer trips
-__global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c) {
+__global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   extern __shared__ __attribute__((aligned(16))) double hsm[];
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, D = d.D, tid = threadIdx.x;
@@ -742,8 +747,8 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c) {
 template <int BW>
 static void launch_group_bw(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
   const size_t lds = ((size_t)c.NPG * c.d.LG + 2 + (c.d.P <= 32 ? (size_t)c.d.D * c.d.P * c.d.P + 2 : 0)) * sizeof(double);
-  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
-  else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
+  if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
+  else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
 }
 
 static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
@@ -773,15 +778,15 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     const size_t tot = (size_t)d.n * c.A2;
     const int n_wblocks = (do_eta || do_xi) ? (int)((tot + 255) / 256) : 0;
     const int n_draws = d.K * d.D + d.K * d.M * d.D + d.K * d.D * d.P * d.M;
-    hipLaunchKernelGGL(k_cov_prep, dim3(n_wblocks + (n_draws + 255) / 256), dim3(256), 0, st, c, n_wblocks);
+    hipLaunchKernelGGL(k_cov_prep, dim3(n_wblocks + (n_draws + 255) / 256, 1, c.nch), dim3(256), 0, st, c, n_wblocks);
   }
   if (do_eta || do_xi) {
     const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)c.NPG * 128) * sizeof(double);
-    hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2), dim3(256), lds_w2, st, c);
+    hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2, c.nch), dim3(256), lds_w2, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
     const size_t lds = (2 * (size_t)PP * PP + PP + d.LG) * sizeof(double);
-    if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.NPAIR), dim3(256), lds, st, c);
-    else hipLaunchKernelGGL(k_cov_factor<64>, dim3(c.NPAIR), dim3(256), lds, st, c);
+    if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.NPAIR, 1, c.nch), dim3(256), lds, st, c);
+    else hipLaunchKernelGGL(k_cov_factor<64>, dim3(c.NPAIR, 1, c.nch), dim3(256), lds, st, c);
     const int n_eta_groups = d.K, n_groups = c.A2 / d.D;
     for (int g = 0; g < n_groups; ++g) {
       if (g < n_eta_groups ? !do_eta : !do_xi) continue;
@@ -792,7 +797,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
   }
   launch_group(c, g_prev, -1, par, st);      // the last group's draws, and the residual sums for the log-likelihood
   const size_t lds_h = ((size_t)d.K * d.D * d.P + (size_t)d.P * d.P + 2 * (size_t)d.D * d.K * d.M) * sizeof(double);
-  hipLaunchKernelGGL(k_cov_hyper, dim3(1), dim3(HT), lds_h, st, c);
+  hipLaunchKernelGGL(k_cov_hyper, dim3(1, 1, c.nch), dim3(HT), lds_h, st, c);
 }
 
 template <int BW>

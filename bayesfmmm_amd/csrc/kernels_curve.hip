@@ -101,7 +101,8 @@ void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 #endif
 
 template <int BW, int LPC, bool COV>
-__global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
+__global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 0);
 #ifdef BFMMM_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c, int do_update) {
 // actual M so that three workgroups fit a CU and the extra scalar-job workgroup never waits for a free slot.
 // ------------------------------------------------------------------------------------------------
 template <int BW, int LPC, bool COV>
-__global__ __launch_bounds__(256) void k_curve_chi(Ctx c, int mode) {
+__global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 5);
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
   if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
@@ -640,8 +642,8 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, L, CV>), dim3(nblk), dim3(256), lds, st, c, do_update);  \
-    else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 8), dim3(256), lds, st, c, do_update);      \
+    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, L, CV>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
+    else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
   if (LPC == 32) { if (cov) LAUNCH_CURVE(32, true); else LAUNCH_CURVE(32, false); }
   else { if (cov) LAUNCH_CURVE(64, true); else LAUNCH_CURVE(64, false); }

@@ -62,7 +62,8 @@ void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP
 
 constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
                                   // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
-__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c, int KS, int do_pg) {
+__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int do_pg) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 1);
 #ifdef BFMMM_TIMELINE
   const int wgid = blockIdx.x + gridDim.x * blockIdx.y;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c, int KS, int do_
 
 // one thread per element of every output tile; fixed summation order over the k-slices
 // (four interleaved partial sums, combined in a fixed order)
-__global__ __launch_bounds__(256) void k_pg_reduce(Ctx c, int NKS) {
+__global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 2);
   const Dims& d = c.d;
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -378,7 +380,8 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi);
 // eigen-decomposition fallback of mvnrnd there).
 // ---------------------------------------------------------------------------------------------
 template <int PP, int BW>
-__global__ __launch_bounds__(256) void k_factor(Ctx c) {
+__global__ __launch_bounds__(256) void k_factor(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 3);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -564,7 +567,8 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi) {
   return (s - n_phi) * d.MD;
 }
 
-__global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c0, int direct) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -762,7 +766,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c, int direct) {
 // ---------------------------------------------------------------------------------------------
 constexpr int DG_RPL = 8;          // directions per lane
 
-__global__ __launch_bounds__(512) void k_sweep_diag(Ctx c) {
+__global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -960,7 +965,8 @@ __device__ inline void sweep_wait_h(SweepH<BW>& s) {
 // so the bulk of the memory traffic (H blocks from L2, delta from LDS) overlaps the dependent chain instead of
 // sitting on it.  H_{b,a} rows are prefetched into registers one to two steps ahead (sweep_ld16 / sweep_wait_h).
 template <int BW>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -1231,7 +1237,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c) {
 // k_loglik: calcLikelihood = sum_il dnorm(y_il; mean_il, sqrt(sigma2), log)  and end-of-iteration
 // bookkeeping (advance the iteration counter / slot for graph replay).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_stored) {
+__global__ __launch_bounds__(256) void k_loglik(Ctx c0, int use_rss_part, int r_stored) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 6);
   __shared__ double red[256];
   Dyn* dyn = c.dyn;
@@ -1259,13 +1266,16 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c, int use_rss_part, int r_s
 }
 
 // reduces a still-pending log-likelihood (launched once at the end of a run)
-__global__ __launch_bounds__(256) void k_loglik_flush(Ctx c) {
+__global__ __launch_bounds__(256) void k_loglik_flush(Ctx c0) {
+  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   __shared__ double red[256];
   if (c.dyn->ll_pending) deferred_loglik(c, red);
 }
 
 // broadcast the current value of blocks a sweep does not update into chain slots [s0, s1)
-__global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1) {
+__global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, size_t chain_bytes) {
+  chain = ptr_shift(chain, blockIdx.z * chain_bytes);      // chain blockIdx.z of the batch
+  cur = ptr_shift(cur, blockIdx.z * chain_bytes);
   const size_t total = len * (size_t)(s1 - s0);
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
     chain[(size_t)s0 * len + e] = cur[e % len];
@@ -1275,22 +1285,22 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
   const size_t lds = std::max((size_t)(KS + 2) * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
-  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1), dim3(PG_THREADS), lds, st, c, KS, do_pg);
+  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1, c.nch), dim3(PG_THREADS), lds, st, c, KS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;
-  hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, c, NKS);
+  hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
 }
 
 template <int PP>
 static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st) {
   switch (c.d.BW) {
-    case 0: hipLaunchKernelGGL((k_factor<PP, 0>), dim3(grid), dim3(256), lds, st, c); break;
-    case 1: hipLaunchKernelGGL((k_factor<PP, 1>), dim3(grid), dim3(256), lds, st, c); break;
-    case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(grid), dim3(256), lds, st, c); break;
-    case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(grid), dim3(256), lds, st, c); break;
-    case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(grid), dim3(256), lds, st, c); break;
-    case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid), dim3(256), lds, st, c); break;
-    default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(grid), dim3(256), lds, st, c); break;
+    case 0: hipLaunchKernelGGL((k_factor<PP, 0>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 1: hipLaunchKernelGGL((k_factor<PP, 1>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
   }
 }
 
@@ -1311,19 +1321,19 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
   if (d.BW == 0 && d.BWP == 0 && d.A <= 8 * DG_RPL && d.P <= 64) {        // diagonal model: independent scalar chains per coordinate
     const size_t lds = 16 * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
-    hipLaunchKernelGGL(k_sweep_diag, dim3(1), dim3((8 * d.P + 63) / 64 * 64), lds, st, c);
+    hipLaunchKernelGGL(k_sweep_diag, dim3(1, 1, c.nch), dim3((8 * d.P + 63) / 64 * 64), lds, st, c);
     return 0;
   }
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
     const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
     const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 24) * sizeof(int) + 16;
     switch (d.BW) {
-      case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1), dim3(nthr), lds, st, c); break;
-      case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1), dim3(nthr), lds, st, c); break;
-      case 2: hipLaunchKernelGGL(k_sweep_fast<2>, dim3(1), dim3(nthr), lds, st, c); break;
-      case 3: hipLaunchKernelGGL(k_sweep_fast<3>, dim3(1), dim3(nthr), lds, st, c); break;
-      case 4: hipLaunchKernelGGL(k_sweep_fast<4>, dim3(1), dim3(nthr), lds, st, c); break;
-      default: hipLaunchKernelGGL(k_sweep_fast<5>, dim3(1), dim3(nthr), lds, st, c); break;
+      case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 2: hipLaunchKernelGGL(k_sweep_fast<2>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 3: hipLaunchKernelGGL(k_sweep_fast<3>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 4: hipLaunchKernelGGL(k_sweep_fast<4>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_fast<5>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
     }
     return 0;
   }
@@ -1337,14 +1347,14 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   if (pf_len > (size_t)NPF * SW_THREADS || lds_for(pf_len) > 160 * 1024) { direct = 1; pf_len = 0; }
   const size_t lds = lds_for(pf_len);
   if (lds > 160 * 1024) return 1;
-  hipLaunchKernelGGL(k_sweep, dim3(1), dim3(SW_THREADS), lds, st, c, direct);
+  hipLaunchKernelGGL(k_sweep, dim3(1, 1, c.nch), dim3(SW_THREADS), lds, st, c, direct);
   return 0;
 }
 
-void launch_loglik_flush(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_loglik_flush, dim3(1), dim3(256), 0, st, c); }
+void launch_loglik_flush(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), 0, st, c); }
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
-  hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, st, c, use_rss_part, r_stored);
+  hipLaunchKernelGGL(k_loglik, dim3(1, 1, c.nch), dim3(256), 0, st, c, use_rss_part, r_stored);
 }
 
 void prepare_sweep_kernels() {
@@ -1359,9 +1369,9 @@ void prepare_sweep_kernels() {
   set_max_lds((const void*)k_factor<32, BWWIDE>); set_max_lds((const void*)k_factor<64, BWWIDE>);
 }
 
-void launch_fill_slots(double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {
+void launch_fill_slots(const Ctx& c, double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st) {
   if (s1 <= s0 || len == 0) return;
-  hipLaunchKernelGGL(k_fill_slots, dim3(256), dim3(256), 0, st, chain, cur, len, s0, s1);
+  hipLaunchKernelGGL(k_fill_slots, dim3(256, 1, c.nch), dim3(256), 0, st, chain, cur, len, s0, s1, c.chain_bytes);
 }
 
 }  // namespace bfmmm

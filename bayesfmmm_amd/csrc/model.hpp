@@ -148,10 +148,47 @@ struct Ctx {
   int NPG, NPAIR;               // in-group direction pairs: D(D+1)/2 per group of D consecutive directions, (A2/D)*NPG in all
   double *c_eta, *c_xi, *c_tau_eta, *c_gamma_xi, *c_delta_xi, *c_A_xi;
   double YY;                    // sum_i yy_i
+  // ---- chain batch: a handle may hold several independent chains over ONE copy of the data (multi-try chains,
+  //      UserFunctions.cpp:302-325).  Every per-chain buffer of chain q is the buffer of chain 0 moved by q * chain_bytes
+  //      (covariate buffers: q * chain_bytes_cov); the kernels run chain blockIdx.z (chain_view below) with RNG chain id
+  //      chain + q * chain_id_stride.  rec, ni, Pmat and X are shared.
+  size_t chain_bytes, chain_bytes_cov;
+  uint32_t chain_id_stride;
+  int nch;                      // chains in the batch = gridDim.z of every launch
   // chain storage (slot-major, each slot laid out exactly as the reference returns it)
   double *c_nu, *c_chi, *c_Z, *c_pi, *c_alpha3, *c_delta, *c_A, *c_sigma, *c_tau, *c_gamma, *c_Phi, *c_loglik;
   int nblk_curve;
 };
+
+// per-chain pointers of Ctx (everything but the shared data rec, ni, Pmat, X)
+#define BFMMM_CHAIN_PTRS(X_)                                                                                         \
+  X_(dyn) X_(Z) X_(chi) X_(theta) X_(delta) X_(Aa) X_(gamma) X_(logz_part) X_(rss_part) X_(pg_part) X_(H) X_(H2)       \
+  X_(tvec) X_(rvec) X_(hq) X_(Lz) X_(gstd) X_(zprep) X_(chi_norm) X_(piprep) X_(Cmat) X_(Lmat)                        \
+  X_(c_nu) X_(c_chi) X_(c_Z) X_(c_pi) X_(c_alpha3) X_(c_delta) X_(c_A) X_(c_sigma) X_(c_tau) X_(c_gamma) X_(c_Phi) X_(c_loglik)
+#define BFMMM_CHAIN_PTRS_COV(X_)                                                                                     \
+  X_(thetaX) X_(tau_eta) X_(gamma_xi) X_(delta_xi) X_(A_xi) X_(stil) X_(yyp_part) X_(cfull) X_(gfull) X_(w2_part)      \
+  X_(H2aa) X_(gstd2) X_(Wdir) X_(C2) X_(Lz2) X_(step_part) X_(thetaN) X_(delta_cur)                                   \
+  X_(c_eta) X_(c_xi) X_(c_tau_eta) X_(c_gamma_xi) X_(c_delta_xi) X_(c_A_xi)
+
+template <typename T>
+__host__ __device__ inline T* ptr_shift(T* p, size_t bytes) { return (T*)((uintptr_t)p + bytes); }
+
+// the context of chain q of the batch
+__host__ __device__ inline Ctx chain_ctx(const Ctx& c0, unsigned q) {
+  Ctx c = c0;
+  const size_t o1 = (size_t)q * c0.chain_bytes, o2 = (size_t)q * c0.chain_bytes_cov;
+#define X_(f) c.f = ptr_shift(c0.f, o1);
+  BFMMM_CHAIN_PTRS(X_)
+#undef X_
+#define X_(f) c.f = ptr_shift(c0.f, o2);
+  BFMMM_CHAIN_PTRS_COV(X_)
+#undef X_
+  c.chain = c0.chain + q * c0.chain_id_stride;
+  return c;
+}
+#ifdef __HIPCC__
+__device__ inline Ctx chain_view(const Ctx& c0) { return chain_ctx(c0, blockIdx.z); }
+#endif
 
 __host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
   return a * n - (a * (a - 1)) / 2 + (b - a);

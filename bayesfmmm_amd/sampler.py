@@ -39,12 +39,14 @@ def default_config(**kw):
 
 class Sampler:
     def __init__(self, cfg, Y, time=None, internal_knots=None, boundary_knots=None, device=0, basis=None, band=None,
-                 penalty=None, penalty_band=None):
+                 penalty=None, penalty_band=None, n_chains=1):
         """Functional model: Y, time are lists of 1-D arrays (one per curve).
         Multivariate model: Y is an (n, P) matrix.
         Functional model over a caller-supplied basis (bfmmm_create_from_basis; the high-dimensional model's tensor-product
         basis): `basis` is a list of n_i x P matrices, `band` the half-bandwidth of B'B, `penalty` the P x P penalty of the
-        nu prior and `penalty_band` its half-bandwidth."""
+        nu prior and `penalty_band` its half-bandwidth.
+        n_chains > 1: a chain batch (bfmmm_create_batch) -- `run` advances all chains in lockstep, `select_chain` picks the
+        chain the state / chain accessors address."""
         self.lib = _lib.load()
         self.cfg = cfg
         self.h = C.c_void_p()
@@ -56,9 +58,9 @@ class Sampler:
             Pm = np.asfortranarray(penalty, dtype=np.float64)
             cfg.n_funct = len(Y)
             self.P = B.shape[1]
-            _lib.check(self.lib.bfmmm_create_from_basis(C.byref(cfg), device, _dp(y), _dp(B),
-                                                        self.offsets.ctypes.data_as(_lib.c_int64_p), self.P, int(band), _dp(Pm),
-                                                        int(penalty_band), C.byref(self.h)))
+            _lib.check(self.lib.bfmmm_create_from_basis_batch(C.byref(cfg), device, _dp(y), _dp(B),
+                                                              self.offsets.ctypes.data_as(_lib.c_int64_p), self.P, int(band),
+                                                              _dp(Pm), int(penalty_band), int(n_chains), C.byref(self.h)))
         elif cfg.model == MODEL_FUNCTIONAL:
             self.offsets = np.zeros(len(Y) + 1, dtype=np.int64)
             self.offsets[1:] = np.cumsum([len(y) for y in Y])
@@ -69,17 +71,27 @@ class Sampler:
             cfg.n_funct = len(Y)
             cfg.n_internal_knots = len(ik)
             self.P = len(ik) + cfg.basis_degree + 1
-            _lib.check(self.lib.bfmmm_create(C.byref(cfg), device, _dp(y), _dp(t),
-                                             self.offsets.ctypes.data_as(_lib.c_int64_p), _dp(ik), _dp(bk),
-                                             C.byref(self.h)))
+            _lib.check(self.lib.bfmmm_create_batch(C.byref(cfg), device, _dp(y), _dp(t),
+                                                   self.offsets.ctypes.data_as(_lib.c_int64_p), _dp(ik), _dp(bk),
+                                                   int(n_chains), C.byref(self.h)))
         else:
             Ym = np.asfortranarray(Y, dtype=np.float64)
             cfg.n_funct, cfg.P = Ym.shape
             self.P = cfg.P
             self.offsets = None
-            _lib.check(self.lib.bfmmm_create(C.byref(cfg), device, _dp(Ym), None, None, None, None, C.byref(self.h)))
+            _lib.check(self.lib.bfmmm_create_batch(C.byref(cfg), device, _dp(Ym), None, None, None, None, int(n_chains),
+                                                   C.byref(self.h)))
         self.n, self.K, self.M, self.T = cfg.n_funct, cfg.K, cfg.n_eigen, cfg.tot_mcmc_iters
         self.D = 0
+        self.n_chains = int(n_chains)
+
+    def select_chain(self, q):
+        """Chain of the batch that set_state / get_state / init_state / get_chain / debug address."""
+        _lib.check(self.lib.bfmmm_select_chain(self.h, int(q)))
+
+    def set_chain_id_stride(self, stride):
+        """Chain q of the batch draws from RNG chain id `chain + q * stride` (default 1)."""
+        _lib.check(self.lib.bfmmm_set_chain_id_stride(self.h, int(stride)))
 
     def set_covariates(self, X, covariance_adj=False):
         """X: (n, D) covariate matrix (the `X` argument of the reference's entry points)."""

@@ -142,6 +142,7 @@ def main():
 
     chain_id = rank                                      # independent chain per rank
     smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=chain_id)
+    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=chain_id)   # graph capture is set-up
     barrier()
     t0 = time.perf_counter()
     smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=chain_id)

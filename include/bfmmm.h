@@ -94,6 +94,22 @@ int bfmmm_create_from_basis(const bfmmm_config* cfg, int device, const double* y
                             int P, int band, const double* Pmat, int pen_band, bfmmm_handle** out);
 void bfmmm_destroy(bfmmm_handle* h);
 
+/* Chain batches.  The multi-try entry points run 1 + n_try independent chains on the same data
+ * (src/UserFunctions.cpp:302-325, sequentially in the reference).  bfmmm_create_batch / bfmmm_create_from_basis_batch make
+ * ONE sampler that holds n_chains such chains over one copy of the per-curve statistics: bfmmm_run advances all of them
+ * in lockstep (the chain index is a grid dimension of every kernel launch), chain q drawing from RNG chain id
+ * `chain + q * stride` (bfmmm_set_chain_id_stride, default 1), so that chain q of a batch is bit-identical to a
+ * stand-alone sampler run with that chain id.  bfmmm_select_chain picks the chain that bfmmm_set_state, bfmmm_get_state,
+ * bfmmm_init_state, bfmmm_get_chain and bfmmm_debug_get address (default 0).  bfmmm_set_covariates applies to every chain.
+ * bfmmm_tempered_transition needs a batch of one chain. */
+int bfmmm_create_batch(const bfmmm_config* cfg, int device, const double* y, const double* t, const int64_t* offsets,
+                       const double* internal_knots, const double* boundary_knots, int n_chains, bfmmm_handle** out);
+int bfmmm_create_from_basis_batch(const bfmmm_config* cfg, int device, const double* y, const double* B, const int64_t* offsets,
+                                  int P, int band, const double* Pmat, int pen_band, int n_chains, bfmmm_handle** out);
+int bfmmm_select_chain(bfmmm_handle* h, int q);
+int bfmmm_n_chains(const bfmmm_handle* h);
+int bfmmm_set_chain_id_stride(bfmmm_handle* h, uint32_t stride);
+
 /* Covariate adjustment (the `X` argument of the reference's entry points, UserFunctions.cpp:176): X is the
  * n_funct x D column-major covariate matrix; covariance_adj != 0 enables the Xi block (BFMMM.h:4602 vs :4067).
  * Call once, right after bfmmm_create.  Adds the state / chain names "eta" (P x D x K), "xi" and "gamma_xi"
