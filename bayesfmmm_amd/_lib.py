@@ -38,6 +38,7 @@ SYMBOLS = {
     "bfmmm_select_chain": (C.c_int, [C.c_void_p, C.c_int]),
     "bfmmm_n_chains": (C.c_int, [C.c_void_p]),
     "bfmmm_set_chain_id_stride": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bfmmm_gather_best": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_double_p, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "bfmmm_set_covariates": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int]),
     "bfmmm_get_basis": (C.c_int, [C.c_void_p, c_double_p, C.c_int64]),
     "bfmmm_set_state": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int64]),

@@ -36,7 +36,8 @@ class EntryArgs(C.Structure):
                 ("max_concurrent", C.c_int32), ("model", C.c_int32), ("P", C.c_int32),
                 ("X", c_double_p), ("D", C.c_int32), ("covariance_adj", C.c_int32), ("dir", C.c_char_p),
                 ("dim", C.c_int32), ("basis_degree_hd", C.POINTER(C.c_int32)), ("n_internal_hd", C.POINTER(C.c_int32)),
-                ("progress_every", C.c_int32), ("progress_cb", C.c_void_p), ("progress_user", C.c_void_p)]
+                ("progress_every", C.c_int32), ("progress_cb", C.c_void_p), ("progress_user", C.c_void_p),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32)]
 
 
 ENTRY_SYMBOLS = {
@@ -144,6 +145,19 @@ def _check(rc):
         raise _lib.BfmmmError(_lib_entry().bfmmm_entry_last_error().decode())
 
 
+def _set_kw(owner, a, kw):
+    """remaining keyword arguments are fields of bfmmm_entry_args; `devices` (a list of GPU indices) selects the
+    multi-GPU multi-try of include/bfmmm_entry.h"""
+    devices = kw.pop("devices", None)
+    if devices is not None:
+        owner.devices = (C.c_int32 * len(devices))(*[int(x) for x in devices])
+        a.devices, a.n_devices = owner.devices, len(devices)
+    for k, v in kw.items():
+        if not hasattr(a, k):
+            raise TypeError(f"unexpected argument '{k}'")
+        setattr(a, k, v)
+
+
 class _ArgsMV:
     """bfmmm_entry_args of the multivariate entry points: Y is the n x P matrix."""
 
@@ -171,10 +185,7 @@ class _ArgsMV:
             if self.c.size != K:
                 raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
             a.c = self.c.ctypes.data_as(c_double_p)
-        for k, v in kw.items():
-            if not hasattr(a, k):
-                raise TypeError(f"unexpected argument '{k}'")
-            setattr(a, k, v)
+        _set_kw(self, a, kw)
 
 
 def _result_to_dict(lib, res, offsets, P):
@@ -245,10 +256,7 @@ class _Args:
             if self.c.size != K:
                 raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
             a.c = self.c.ctypes.data_as(c_double_p)
-        for k, v in kw.items():
-            if not hasattr(a, k):
-                raise TypeError(f"unexpected argument '{k}'")
-            setattr(a, k, v)
+        _set_kw(self, a, kw)
 
 
 def BFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,
@@ -515,10 +523,7 @@ class _ArgsHD:
             if self.c.size != K:
                 raise _lib.BfmmmError("number of elements of the vector 'c' must be equal to K")
             a.c = self.c.ctypes.data_as(c_double_p)
-        for k, v in kw.items():
-            if not hasattr(a, k):
-                raise TypeError(f"unexpected argument '{k}'")
-            setattr(a, k, v)
+        _set_kw(self, a, kw)
 
 
 def BHDFMMM_Nu_Z_multiple_try(tot_mcmc_iters, n_try, K, Y, time, n_funct, basis_degree, n_eigen, boundary_knots,

@@ -1074,3 +1074,85 @@ extern "C" int bfmmm_get_timing(bfmmm_handle* h, const char* name, double* ms, i
     if (!strcmp(name, kFamNames[f])) { *ms = h->fam_ms[f]; *launches = h->fam_launches[f]; return 0; }
   return fail("bfmmm_get_timing: unknown name");
 }
+
+// ---- final gather of a multi-GPU multi-try over RCCL ------------------------------------------------------------------
+// BFMMM_Nu_Z_multiple_try / BFMMM_Theta_est keep the best of 1 + n_try independent chains (src/UserFunctions.cpp:302-325,
+// :861-885).  With the chains dealt over several GPUs (one handle per device, all in this process) the only exchange of
+// the whole computation is this one: an ncclAllGather of one (score, chain index) pair per device -- every rank then
+// knows the winner: largest score, lowest chain index on ties (the reference's `<` at :320 keeps the earlier chain) --
+// and the winner's chain arena (state + every chain slot) travels device to device over xGMI (ncclSend / ncclRecv) into
+// the selected chain of handles[0], from where the entry point assembles its result.  No collective runs inside a chain.
+#include <rccl/rccl.h>
+
+#define NCCLCHK(x)                                                                                   \
+  do {                                                                                              \
+    ncclResult_t r_ = (x);                                                                          \
+    if (r_ != ncclSuccess) {                                                                        \
+      char buf_[512];                                                                               \
+      snprintf(buf_, sizeof buf_, "RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #x); \
+      for (ncclComm_t cm_ : comms) if (cm_) (void)ncclCommDestroy(cm_);                             \
+      return fail(buf_);                                                                            \
+    }                                                                                               \
+  } while (0)
+
+extern "C" int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, const double* scores, const int32_t* chain_ids,
+                                 int* winner_out) {
+  if (!handles || !scores || !chain_ids || n_handles < 1) return fail("bfmmm_gather_best: bad arguments");
+  const int G = n_handles;
+  std::vector<int> devs(G);
+  for (int g = 0; g < G; ++g) {
+    if (!handles[g]) return fail("bfmmm_gather_best: null handle");
+    devs[g] = handles[g]->device;
+    if (handles[g]->c.chain_bytes != handles[0]->c.chain_bytes || handles[g]->c.chain_bytes_cov != handles[0]->c.chain_bytes_cov)
+      return fail("bfmmm_gather_best: the handles were not created with the same configuration");
+    for (int g2 = 0; g2 < g; ++g2)
+      if (devs[g2] == devs[g]) return fail("bfmmm_gather_best: one handle per device");
+  }
+  std::vector<ncclComm_t> comms(G, nullptr);
+  NCCLCHK(ncclCommInitAll(comms.data(), G, devs.data()));
+  // (score, chain index) pairs: send 2 doubles, receive 2 G
+  std::vector<double*> sbuf(G, nullptr), rbuf(G, nullptr);
+  for (int g = 0; g < G; ++g) {
+    HIPCHK(hipSetDevice(devs[g]));
+    if (dalloc(handles[g], &sbuf[g], 2) || dalloc(handles[g], &rbuf[g], 2 * (size_t)G)) return 1;
+    const double pair[2] = {scores[g], (double)chain_ids[g]};
+    HIPCHK(copy_sync(handles[g], sbuf[g], pair, sizeof pair, hipMemcpyHostToDevice));
+  }
+  NCCLCHK(ncclGroupStart());
+  for (int g = 0; g < G; ++g) NCCLCHK(ncclAllGather(sbuf[g], rbuf[g], 2, ncclDouble, comms[g], handles[g]->st));
+  NCCLCHK(ncclGroupEnd());
+  std::vector<double> all(2 * (size_t)G);
+  int winner = -1;
+  for (int g = 0; g < G; ++g) {          // every rank holds the same table and takes the same decision
+    HIPCHK(hipSetDevice(devs[g]));
+    HIPCHK(hipStreamSynchronize(handles[g]->st));
+    HIPCHK(copy_sync(handles[g], all.data(), rbuf[g], sizeof(double) * all.size(), hipMemcpyDeviceToHost));
+    int w = -1;
+    for (int r = 0; r < G; ++r) {
+      if (!(all[2 * r] == all[2 * r])) continue;             // a rank without a valid chain reports NaN
+      if (w < 0 || all[2 * r] > all[2 * w] || (all[2 * r] == all[2 * w] && all[2 * r + 1] < all[2 * w + 1])) w = r;
+    }
+    if (g == 0) winner = w;
+    else if (w != winner) { for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm); return fail("bfmmm_gather_best: ranks disagree on the winner"); }
+  }
+  if (winner < 0) { for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm); return fail("bfmmm_gather_best: no rank holds a valid chain"); }
+  if (winner != 0) {
+    const Ctx src = selc(handles[winner]), dst = selc(handles[0]);
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclSend(src.dyn, src.chain_bytes, ncclChar, 0, comms[winner], handles[winner]->st));
+    NCCLCHK(ncclRecv(dst.dyn, dst.chain_bytes, ncclChar, winner, comms[0], handles[0]->st));
+    if (src.chain_bytes_cov) {
+      NCCLCHK(ncclSend(src.thetaX, src.chain_bytes_cov, ncclChar, 0, comms[winner], handles[winner]->st));
+      NCCLCHK(ncclRecv(dst.thetaX, dst.chain_bytes_cov, ncclChar, winner, comms[0], handles[0]->st));
+    }
+    NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipSetDevice(devs[winner]));
+    HIPCHK(hipStreamSynchronize(handles[winner]->st));
+    HIPCHK(hipSetDevice(devs[0]));
+    HIPCHK(hipStreamSynchronize(handles[0]->st));
+    handles[0]->state_dirty = true;
+  }
+  for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm);
+  if (winner_out) *winner_out = winner;
+  return 0;
+}

@@ -87,7 +87,7 @@ extern "C" void bfmmm_entry_defaults(bfmmm_entry_args* a, int entry) {
   a->a_Z_PM = 10000; a->a_pi_PM = 1000; a->var_alpha3 = 0.05; a->var_epsilon1 = 1; a->var_epsilon2 = 1;
   a->alpha_nu = 10; a->beta_nu = 1; a->alpha_eta = 10; a->beta_eta = 1; a->alpha_0 = 1; a->beta_0 = 1;
   a->thinning_num = 1; a->beta_N_t = 1; a->N_t = 1; a->n_temp_trans = 0; a->r_stored_iters = 0;
-  a->seed = 1; a->device = 0; a->chain_offset = 0; a->chain_stride = 1; a->max_concurrent = 4;
+  a->seed = 1; a->device = 0; a->chain_offset = 0; a->chain_stride = 1; a->max_concurrent = 8;
 }
 
 // argument checks in the reference's order and wording (UserFunctions.cpp:198-286, 727-818, 1394-1498)
@@ -154,8 +154,6 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   return 0;
 }
 
-static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, bfmmm_handle** h);
-
 static void make_cfg(const bfmmm_entry_args* a, int T, bfmmm_config* cfg) {
   bfmmm_config_defaults(cfg);
   cfg->model = a->model;
@@ -192,11 +190,9 @@ static double tail_median(const double* chain, int64_t len, int64_t e, int64_t b
 }
 
 struct ChainRun {
-  bfmmm_handle* h = nullptr;
+  bfmmm_handle* h = nullptr;      // batch handle with the best chain selected
   double score = -INFINITY;
   int chain = -1;
-  int rc = 0;
-  std::string err;
 };
 
 // mean of the last 99 log-likelihood values, UserFunctions.cpp:309,320
@@ -207,51 +203,112 @@ static double tail_score(const std::vector<double>& ll, int T) {
 }
 
 typedef int (*chain_setup_fn)(bfmmm_handle* h, int chain, const void* ctx);
+static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, int device, int n_chains, bfmmm_handle** h);
+static int attach_cov(bfmmm_handle* h, const bfmmm_entry_args* a);
 
-// Runs the chains {offset, offset+stride, ...} <= n_try, at most max_concurrent at a time (each on
-// its own stream), and keeps the handle of the best one (strictly larger score wins, earlier chain
-// on ties -- the reference's `<` at UserFunctions.cpp:320).
+// the chains one device runs, and what it found
+struct DevRun {
+  int device = 0;
+  std::vector<int> chains;        // ascending, equally spaced
+  ChainRun best;
+  int n_ok = 0;
+  std::string err;
+};
+
+// Runs the device's chains in batches of at most max_concurrent (one batch = ONE sampler whose kernels carry the chain
+// index as a grid dimension, bfmmm_create_batch) and keeps the batch that holds the device's best chain.
+static void run_device(const bfmmm_entry_args* a, const bfmmm_config& cfg, uint32_t mask, int phi_chi_zero,
+                       chain_setup_fn setup, const void* ctx, DevRun& r) {
+  const int T = cfg.tot_mcmc_iters;
+  const size_t cap = (size_t)std::max(1, a->max_concurrent);
+  const uint32_t id_stride = r.chains.size() > 1 ? (uint32_t)(r.chains[1] - r.chains[0]) : 1u;
+  std::vector<double> ll(T);
+  for (size_t base = 0; base < r.chains.size(); base += cap) {
+    const int nb = (int)std::min(r.chains.size() - base, cap);
+    bfmmm_handle* h = nullptr;
+    auto lib_fail = [&]() { if (r.err.empty()) r.err = bfmmm_last_error(); if (h) bfmmm_destroy(h); h = nullptr; };
+    if (make_handle(a, &cfg, r.device, nb, &h)) { lib_fail(); continue; }
+    if (attach_cov(h, a) || bfmmm_set_chain_id_stride(h, id_stride)) { lib_fail(); continue; }
+    bool ok = true;
+    for (int q = 0; q < nb && ok; ++q) ok = !bfmmm_select_chain(h, q) && !setup(h, r.chains[base + q], ctx);
+    // a failing batch loses its own chains only: the chains that did finish still compete (the reference would have
+    // returned the best of those it completed)
+    if (!ok || bfmmm_run(h, mask, 0, T, a->seed, (uint32_t)r.chains[base], phi_chi_zero, 1.0)) { lib_fail(); continue; }
+    int sel = -1;
+    for (int q = 0; q < nb; ++q) {
+      if (bfmmm_select_chain(h, q) || bfmmm_get_chain(h, "loglik", T, ll.data(), T)) { lib_fail(); break; }
+      const double sc = tail_score(ll, T);
+      if (!(sc == sc)) continue;                          // a chain whose log-likelihood is not a number does not compete
+      r.n_ok += 1;
+      // strictly larger score wins, the earlier chain on ties (the reference's `<` at UserFunctions.cpp:320)
+      if (r.best.chain < 0 || r.best.score < sc) { r.best.score = sc; r.best.chain = r.chains[base + q]; sel = q; }
+    }
+    if (!h) continue;
+    if (sel >= 0) {
+      if (r.best.h) bfmmm_destroy(r.best.h);
+      r.best.h = h;
+      (void)bfmmm_select_chain(h, sel);
+    } else {
+      bfmmm_destroy(h);
+    }
+  }
+}
+
+// Runs the chains {offset, offset + stride, ...} <= n_try and returns the sampler holding the best one (selected).
+// The chains are dealt round-robin over the devices of a->devices (default: the single a->device), one host thread per
+// device; with more than one device the final selection is the RCCL gather of bfmmm_gather_best.
 static int run_multi_try(const bfmmm_entry_args* a, const bfmmm_config& cfg, uint32_t mask, int phi_chi_zero,
                          chain_setup_fn setup, const void* ctx, ChainRun* best) {
   std::vector<int> chains;
   for (int c = a->chain_offset; c <= a->n_try; c += a->chain_stride) chains.push_back(c);
-  const int T = cfg.tot_mcmc_iters;
-  const int conc = std::max(1, a->max_concurrent);
-  for (size_t base = 0; base < chains.size(); base += conc) {
-    const size_t cnt = std::min(chains.size() - base, (size_t)conc);
-    std::vector<ChainRun> runs(cnt);
+  if (chains.empty()) return efail("no chain index falls in this process's chain_offset / chain_stride range");
+  std::vector<int> devs;
+  if (a->n_devices > 0 && a->devices) devs.assign(a->devices, a->devices + a->n_devices);
+  else devs.push_back(a->device);
+  const bool use_rccl = a->n_devices > 0 && a->devices;       // an explicit device list asks for the RCCL selection
+  const size_t G = std::min(devs.size(), chains.size());
+  std::vector<DevRun> runs(G);
+  for (size_t g = 0; g < G; ++g) {
+    runs[g].device = devs[g];
+    for (size_t i = g; i < chains.size(); i += G) runs[g].chains.push_back(chains[i]);
+  }
+  if (G == 1) {
+    run_device(a, cfg, mask, phi_chi_zero, setup, ctx, runs[0]);
+  } else {
     std::vector<std::thread> th;
-    for (size_t q = 0; q < cnt; ++q) {
-      runs[q].chain = chains[base + q];
-      th.emplace_back([&, q]() {
-        ChainRun& r = runs[q];
-        auto lib_fail = [&]() { r.rc = 1; r.err = bfmmm_last_error(); };
-        if (make_handle(a, &cfg, &r.h)) return lib_fail();
-        if (setup(r.h, r.chain, ctx)) return lib_fail();
-        if (bfmmm_run(r.h, mask, 0, T, a->seed, (uint32_t)r.chain, phi_chi_zero, 1.0)) return lib_fail();
-        std::vector<double> ll(T);
-        if (bfmmm_get_chain(r.h, "loglik", T, ll.data(), T)) return lib_fail();
-        r.score = tail_score(ll, T);
-      });
-    }
+    for (size_t g = 0; g < G; ++g) th.emplace_back([&, g]() { run_device(a, cfg, mask, phi_chi_zero, setup, ctx, runs[g]); });
     for (auto& t : th) t.join();
-    for (size_t q = 0; q < cnt; ++q) {
-      ChainRun& r = runs[q];
-      if (r.rc) {
-        for (auto& x : runs) if (x.h) bfmmm_destroy(x.h);
-        if (best->h) { bfmmm_destroy(best->h); best->h = nullptr; }
-        return efail(r.err);
-      }
-      if (!best->h || best->score < r.score) {
-        if (best->h) bfmmm_destroy(best->h);
-        *best = r;
-      } else {
-        bfmmm_destroy(r.h);
-      }
-      r.h = nullptr;
+  }
+  auto cleanup = [&]() { for (DevRun& r : runs) if (r.best.h) { bfmmm_destroy(r.best.h); r.best.h = nullptr; } };
+  int n_ok = 0;
+  std::string first_err;
+  for (DevRun& r : runs) { n_ok += r.n_ok; if (first_err.empty()) first_err = r.err; }
+  if (n_ok == 0) { cleanup(); return efail(first_err.empty() ? "no chain produced a finite log-likelihood" : first_err); }
+  size_t w = 0;
+  if (use_rccl) {
+    // ranks that hold a sampler take part; the winner's chain ends up in the first of them
+    std::vector<bfmmm_handle*> hs;
+    std::vector<double> sc;
+    std::vector<int32_t> ids;
+    std::vector<size_t> idx;
+    for (size_t g = 0; g < G; ++g)
+      if (runs[g].best.h) { hs.push_back(runs[g].best.h); sc.push_back(runs[g].best.score); ids.push_back(runs[g].best.chain); idx.push_back(g); }
+    int win = 0;
+    if (bfmmm_gather_best(hs.data(), (int)hs.size(), sc.data(), ids.data(), &win)) { efail_lib(); cleanup(); return 1; }
+    w = idx[0];
+    runs[w].best.score = sc[win];
+    runs[w].best.chain = ids[win];
+  } else {
+    bool have = false;
+    for (size_t g = 0; g < G; ++g) {
+      if (!runs[g].best.h) continue;
+      const ChainRun& b = runs[g].best;
+      if (!have || b.score > runs[w].best.score || (b.score == runs[w].best.score && b.chain < runs[w].best.chain)) { w = g; have = true; }
     }
   }
-  if (!best->h) return efail("no chain index falls in this process's chain_offset / chain_stride range");
+  *best = runs[w].best;
+  runs[w].best.h = nullptr;
+  cleanup();
   return 0;
 }
 
@@ -289,8 +346,8 @@ static int dimP(const bfmmm_entry_args* a) {
 // sampler handle of an entry point: univariate B-splines / multivariate data (bfmmm_create) or, for the high-dimensional
 // model, the tensor-product basis and penalty of BSplines.h:18-120 built on the host (BFMMM.h:2923-2936 does the same
 // per call) and handed to bfmmm_create_from_basis
-static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, bfmmm_handle** h) {
-  if (a->dim <= 0) return bfmmm_create(cfg, a->device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, h);
+static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, int device, int n_chains, bfmmm_handle** h) {
+  if (a->dim <= 0) return bfmmm_create_batch(cfg, device, a->y, a->t, a->offsets, a->internal_knots, a->boundary_knots, n_chains, h);
   const int dim = a->dim, P = dimP(a);
   const int64_t n_obs = a->offsets[a->n_funct];
   std::vector<double> B((size_t)n_obs * P), tmp;
@@ -312,8 +369,8 @@ static int make_handle(const bfmmm_entry_args* a, const bfmmm_config* cfg, bfmmm
     pen_band = stride;
     stride *= a->n_internal_hd[j] + a->basis_degree_hd[j] + 1;
   }
-  return bfmmm_create_from_basis(cfg, a->device, a->y, B.data(), a->offsets, P, std::min(band, P - 1), Pm.data(),
-                                 std::min(pen_band, P - 1), h);
+  return bfmmm_create_from_basis_batch(cfg, device, a->y, B.data(), a->offsets, P, std::min(band, P - 1), Pm.data(),
+                                       std::min(pen_band, P - 1), n_chains, h);
 }
 
 static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a, const char* name) {
@@ -326,7 +383,7 @@ static int fetch_basis(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args*
   return 0;
 }
 
-static int attach_cov(bfmmm_handle* h, const bfmmm_entry_args* a) {
+static int attach_cov(bfmmm_handle* h, const bfmmm_entry_args* a) {      // every chain of the sampler
   if (!a->X) return 0;
   return bfmmm_set_covariates(h, a->X, a->D, a->covariance_adj);
 }
@@ -348,8 +405,7 @@ static int fetch_cov(bfmmm_handle* h, bfmmm_result* r, const bfmmm_entry_args* a
 
 // ------------------------------------------------------------------------------------------------
 static int setup_nu_z(bfmmm_handle* h, int chain, const void* ctx) {
-  const bfmmm_entry_args* a = (const bfmmm_entry_args*)ctx;
-  if (attach_cov(h, a)) return 1;                                // eta = 0, tau_eta = 1 (BFMMM.h:3705-3722)
+  const bfmmm_entry_args* a = (const bfmmm_entry_args*)ctx;       // (covariates attached per sampler: eta = 0, tau_eta = 1, BFMMM.h:3705-3722)
   return bfmmm_init_state(h, 0, a->seed, (uint32_t)chain);      // BFMMM.h:1039-1071
 }
 
@@ -387,7 +443,6 @@ struct ThetaCtx {
 
 static int setup_theta(bfmmm_handle* h, int chain, const void* ctx) {
   const ThetaCtx* t = (const ThetaCtx*)ctx;
-  if (attach_cov(h, t->a)) return 1;
   if (bfmmm_init_state(h, 1, t->a->seed, (uint32_t)chain)) return 1;             // BFMMM.h:1210-1235
   if (t->a->X && bfmmm_set_state(h, "eta", t->eta_est.data(), (int64_t)t->eta_est.size())) return 1;   // BFMMM.h:3936-3942
   if (bfmmm_set_state(h, "Z", t->Z_est.data(), (int64_t)t->Z_est.size())) return 1;   // BFMMM.h:1244-1250
@@ -627,7 +682,7 @@ extern "C" int bfmmm_BFMMM_warm_start(const bfmmm_entry_args* a, const bfmmm_res
   bfmmm_config cfg;
   make_cfg(a, batched ? rs : T, &cfg);          // chain slots in HBM
   bfmmm_handle* h = nullptr;
-  if (make_handle(a, &cfg, &h)) return efail_lib();
+  if (make_handle(a, &cfg, a->device, 1, &h)) return efail_lib();
   const uint32_t mask_ws = BFMMM_SWEEP_WARM | (a->X ? (BFMMM_COV_MEAN | (a->covariance_adj ? BFMMM_COV_XI : 0)) : 0);   // BFMMM.h:4248-4312 / 4809-4894
   int rc = attach_cov(h, a) ||
            (a->X && (bfmmm_set_state(h, "eta", eta_est.data(), (int64_t)eta_est.size()) ||

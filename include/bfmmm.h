@@ -110,6 +110,15 @@ int bfmmm_select_chain(bfmmm_handle* h, int q);
 int bfmmm_n_chains(const bfmmm_handle* h);
 int bfmmm_set_chain_id_stride(bfmmm_handle* h, uint32_t stride);
 
+/* Final gather of a multi-GPU multi-try (the reference keeps the best of its 1 + n_try chains, src/UserFunctions.cpp:302-325,
+ * :861-885).  handles[g], g < n_handles, live on distinct devices of THIS process, were created with the same configuration
+ * and have their best chain selected (bfmmm_select_chain); scores[g] / chain_ids[g] are that chain's score and chain index
+ * (NaN score: the device holds no valid chain).  One RCCL communicator over the devices: ncclAllGather of the
+ * (score, chain index) pairs, then the winner's chain (state and every chain slot) is sent over xGMI (ncclSend / ncclRecv)
+ * into the selected chain of handles[0].  *winner = index of the winning handle (largest score, lowest chain index on
+ * ties).  This is the only inter-GPU exchange of the library: nothing is communicated inside a chain. */
+int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, const double* scores, const int32_t* chain_ids, int* winner);
+
 /* Covariate adjustment (the `X` argument of the reference's entry points, UserFunctions.cpp:176): X is the
  * n_funct x D column-major covariate matrix; covariance_adj != 0 enables the Xi block (BFMMM.h:4602 vs :4067).
  * Call once, right after bfmmm_create.  Adds the state / chain names "eta" (P x D x K), "xi" and "gamma_xi"

@@ -64,7 +64,7 @@ typedef struct {
   uint64_t seed;
   int32_t device;
   int32_t chain_offset, chain_stride;
-  int32_t max_concurrent;          /* chains run concurrently on the device (>= 1) */
+  int32_t max_concurrent;          /* chains per sampler batch: that many multi-try chains advance in lockstep on a device (>= 1) */
   /* multivariate model (BMVMMM_*): model = 1, y = the n_funct x P column-major matrix `Y`
    * (UserFunctions.cpp:4582); t, offsets and the knot arguments are ignored */
   int32_t model;
@@ -97,6 +97,12 @@ typedef struct {
   int32_t progress_every;
   int (*progress_cb)(int32_t iter, double loglik, void* user);
   void* progress_user;
+  /* multi-GPU multi-try: with n_devices > 0 the chains of this call are dealt round-robin over devices[0 .. n_devices)
+   * (one host thread and one sampler batch per device) and the best chain is selected by the RCCL gather of
+   * bfmmm_gather_best (bfmmm.h): an all-gather of one score per device, then the winner's chain is sent over xGMI to
+   * devices[0].  n_devices == 0: everything runs on `device`, no communicator is created. */
+  const int32_t* devices;
+  int32_t n_devices;
 } bfmmm_entry_args;
 
 /* fills in the reference defaults of the named entry point:
