@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- Gibbs iterations/sec of the BFMMM warm-start sweep on MI355X.
+"""bench.py -- Gibbs iterations/sec of the BayesFMMM sweep on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], SURVEY.md 8(d) "Config 2"): n_funct=4096 curves, n_i=100
-(t = 0:10:990), cubic B-splines with 26 equispaced internal knots (P=30), K=3, M=6, fp64,
-full warm-start sweep of BFMMM_MTT_warm_start (Z, pi, alpha_3, Phi, delta, A, gamma, nu, tau,
-sigma^2, chi + log-likelihood; BFMMM.h:1502-1553,1670), chain started at the generating values,
-reference default hyper-parameters.  A "step" is one Gibbs iteration of one chain.
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank runs an independent chain
-of the same workload (multi-try chains are independent) -- weak scaling, no
-data-path collective; RCCL is used for the barrier and the final gather only.
+A "step" is one Gibbs iteration of every chain in flight.  Data: SURVEY.md 8(d) "Config 2" (n_funct = 4096 curves of
+n_i = 100 points, cubic B-splines with 26 internal knots => P = 30, K = 3, M = 6, fp64), synthetic.
+
+N = 1   `value` = the headline of BASELINE.json configs[1]: ONE chain of the full warm-start sweep of BFMMM_MTT_warm_start
+        (Z, pi, alpha_3, Phi, delta, A, gamma, nu, tau, sigma^2, chi + log-likelihood; BFMMM.h:1502-1553, :1670), started at
+        the generating values, inputs and chain resident in HBM.  The same line carries `roofline` (per-kernel HIP-event
+        times of the same sweep, SURVEY 8(d) bytes, measured bytes), `cpu_baseline` (the oracle on one host core) and, as
+        extra keys, `config5` (the 8 multi-try chains of configs[4] on this one GPU) and `other_configs` (configs[2], [3]).
+N > 1   `value` = BASELINE.json configs[4] / SURVEY 8(d) "Config 5": the 8 chains of BFMMM_Nu_Z_multiple_try (n_try = 7;
+        reduced sweep Z, pi, alpha_3, nu, tau, sigma^2, log-likelihood, BFMMM.h:1073-1113) on the config-2 data, dealt
+        round-robin over the N ranks, each rank running its chains as ONE sampler batch; total chain-iterations / time of
+        the slowest rank (strong scaling: 8 chains whatever N).  No collective inside the timed steps -- chains are
+        independent (src/UserFunctions.cpp:302-325); the reference's final selection (all-gather of one score per rank +
+        broadcast of the winning chain, RCCL) is timed separately: `gather_s`, `time_to_best_chain_s` = steps + gather.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,7 +31,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, HBM section)
+FP64_MFMA_PEAK_TF = 78.6    # dense fp64 matrix peak (the same as the vector fp64 peak)
+N_CHAINS_CONFIG5 = 8        # 1 + n_try, n_try = 7
 
 
 def make_config2(n=4096, n_i=100, K=3, M=6, n_internal=26, seed=1):
@@ -54,51 +63,170 @@ def make_config2(n=4096, n_i=100, K=3, M=6, n_internal=26, seed=1):
                 boundary_knots=np.array([b0, b1]), K=K, M=M, P=P, n=n, n_i=n_i, degree=degree, state=state)
 
 
-def algorithmic_bytes_per_iteration(n, P, M, K, n_blocks=5):
-    """B_alg = N_blocks * n * 8 * (P^2 + P + 1) + 8 * n * (2M + 2K)."""
-    return n_blocks * n * 8 * (P * P + P + 1) + 8 * n * (2 * M + 2 * K)
+def algorithmic_bytes_per_iteration(n, P, M, K, n_blocks=5, dense=True, bw=3):
+    """B_alg = N_blocks * n * 8 * (P^2 + P + 1) + 8 * n * (2M + 2K).
+    dense=False: the same count with the band-packed record this build keeps ((bw + 1) P + P + 1 doubles per curve)."""
+    rec = (P * P + P + 1) if dense else ((bw + 1) * P + P + 1)
+    return n_blocks * n * 8 * rec + 8 * n * (2 * M + 2 * K)
+
+
+def host_cpu():
+    """model name and logical core count of the host (SURVEY.md 8(d) asks for lscpu's)"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
 
 
 def cpu_baseline(w, iters=2):
-    """Times the CPU oracle (reference-structure C restatement of the Armadillo sweep, 1 thread, the
-    reference is single-threaded) on a bounded sample of the SAME workload: `iters` full-size
-    warm-start sweeps (about 12 s each on a 2-3 GHz x86 core)."""
+    """Times the CPU oracle (reference-structure C restatement of the Armadillo sweep, 1 thread: the reference is
+    single-threaded, src/Makevars has OpenMP flags but the sources no pragma) on a bounded sample of the SAME workload:
+    `iters` full-size warm-start sweeps (about 6 s each on a 2-3 GHz x86 core)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     model = O.Model(w["y"], w["B"], w["K"], w["M"])
-    ch = O.Chain(model, iters)
     names = {"alpha_3": "alpha3", "sigma_sq": "sigma"}
-    for nm, v in w["state"].items():
-        arr = getattr(ch, names.get(nm, nm))
-        if nm == "tau":
-            arr[0, :] = v
-        elif arr.ndim == 1:
-            arr[0] = v[0]
-        else:
-            arr[..., 0] = v
+
+    def start_chain(T):
+        ch = O.Chain(model, T)
+        for nm, v in w["state"].items():
+            arr = getattr(ch, names.get(nm, nm))
+            if nm == "tau":
+                arr[0, :] = v
+            elif arr.ndim == 1:
+                arr[0] = v[0]
+            else:
+                arr[..., 0] = v
+        return ch
     h = O.make_hyper(w["K"])
+    ch = start_chain(iters)
     t0 = time.perf_counter()
     O.run_sweeps(model, h, ch, O.SWEEP_WARM, n_iter=iters, seed=1)
     dt = time.perf_counter() - t0
     # the same sweep in sufficient-statistics ("Gram") form on the same core (oracle/gram.c): splits the GPU speed-up
     # into its algorithmic part (this / the reference-structure loops) and its hardware part (GPU / this)
     g_iters = 20
-    ch2 = O.Chain(model, g_iters)
-    for nm, v in w["state"].items():
-        arr = getattr(ch2, names.get(nm, nm))
-        if nm == "tau":
-            arr[0, :] = v
-        elif arr.ndim == 1:
-            arr[0] = v[0]
-        else:
-            arr[..., 0] = v
-    dtg = O.run_warm_gram(model, h, ch2, n_iter=g_iters, seed=1)
-    return dict(value=iters / dt, unit="Gibbs iterations/sec", cores=1, kind="port",
+    dtg = O.run_warm_gram(model, h, start_chain(g_iters), n_iter=g_iters, seed=1)
+    cpu_model, ncores = host_cpu()
+    return dict(value=iters / dt, unit="Gibbs iterations/sec", cores=1, kind="port", host_cpu=cpu_model,
+                host_logical_cores=ncores,
                 sample=f"{iters} full-size warm-start sweeps (n_funct={w['n']}) of the reference-structure C "
-                       f"restatement of the Armadillo path, {dt:.1f} s, gcc -O2, 1 thread",
+                       f"restatement of the Armadillo path, {dt:.1f} s, gcc -O2, 1 thread (the reference is single-threaded)",
                 gram_form=dict(value=g_iters / dtg, unit="Gibbs iterations/sec", cores=1,
                                sample=f"{g_iters} sweeps of the same restatement in sufficient-statistics form "
                                       f"(oracle/gram.c), {dtg:.1f} s; G_i, s_i, yy_i prepared once, not timed"))
+
+
+def pmc_summary():
+    """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh), condensed by
+    tools/summarize_profile.py into profiles/*_pmc_summary.json (reads corrected x2 as MI355X_MICROARCH.md prescribes
+    for gfx950).  The newest committed summary, or None."""
+    summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc_summary.json")))
+    if not summ:
+        return None, None
+    try:
+        return json.load(open(summ[-1])), os.path.basename(summ[-1])
+    except Exception:
+        return None, None
+
+
+KERNELS_OF = {"sweep": ["k_sweep_fast", "k_sweep", "k_sweep_diag"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
+              "pair_gram": ["k_pair_gram", "k_pg_reduce"], "factor": ["k_factor"]}
+
+
+def measured_bytes(pm, fam):
+    if not pm:
+        return None
+    tb, hit = 0.0, False
+    for kn in KERNELS_OF.get(fam, []):
+        if kn in pm and pm[kn].get("hbm_read_bytes_per_launch") is not None:
+            tb += pm[kn]["hbm_read_bytes_per_launch"] + (pm[kn].get("hbm_write_bytes_per_launch") or 0.0)
+            hit = True
+    return tb if hit else None
+
+
+def run_config5(bf, w, device, chain_ids, steps, warmup, seed=1):
+    """This rank's share of the 8 multi-try chains as ONE sampler batch, warmed up and with its graphs captured;
+    returns (sampler, number of chain slots)."""
+    T = warmup + steps
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"], tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=device, n_chains=len(chain_ids))
+    stride = (chain_ids[1] - chain_ids[0]) if len(chain_ids) > 1 else 1
+    smp.set_chain_id_stride(stride)
+    for q, cid in enumerate(chain_ids):
+        smp.select_chain(q)
+        smp.init_state(0, seed, chain=cid)          # BFMMM_Nu_Z's own starting state (BFMMM.h:1039-1071)
+    smp.run(bf.SWEEP_NU_Z, warmup, first_iter=0, seed=seed, chain=chain_ids[0], phi_chi_zero=True)
+    smp.prepare_run(bf.SWEEP_NU_Z, steps, first_iter=warmup, seed=seed, chain=chain_ids[0], phi_chi_zero=True)
+    return smp, T
+
+
+def config5_scores(smp, chain_ids, T):
+    """per-chain score of the reference's selection: mean of the last 99 log-likelihood values (UserFunctions.cpp:309)"""
+    out = []
+    for q in range(len(chain_ids)):
+        smp.select_chain(q)
+        ll = smp.get_chain("loglik", T)
+        assert np.isfinite(ll).all()
+        out.append(float(ll[max(T - 99, 0):].mean()))
+    return out
+
+
+def other_configs(bf, steps=200, warmup=20):
+    """BASELINE.json configs[2] (covariate-adjusted, D = 5) and configs[3] (multivariate) on this GPU: ms per sweep and the
+    SURVEY 8(d) byte fraction, so that driver-run numbers exist for them."""
+    S = bf.sampler
+    out = {}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_config3 import make_config3
+    w = make_config3()
+    T = steps + warmup
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=3, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"])
+    smp.set_covariates(w["X"], True)
+    smp.set_state(**w["state"])
+    smp.set_state(eta=w["eta"], xi=w["xi"])
+    mask = S.SWEEP_WARM | S.COV_MEAN | S.COV_XI
+    smp.run(mask, warmup, seed=2)
+    smp.prepare_run(mask, steps, first_iter=warmup, seed=2)
+    t0 = time.perf_counter()
+    smp.run(mask, steps, first_iter=warmup, seed=2)
+    dt = (time.perf_counter() - t0) / steps
+    n, P, M, K, D = w["n"], w["P"], w["M"], w["K"], w["D"]
+    b_alg = 7 * n * 8 * (P * P + P + 1) + 8 * n * (2 * M + 2 * K) + 8 * n * D
+    out["config3"] = dict(workload="covariate-adjusted Mean_CovAdj sweep (19 updates, BFMMM.h:4809-4894), n_funct=4096, D=5, K=3, P=30, M=6",
+                          steps=steps, ms_per_sweep=dt * 1e3, iterations_per_s=1.0 / dt, algorithmic_bytes=b_alg,
+                          hbm_frac=b_alg / dt / 1e9 / HBM_PEAK_GBS)
+    smp.close()
+    rng = np.random.default_rng(4)
+    n, P, K, M = 8192, 50, 4, 8
+    nu = rng.standard_normal((K, P)) * 2
+    Phi = np.stack([(M - m) / M * 0.5 * rng.standard_normal((K, P)) for m in range(M)], axis=2)
+    chi = rng.standard_normal((n, M))
+    Z = rng.dirichlet(np.ones(K), size=n)
+    Z = np.clip(Z, 1e-10, None)
+    Z /= Z.sum(axis=1, keepdims=True)
+    Y = Z @ nu + np.einsum("ik,im,kpm->ip", Z, chi, Phi) + np.sqrt(0.001) * rng.standard_normal((n, P))
+    cfg = bf.default_config(model=bf.MODEL_MULTIVARIATE, K=K, n_eigen=M, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, Y)
+    smp.set_state(nu=nu, Phi=Phi, chi=chi, Z=Z, pi=np.full(K, 1.0 / K), alpha_3=[10.0], delta=np.ones((K, M)),
+                  A=np.ones((K, 2)), gamma=np.ones((K, P, M)), tau=np.ones(K), sigma_sq=[0.001])
+    smp.run(S.SWEEP_WARM, warmup, seed=2)
+    smp.prepare_run(S.SWEEP_WARM, steps, first_iter=warmup, seed=2)
+    t0 = time.perf_counter()
+    smp.run(S.SWEEP_WARM, steps, first_iter=warmup, seed=2)
+    dt = (time.perf_counter() - t0) / steps
+    b_alg = 5 * n * P * 8 + 8 * n * (2 * M + 2 * K)
+    out["config4"] = dict(workload="BMVMMM warm-start sweep (BFMMM.h:2597-2650), N=8192, dim=50, K=4, M=8", steps=steps,
+                          ms_per_sweep=dt * 1e3, iterations_per_s=1.0 / dt, algorithmic_bytes=b_alg,
+                          hbm_frac=b_alg / dt / 1e9 / HBM_PEAK_GBS)
+    smp.close()
+    return out
 
 
 def main():
@@ -109,9 +237,7 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent-chains", type=int, default=8,
-                    help="extra (untimed-region) measurement: this many independent chains at once on GPU 0")
-    ap.add_argument("--concurrent-steps", type=int, default=400)
+    ap.add_argument("--no-extras", action="store_true", help="skip config5 / other_configs at N = 1 (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,20 +245,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # rehearsal on a box with fewer GPUs than ranks (BFMMM_BENCH_BACKEND=gloo): the ranks share the visible devices and
+    # the final gather runs over gloo; the driver's runs use one GPU per rank and RCCL ("nccl")
+    backend = os.environ.get("BFMMM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import bayesfmmm_amd as bf
     w = make_config2(n=args.n, seed=1)
-    T = args.warmup + args.steps
-    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"],
-                            tot_mcmc_iters=max(T, args.profile_steps))
-    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
-    smp.set_state(**w["state"])
+    n, P, M, K = w["n"], w["P"], w["M"], w["K"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,116 +268,187 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    chain_id = rank                                      # independent chain per rank
-    smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=chain_id)
-    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=chain_id)   # graph capture is set-up
+    if world > 1:
+        # ---------------- config 5: 8 multi-try chains dealt over the ranks ----------------
+        chain_ids = list(range(rank, N_CHAINS_CONFIG5, world))
+        smp, T = (None, args.warmup + args.steps)
+        if chain_ids:
+            smp, T = run_config5(bf, w, local_rank, chain_ids, args.steps, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        if smp is not None:
+            smp.run(bf.SWEEP_NU_Z, args.steps, first_iter=args.warmup, seed=1, chain=chain_ids[0], phi_chi_zero=True)
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # final selection of BFMMM_Nu_Z_multiple_try (UserFunctions.cpp:302-325): score all-gather + winner broadcast
+        from bayesfmmm_amd import parallel
+        t1 = time.perf_counter()
+        local = None
+        if smp is not None:
+            scores = config5_scores(smp, chain_ids, T)
+            b = int(np.argmax(scores))
+            smp.select_chain(b)
+            local = dict(best_score=scores[b], best_chain=float(chain_ids[b]))
+            for nm in ("nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik", "A", "delta"):
+                local[nm] = smp.get_chain(nm, T)
+        best = parallel.gather_select_broadcast(local, None)
+        barrier()
+        gather_s = time.perf_counter() - t1
+        assert np.isfinite(best["loglik"]).all() and best["Z"].shape == (n, K, T)
+        if rank == 0:
+            total = N_CHAINS_CONFIG5 * args.steps
+            b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K          # SURVEY 8(d) config 5, per chain-iteration
+            out = {
+                "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30", "value": total / dt,
+                "unit": "Gibbs iterations/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains of the Nu_Z sweep), n_funct={n}, "
+                                       f"n_i={w['n_i']}, K={K}, P={P}, fp64, chains dealt round-robin over {world} GPUs "
+                                       f"({-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch)",
+                           "chains": N_CHAINS_CONFIG5, "chains_per_gpu": -(-N_CHAINS_CONFIG5 // world)},
+                "roofline": {"bound": "hbm", "kernel": "iteration (all kernels of a chain-iteration)",
+                             "achieved": b_alg5 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": b_alg5 * total / dt / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                             "note": "SURVEY 8(d) config-5 bytes (3 blocks x n x 8 (P^2+P+1) per chain-iteration) x "
+                                     "chain-iterations/s against N x 8 TB/s; per-kernel figures are on the N = 1 line"},
+                "gather_s": gather_s, "time_to_best_chain_s": dt + gather_s,
+                "best_chain": best["best_chain"], "best_score": best["best_score"],
+            }
+            print(json.dumps(out))
+        if smp is not None:
+            smp.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---------------- N = 1: the single-chain headline (BASELINE.json configs[1]) ----------------
+    T = args.warmup + args.steps
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=w["degree"],
+                            tot_mcmc_iters=max(T, args.profile_steps))
+    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
+    smp.set_state(**w["state"])
+    smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=0)
+    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=0)   # graph capture is set-up
     barrier()
     t0 = time.perf_counter()
-    smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=chain_id)
+    smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=0)
     barrier()
     dt = time.perf_counter() - t0
     dev_ms, _ = smp.timing("total")
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    loglik = smp.get_chain("loglik", T)
-    assert np.isfinite(loglik).all()
+    assert np.isfinite(smp.get_chain("loglik", T)).all()
+    value = args.steps / dt
 
-    # per-kernel HIP-event pass (same sweep, eager launches bracketed by events on the sampler's stream)
+    # per-kernel pass: the same sweep, eager launches bracketed by HIP events on the sampler's stream (a replayed graph
+    # cannot carry per-launch events; the brackets add about 3 us per launch, so these are upper bounds -- the rocprofv3
+    # averages of the same command are committed under profiles/)
     fams = {}
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
         smp.set_state(**w["state"])
         smp.set_profile(True)
-        smp.run(bf.SWEEP_WARM, args.profile_steps, first_iter=0, seed=1, chain=chain_id)
+        smp.run(bf.SWEEP_WARM, args.profile_steps, first_iter=0, seed=1, chain=0)
         for nm in ["curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik"]:
             ms, cnt = smp.timing(nm)
-            fams[nm] = dict(ms_per_launch=ms / max(cnt, 1), launches=cnt)
+            fams[nm] = dict(ms_per_launch=ms / max(cnt, 1), launches=cnt, ms_per_iteration=ms / args.profile_steps)
         smp.set_profile(False)
+    smp.close()
 
-    # extra: aggregate throughput of C independent chains sharing GPU 0 (multi-try chains are independent;
-    # the single-chain sweep is latency-bound and leaves most CUs idle)
-    multi = None
-    if rank == 0 and args.concurrent_chains > 1 and world == 1:
-        import threading
-        C_ = args.concurrent_chains
-        cfg2 = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"],
-                                 tot_mcmc_iters=args.concurrent_steps + 10)
-        smps = [bf.Sampler(cfg2, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
-                for _ in range(C_)]
-        for q, s_ in enumerate(smps):
-            s_.set_state(**w["state"])
-            s_.run(bf.SWEEP_WARM, 10, first_iter=0, seed=1, chain=100 + q)
-
-        def work(q):
-            smps[q].run(bf.SWEEP_WARM, args.concurrent_steps, first_iter=10, seed=1, chain=100 + q)
+    b_alg = algorithmic_bytes_per_iteration(n, P, M, K)
+    b_band = algorithmic_bytes_per_iteration(n, P, M, K, dense=False)
+    # SURVEY 8(d) data-touching blocks each kernel family implements (k_curve_chi carries chi + the next iteration's Z)
+    blocks = {"curve_z": 1, "pair_gram": 2, "sweep": 1, "curve_chi": 2, "factor": 0, "loglik": 0}
+    pm, pm_file = pmc_summary()
+    roofline = None
+    if fams:
+        # dominant kernel = largest time PER ITERATION among the families that run every iteration
+        every = [k for k in fams if blocks[k] > 0 and fams[k]["launches"] >= args.profile_steps]
+        dom = max(every, key=lambda k: fams[k]["ms_per_iteration"])
+        ms = fams[dom]["ms_per_launch"]
+        bytes_dom = blocks[dom] * n * 8 * (P * P + P + 1)
+        ach = bytes_dom / (ms * 1e-3) / 1e9
+        it_bytes = None
+        if pm:
+            parts = [measured_bytes(pm, f) for f in ("pair_gram", "factor", "sweep", "curve_chi")]
+            it_bytes = sum(p for p in parts if p is not None) if any(p is not None for p in parts) else None
+        # pair-Gram contraction on the fp64 matrix cores: [R pair rows x n] . [n x (BW+1) P + P columns]
+        R_pairs, A_dirs = (K * (K + 1) // 2) * ((M + 1) * (M + 2) // 2), K * (M + 1)
+        pg_flop = 2.0 * n * (R_pairs * 4 * P + A_dirs * P)
+        roofline = dict(
+            bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+            traffic=measured_bytes(pm, dom), traffic_source=pm_file,
+            algorithmic_bytes_per_launch=bytes_dom,
+            iteration=dict(algorithmic_bytes=b_alg, achieved=b_alg * value / 1e9, frac=b_alg * value / 1e9 / HBM_PEAK_GBS,
+                           banded_record_bytes=b_band, banded_frac=b_band * value / 1e9 / HBM_PEAK_GBS,
+                           measured_bytes=it_bytes,
+                           measured_frac=None if it_bytes is None else it_bytes * value / 1e9 / HBM_PEAK_GBS),
+            per_kernel_ms={k: round(v["ms_per_launch"], 6) for k, v in fams.items()},
+            per_kernel_ms_per_iteration={k: round(v["ms_per_iteration"], 6) for k, v in fams.items()},
+            mfma=dict(kernel="k_pair_gram", flop_per_launch=pg_flop,
+                      achieved_tflops=pg_flop / (fams["pair_gram"]["ms_per_launch"] * 1e-3) / 1e12,
+                      peak_tflops=FP64_MFMA_PEAK_TF,
+                      frac=pg_flop / (fams["pair_gram"]["ms_per_launch"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
+                      note="event-bracketed time of the pair_gram family; counter evidence: profiles/*_mfma_pmc.json"),
+            note="`achieved` charges the dominant kernel the SURVEY 8(d) bytes of the update blocks it implements; the "
+                 "sweep is a chain of K*M + K dependent P x P steps bound by step latency, not by bytes: `traffic` "
+                 "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch) and iteration.measured_* are what actually moves")
+    out = {
+        "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30",
+        "value": value, "unit": "Gibbs iterations/sec", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BFMMM_warm_start sweep, n_funct={n}, n_i={w['n_i']}, K={K}, P={P}, M={M}, fp64, one chain",
+                   "chains": 1, "device_ms_per_step": dev_ms / args.steps},
+        "roofline": roofline,
+    }
+    if not args.no_extras:
+        # config 5 on this one GPU: the N = 1 point of the 8-chain curve the N > 1 runs report
+        c5_steps, c5_warm = max(args.steps, 100), max(args.warmup, 20)
+        chain_ids = list(range(N_CHAINS_CONFIG5))
+        s5, T5 = run_config5(bf, w, local_rank, chain_ids, c5_steps, c5_warm)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s5.run(bf.SWEEP_NU_Z, c5_steps, first_iter=c5_warm, seed=1, chain=0, phi_chi_zero=True)
+        torch.cuda.synchronize()
+        dt5 = time.perf_counter() - t0
         t1 = time.perf_counter()
-        ths = [threading.Thread(target=work, args=(q,)) for q in range(C_)]
-        [t_.start() for t_ in ths]
-        [t_.join() for t_ in ths]
+        scores = config5_scores(s5, chain_ids, T5)
+        bsel = int(np.argmax(scores))
+        s5.select_chain(bsel)
+        keep = {nm: s5.get_chain(nm, T5) for nm in ("nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik", "A", "delta")}
+        sel_s = time.perf_counter() - t1
+        assert keep["Z"].shape == (n, K, T5)
+        s5.close()
+        b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K
+        tot5 = N_CHAINS_CONFIG5 * c5_steps
+        out["config5"] = dict(workload="BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains, Nu_Z sweep) on the config-2 data, "
+                                       "all 8 on this GPU as one sampler batch", chains=N_CHAINS_CONFIG5, steps=c5_steps,
+                              value=tot5 / dt5, unit="Gibbs iterations/sec (all chains)", ms_per_step=dt5 / c5_steps * 1e3,
+                              hbm_frac=b_alg5 * tot5 / dt5 / 1e9 / HBM_PEAK_GBS, gather_s=sel_s,
+                              time_to_best_chain_s=dt5 + sel_s, best_chain=chain_ids[bsel])
+        # 8 warm-start chains (the headline sweep) as one batch on this GPU
+        cfg8 = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=w["degree"], tot_mcmc_iters=c5_warm + c5_steps)
+        s8 = bf.Sampler(cfg8, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank, n_chains=8)
+        for q in range(8):
+            s8.select_chain(q)
+            s8.set_state(**w["state"])
+        s8.run(bf.SWEEP_WARM, c5_warm, first_iter=0, seed=1, chain=100)
+        s8.prepare_run(bf.SWEEP_WARM, c5_steps, first_iter=c5_warm, seed=1, chain=100)
         torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        multi = dict(chains=C_, steps_per_chain=args.concurrent_steps, value=C_ * args.concurrent_steps / dt2,
-                     unit="Gibbs iterations/sec (all chains)")
-        for s_ in smps:
-            s_.close()
-
-    if rank == 0:
-        n, P, M, K = w["n"], w["P"], w["M"], w["K"]
-        value = world * args.steps / dt
-        b_alg = algorithmic_bytes_per_iteration(n, P, M, K)
-        # dominant kernel = the family with the largest time per iteration; its algorithmic bytes are the
-        # data-touching update blocks it implements (n*8*(P^2+P+1) per block)
-        # (k_curve_chi also carries the next iteration's Z update since the fusion: two blocks; "curve_z" is the single
-        #  stand-alone launch at the start of a run)
-        blocks = {"curve_z": 1, "pair_gram": 2, "sweep": 1, "curve_chi": 2, "factor": 0, "loglik": 0}
-        roofline = None
-        if fams:
-            dom = max((k for k in fams if blocks[k] > 0), key=lambda k: fams[k]["ms_per_launch"])
-            ms = fams[dom]["ms_per_launch"]
-            bytes_dom = blocks[dom] * n * 8 * (P * P + P + 1)
-            ach = bytes_dom / (ms * 1e-3) / 1e9
-            # measured HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (tools/profile_round.sh), condensed by tools/summarize_profile.py into profiles/ (read is corrected
-            # x2 as MI355X_MICROARCH.md prescribes for gfx950); null when no summary is committed
-            traffic = None
-            try:
-                import glob
-                summ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.json")))
-                if summ:
-                    pm = json.load(open(summ[-1]))
-                    kname = {"sweep": ["k_sweep_fast", "k_sweep"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
-                             "pair_gram": ["k_pair_gram", "k_pg_reduce"]}[dom]
-                    tb = 0.0
-                    for kn in kname:
-                        if kn in pm and pm[kn].get("hbm_read_bytes_per_launch") is not None:
-                            tb += pm[kn]["hbm_read_bytes_per_launch"] + (pm[kn].get("hbm_write_bytes_per_launch") or 0.0)
-                    traffic = tb if tb > 0 else None
-            except Exception:
-                traffic = None
-            roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBS, traffic=traffic,
-                            iteration_achieved=b_alg * (args.steps / dt) / 1e9,
-                            iteration_frac=b_alg * (args.steps / dt) / 1e9 / HBM_PEAK_GBS,
-                            per_kernel_ms={k: round(v["ms_per_launch"], 6) for k, v in fams.items()})
-        out = {
-            "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30",
-            "value": value, "unit": "Gibbs iterations/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BFMMM_warm_start sweep, n_funct={n}, n_i={w['n_i']}, K={K}, P={P}, M={M}, "
-                                   f"fp64, one independent chain per GPU", "chains": world,
-                       "device_ms_per_step": dev_ms / args.steps},
-            "roofline": roofline,
-            "multi_chain": multi,
-        }
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        t0 = time.perf_counter()
+        s8.run(bf.SWEEP_WARM, c5_steps, first_iter=c5_warm, seed=1, chain=100)
+        torch.cuda.synchronize()
+        dt8 = time.perf_counter() - t0
+        s8.close()
+        out["multi_chain"] = dict(chains=8, steps_per_chain=c5_steps, value=8 * c5_steps / dt8,
+                                  unit="Gibbs iterations/sec (all chains)", ms_per_step=dt8 / c5_steps * 1e3,
+                                  workload="8 independent chains of the warm-start sweep as one sampler batch on this GPU")
+        out["other_configs"] = other_configs(bf)
+    if not args.no_cpu_baseline:      # rank 0's host cores
+        out["cpu_baseline"] = cpu_baseline(w)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -9,10 +9,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --concurrent-chains 0 --profile-steps 0 > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_trace.log" 2>&1
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --concurrent-chains 0 --profile-steps 0 > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_fetch.log" 2>&1
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --concurrent-chains 0 --profile-steps 0 > "$OUT/bench_write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_write.log" 2>&1
 echo "write done"
 find "$OUT" -name "*.csv" | head -20
