@@ -10,7 +10,9 @@
 // The two triangular recursions are chains of P dependent pivots, so they run in the registers of
 // ONE wave (lane i owns band row i of U, then column i of X; the pivot row travels by v_readlane)
 // instead of through LDS; C = X'X is 16x16x4 fp64 MFMA tiles on all four waves.
-// 256 threads; returns true on the calling thread if a non-positive pivot was met.
+// 256 threads.  Returns true -- on EVERY thread of the workgroup -- when a pivot fell to 1e-12 of the largest diagonal
+// entry or below: the precision is singular to working accuracy, nothing has been written, and the caller takes the
+// pseudo-inverse route (factor_pinv below), as the reference does through arma::pinv / mvnrnd's eigen fallback.
 #pragma once
 #include "model.hpp"
 
@@ -44,12 +46,16 @@ __device__ inline bool factor_wave(double* S, double* X, const double* zv, int P
   }
   double rinv = 0.0;                   // 1 / U(i, i)
   bool bad = false;
+  double dmax = s[0];                  // largest diagonal entry of Prec: the pivots are judged against it
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+  const double thr = 1e-12 * dmax;
   for (int k = P - 1; k >= 0; --k) {
     double dloc = s[0];
 #pragma unroll
     for (int t = 1; t <= BWT; ++t) dloc -= u[t] * u[t];
     const double dk = readlane_f64(dloc, k);
-    if (!(dk > 0.0)) bad = true;
+    if (!(dk > thr)) bad = true;
     // 1 / sqrt(dk) from the hardware estimate and two Newton steps (the pivot is on the 30-step dependent chain:
     // a correctly rounded sqrt followed by a division costs three times as many dependent instructions)
     double rk = __builtin_amdgcn_rsq(dk);
@@ -142,10 +148,13 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
     // wide band (user-supplied / tensor-product bases): plain dense reverse Cholesky in LDS.  S must be fully defined.
     // Prec = U U', U upper, columns from the last to the first: U(k,k) = sqrt(A(k,k)), U(i,k) = A(i,k) / U(k,k) (i < k),
     // then A(i,j) -= U(i,k) U(j,k) for i, j < k (right-looking).  U overwrites the upper triangle of S (S[i + PP*k]).
+    double dmaxw = 0.0;
+    for (int i = 0; i < P; ++i) dmaxw = fmax(dmaxw, S[i + PP * i]);
+    const double thrw = 1e-12 * dmaxw;
     for (int k = P - 1; k >= 0; --k) {
       __syncthreads();                               // the previous column's update of the leading block is complete
       const double dk = S[k + PP * k];
-      if (!(dk > 0.0)) bad = true;
+      if (!(dk > thrw)) bad = true;
       const double rk = 1.0 / sqrt(dk);
       __syncthreads();                               // everyone has the pivot before column k is overwritten
       if (tid <= k) S[tid + PP * k] = (tid == k) ? dk * rk : S[tid + PP * k] * rk;
@@ -175,7 +184,8 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       for (int i = 0; i <= tid; ++i) lz += X[i * PP + tid] * zv[i];
       Lz_out[tid] = lz;
     }
-    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;      // (also publishes X and Lz to every thread)
+    if (bad) return true;
   } else if (tid < 64) {
     switch (bw) {
       case 0: bad = factor_wave<PP, 0>(S, X, zv, P, Lz_out, tid); break;
@@ -186,7 +196,10 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       default: bad = factor_wave<PP, 5>(S, X, zv, P, Lz_out, tid); break;
     }
   }
-  __syncthreads();
+  if (bw <= 5) {                                     // (wave 0 ran the factorisation: its verdict goes to every thread)
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (bad) return true;
+  }
   FCT(2);
   // C = X' X on the matrix cores: tile (pt, qt) of 16 x 16, K = P rounded up to 4 (rows k > min(p, q) of X are zero)
   {
@@ -216,6 +229,115 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       if (p < P && q < P) Lg[p + (size_t)P * q] = (q <= p) ? X[q * PP + p] : 0.0;
     }
   return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pseudo-inverse route for a precision that is singular to working accuracy (factor_core returned true).  The reference
+// takes arma::pinv for nu and eta (UpdateNu.h:67-68, UpdateEta.h:85-86): a cluster without members leaves Prec = tau P_mat
+// of rank P - 1, pinv drops the null direction and arma::mvnrnd -- its Cholesky factorisation of the singular covariance
+// failing -- draws through the symmetric eigen-decomposition.  Same law here, by the specification shared with the
+// oracle (oracle/linalg.c): Prec = V diag(w) V' by Jacobi rotations, eigenpairs by ascending w, eigenvectors signed by
+// the generic-weights rule, winv_k = 1 / w_k above Armadillo's tolerance P max|w| eps and 0 below,
+//     C = V diag(winv) V',     L = V diag(sqrt(winv)),     L z with z in index order.
+// S: the full symmetric PP x PP precision (zero beyond P), X: PP x PP scratch (V), wk: 4 PP + 2 doubles of scratch.
+// A rare path: parallel cyclic Jacobi, PP / 2 disjoint rotations per round (round-robin pairing), three barriers a round.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PP>
+__device__ __noinline__ void factor_pinv(double* S, double* V, const double* zv, int P, double* Cg, double* Lg, double* Lz_out,
+                                         int tid, double* wk) {
+  constexpr int NPR = PP / 2;
+  double* cs = wk;                    // NPR
+  double* sn = wk + NPR;              // NPR
+  double* w = wk + PP;                // PP   eigenvalues, then winv
+  int* pp = (int*)(wk + 2 * PP);      // NPR
+  int* qq = pp + NPR;                 // NPR
+  int* ord = qq + NPR;                // PP   ord[rank] = eigenpair
+  int* flag = ord + PP;               // 1    a rotation was applied in this sweep
+  double* sg = wk + 3 * PP + 1;       // PP   sign of every eigenvector
+  for (int e = tid; e < PP * PP; e += 256) V[e] = ((e % PP) == (e / PP)) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int r = 0; r < PP - 1; ++r) {
+      if (tid < NPR) {
+        const int p = (r + tid) % (PP - 1);
+        const int q = (tid == 0) ? PP - 1 : (r - tid + (PP - 1)) % (PP - 1);
+        const double apq = S[p + PP * q], app = S[p + PP * p], aqq = S[q + PP * q];
+        double c = 1.0, sv = 0.0;
+        if (fabs(apq) > 1e-20 * sqrt(fabs(app * aqq)) && apq != 0.0) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          sv = t * c;
+          *flag = 1;
+        }
+        cs[tid] = c; sn[tid] = sv; pp[tid] = p; qq[tid] = q;
+      }
+      __syncthreads();
+      for (int e = tid; e < PP * NPR; e += 256) {          // columns p, q of S and V
+        const int k = e % PP, i = e / PP, p = pp[i], q = qq[i];
+        const double c = cs[i], sv = sn[i];
+        const double akp = S[k + PP * p], akq = S[k + PP * q];
+        S[k + PP * p] = c * akp - sv * akq;
+        S[k + PP * q] = sv * akp + c * akq;
+        const double vkp = V[k + PP * p], vkq = V[k + PP * q];
+        V[k + PP * p] = c * vkp - sv * vkq;
+        V[k + PP * q] = sv * vkp + c * vkq;
+      }
+      __syncthreads();
+      for (int e = tid; e < PP * NPR; e += 256) {          // rows p, q of S
+        const int k = e % PP, i = e / PP, p = pp[i], q = qq[i];
+        const double c = cs[i], sv = sn[i];
+        const double apk = S[p + PP * k], aqk = S[q + PP * k];
+        S[p + PP * k] = c * apk - sv * aqk;
+        S[q + PP * k] = sv * apk + c * aqk;
+      }
+      __syncthreads();
+    }
+    if (*flag == 0) break;                                 // (uniform: read after the round's last barrier)
+    __syncthreads();
+  }
+  // the real eigenpairs are columns 0 .. P-1 (the zero padding never mixes with them)
+  if (tid < PP) w[tid] = (tid < P) ? S[tid + PP * tid] : 0.0;
+  __syncthreads();
+  if (tid < P) {
+    int rank = 0;
+    double wmax = 0.0;
+    for (int j = 0; j < P; ++j) {
+      if (w[j] < w[tid] || (w[j] == w[tid] && j < tid)) ++rank;
+      wmax = fmax(wmax, fabs(w[j]));
+    }
+    ord[rank] = tid;
+    double gs = 0.0;                  // sign rule of the specification: sum_i g_i v_i > 0, g_i = 1 / (i + 1.37)
+    for (int i = 0; i < P; ++i) {
+      gs += V[i + PP * tid] / ((double)i + 1.37);
+    }
+    sg[tid] = (gs < 0) ? -1.0 : 1.0;
+    const double tol = (double)P * wmax * 2.220446049250313e-16;
+    wk[tid] = (fabs(w[tid]) > tol) ? 1.0 / w[tid] : 0.0;   // winv takes over the (now free) rotation table wk[0 .. PP)
+  }
+  __syncthreads();
+  const double* winv = wk;                                 // PP entries (cs and sn areas)
+  for (int e = tid; e < P * P; e += 256) {
+    const int i = e % P, j = e / P;
+    double acc = 0.0;
+    for (int k = 0; k < P; ++k) acc += V[i + PP * k] * winv[k] * V[j + PP * k];
+    Cg[j + (size_t)P * i] = acc;
+    if (Lg) {                                              // column j of the factor = eigenpair ord[j]
+      const int k = ord[j];
+      Lg[i + (size_t)P * j] = sg[k] * V[i + PP * k] * sqrt(fmax(winv[k], 0.0));
+    }
+  }
+  if (tid < P) {
+    double lz = 0.0;
+    for (int r = 0; r < P; ++r) {
+      const int k = ord[r];
+      lz += sg[k] * V[tid + PP * k] * sqrt(fmax(winv[k], 0.0)) * zv[r];
+    }
+    Lz_out[tid] = lz;
+  }
+  __syncthreads();
 }
 
 }  // namespace bfmmm

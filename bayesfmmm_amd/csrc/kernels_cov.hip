@@ -211,22 +211,25 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c0) {
     for (int m2 = 0; m2 < a.mt; ++m2) tt *= c.delta_xi[a.j + (size_t)K * (m2 + (size_t)M * a.dd)];
   const double te = c.tau_eta[a.j + (size_t)K * a.dd];
   const double* gx = c.gamma_xi + (size_t)a.j * P * D * M;
-  for (int e = tid; e < PP * PP; e += 256) {
-    const int p = e & (PP - 1), q = e / PP;
-    double v = 0.0;
-    if (p < P && q < P) {
-      const int lo = min(p, q), dd = max(p, q) - lo;
-      v = (dd <= d.BW) ? f * hb[dd * P + lo] : 0.0;
-      if (a.mt == 0) {
-        if (d.mv) { if (p == q) v += 1.0 / te; }
-        else v += te * c.Pmat[p + (size_t)P * q];                                   // UpdateEta.h:84
-      } else if (p == q) {
-        v += tt * gx[p + (size_t)P * (a.dd + (size_t)D * (a.mt - 1))];            // UpdateXi.h:76-78
+  auto build_prec = [&]() {        // the full symmetric precision (zero beyond P)
+    for (int e = tid; e < PP * PP; e += 256) {
+      const int p = e & (PP - 1), q = e / PP;
+      double v = 0.0;
+      if (p < P && q < P) {
+        const int lo = min(p, q), dd = max(p, q) - lo;
+        v = (dd <= d.BW) ? f * hb[dd * P + lo] : 0.0;
+        if (a.mt == 0) {
+          if (d.mv) { if (p == q) v += 1.0 / te; }
+          else v += te * c.Pmat[p + (size_t)P * q];                                   // UpdateEta.h:84
+        } else if (p == q) {
+          v += tt * gx[p + (size_t)P * (a.dd + (size_t)D * (a.mt - 1))];            // UpdateXi.h:76-78
+        }
       }
+      S[e] = v;
+      X[e] = 0.0;
     }
-    S[e] = v;
-    X[e] = 0.0;
-  }
+  };
+  build_prec();
   if (tid >= 64 && tid < 64 + P) {
     const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
     const int p = tid - 64;
@@ -234,8 +237,12 @@ __global__ __launch_bounds__(256) void k_cov_factor(Ctx c0) {
     else zv[p] = rnorm(key, UPD_XI, (uint32_t)((((a.j * M + (a.mt - 1)) * D + a.dd) * P) + p));
   }
   __syncthreads();
-  const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.C2 + (size_t)a2 * P * P, nullptr, c.Lz2 + (size_t)a2 * P, tid);
-  if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
+  if (factor_core<PP>(S, X, zv, P, d.BWP, c.C2 + (size_t)a2 * P * P, nullptr, c.Lz2 + (size_t)a2 * P, tid)) {
+    // singular to working accuracy: the reference's arma::pinv route (UpdateEta.h:85-87), factor_pinv here
+    build_prec();
+    __syncthreads();
+    factor_pinv<PP>(S, X, zv, P, c.C2 + (size_t)a2 * P * P, nullptr, c.Lz2 + (size_t)a2 * P, tid, hb + d.LG);
+  }
 }
 
 // ---- one GROUP of the eta / Xi sweep per launch ---------------------------------------------------------
@@ -784,7 +791,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)c.NPG * 128) * sizeof(double);
     hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2, c.nch), dim3(256), lds_w2, st, c);
     const int PP = (d.P <= 32) ? 32 : 64;
-    const size_t lds = (2 * (size_t)PP * PP + PP + d.LG) * sizeof(double);
+    const size_t lds = (2 * (size_t)PP * PP + PP + d.LG + 4 * PP + 2) * sizeof(double);      // + scratch of the pseudo-inverse route
     if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.NPAIR, 1, c.nch), dim3(256), lds, st, c);
     else hipLaunchKernelGGL(k_cov_factor<64>, dim3(c.NPAIR, 1, c.nch), dim3(256), lds, st, c);
     const int n_eta_groups = d.K, n_groups = c.A2 / d.D;

@@ -521,28 +521,36 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c0) {
   double tt = 1.0;
   for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
   // only the band of Prec is read by the factorisation (factor_core): (BWP + 1) x P entries
-  for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
-  if (BW > 5) {                     // the dense factorisation reads all of S
-    for (int e = tid; e < PP * PP; e += 256) S[e] = (e % PP == e / PP) ? 1.0 : 0.0;
-    __syncthreads();
-  }
-#pragma unroll
-  for (int u = 0; u < NPRI; ++u) {
-    const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
-    if (t <= d.BWP && q < P) {
-      double v = (t <= BW) ? f * hb2[p * W + BW + t] : 0.0;
-      if (mt == 0) v += d.mv ? ((t == 0) ? 1.0 / tau_j : 0.0) : tau_j * pri[u];    // UpdateNu.h:197 (MV) / :66
-      else v += tt * pri[u];                                                       // UpdatePhi.h:76-78 (diagonal)
-      S[p + PP * q] = v;
-      if (BW > 5) S[q + PP * p] = v;
+  auto build_prec = [&](bool full) {     // full: the whole symmetric matrix (pseudo-inverse route)
+    for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
+    if (BW > 5 || full) {             // the dense factorisation / the Jacobi rotations read all of S
+      for (int e = tid; e < PP * PP; e += 256) S[e] = (!full && e % PP == e / PP) ? 1.0 : 0.0;
+      __syncthreads();
     }
-  }
+#pragma unroll
+    for (int u = 0; u < NPRI; ++u) {
+      const int e = tid + 256 * u, t = e / PP, p = e - t * PP, q = p + t;
+      if (t <= d.BWP && q < P) {
+        double v = (t <= BW) ? f * hb2[p * W + BW + t] : 0.0;
+        if (mt == 0) v += d.mv ? ((t == 0) ? 1.0 / tau_j : 0.0) : tau_j * pri[u];    // UpdateNu.h:197 (MV) / :66
+        else v += tt * pri[u];                                                       // UpdatePhi.h:76-78 (diagonal)
+        S[p + PP * q] = v;
+        if (BW > 5 || full) S[q + PP * p] = v;
+      }
+    }
+    __syncthreads();
+  };
+  build_prec(false);
   FST(5);
-  __syncthreads();
-  const bool bad = factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P,
-                                   c.Lz + (size_t)a * P, tid, nullptr);
+  double* wkp = dsc + 16;             // 4 PP + 2 doubles: scratch of the pseudo-inverse route
+  if (factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P, c.Lz + (size_t)a * P, tid,
+                      nullptr)) {
+    // singular to working accuracy (e.g. a cluster without members: Prec = tau P_mat): arma::pinv + the eigen route of
+    // arma::mvnrnd in the reference (UpdateNu.h:67-69), factor_pinv here
+    build_prec(true);
+    factor_pinv<PP>(S, X, zv, P, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P, c.Lz + (size_t)a * P, tid, wkp);
+  }
   FST(6);
-  if (bad && tid == 0) atomicOr(&c.dyn->status, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1307,7 +1315,7 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
-  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16) * sizeof(double);
+  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16 + 4 * PP + 2) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + 15) / 16 : 0;       // 16 curves per workgroup (z_proposal.hpp)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;

@@ -199,3 +199,73 @@ void orc_mvnrnd(const orc_rng* r, uint32_t upd, uint32_t idx0, int P,
   }
   free(L); free(z);
 }
+
+/* ---- rank-deficient conditional precisions -------------------------------------------------------------------------
+ * The reference takes arma::pinv for nu and eta (UpdateNu.h:67-68, UpdateEta.h:85-86), so a precision that is singular
+ * to working accuracy -- a cluster nobody belongs to leaves tau * P_mat, whose rank is P - 1 -- is a legal input: pinv
+ * truncates the null directions and arma::mvnrnd, whose Cholesky factorisation of the singular covariance fails, falls
+ * back to the symmetric eigen-decomposition.  Which of Armadillo's branches a borderline matrix takes depends on the last
+ * bit of a pivot, so for THIS case the restatement and the device share a specification instead (draw-level parity with
+ * R is unpinned anyway, oracle.h):
+ *   trigger   a pivot of the reverse Cholesky factorisation Prec = U U' (last row first) is <= 1e-12 * max_i Prec(i,i);
+ *   spectrum  Prec = V diag(w) V' (Jacobi), eigenpairs sorted by ascending w, every eigenvector v signed so that
+ *             sum_i g_i v_i > 0 with the fixed generic weights g_i = 1 / (i + 1.37) (an entry-based
+ *             rule -- "largest entry positive" -- is ambiguous for the symmetric / antisymmetric eigenvectors of a
+ *             random-walk penalty, whose entries come in pairs of equal magnitude);
+ *   C         = V diag(winv) V',  winv_k = 1 / w_k if |w_k| > P * max|w| * eps (Armadillo's pinv tolerance), else 0;
+ *   draw      = C rhs + V diag(sqrt(max(winv, 0))) z,   z ~ N(0, I) in index order (column k of the factor takes z_k).
+ * The law is the one the reference samples from: N(pinv(Prec) rhs, pinv(Prec)). */
+int orc_prec_is_singular(int P, const double* A) {
+  double* U = (double*)calloc((size_t)P * P, sizeof(double));
+  double dmax = 0.0;
+  for (int i = 0; i < P; ++i) dmax = fmax(dmax, A_(i, i));
+  int bad = 0;
+  for (int k = P - 1; k >= 0 && !bad; --k) {
+    double dk = 0.5 * (A_(k, k) + A_(k, k));
+    for (int m = k + 1; m < P; ++m) dk -= U[k + (size_t)P * m] * U[k + (size_t)P * m];
+    if (!(dk > 1e-12 * dmax)) { bad = 1; break; }
+    const double ukk = sqrt(dk);
+    U[k + (size_t)P * k] = ukk;
+    for (int i = 0; i < k; ++i) {
+      double acc = 0.5 * (A_(i, k) + A_(k, i));
+      for (int m = k + 1; m < P; ++m) acc -= U[i + (size_t)P * m] * U[k + (size_t)P * m];
+      U[i + (size_t)P * k] = acc / ukk;
+    }
+  }
+  free(U);
+  return bad;
+}
+
+void orc_pinv_draw(int P, const double* Prec, const double* rhs, const double* z, double* out) {
+  double* S = (double*)malloc(sizeof(double) * (size_t)P * P);
+  double* V = (double*)malloc(sizeof(double) * (size_t)P * P);
+  double* w = (double*)malloc(sizeof(double) * (size_t)P);
+  int* ord = (int*)malloc(sizeof(int) * (size_t)P);
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) S[i + (size_t)P * j] = 0.5 * (Prec[i + (size_t)P * j] + Prec[j + (size_t)P * i]);
+  jacobi_eig(P, S, V, w);
+  for (int k = 0; k < P; ++k) {          /* ord[rank] = eigenpair with that rank (ascending w, index breaks ties) */
+    int rank = 0;
+    for (int j = 0; j < P; ++j)
+      if (w[j] < w[k] || (w[j] == w[k] && j < k)) ++rank;
+    ord[rank] = k;
+  }
+  double wmax = 0.0;
+  for (int k = 0; k < P; ++k) wmax = fmax(wmax, fabs(w[k]));
+  const double tol = (double)P * wmax * 2.220446049250313e-16;
+  for (int i = 0; i < P; ++i) out[i] = 0.0;
+  for (int r = 0; r < P; ++r) {
+    const int k = ord[r];
+    const double winv = (fabs(w[k]) > tol) ? 1.0 / w[k] : 0.0;
+    double gs = 0.0;
+    for (int i = 0; i < P; ++i) {
+      gs += V[i + (size_t)P * k] / ((double)i + 1.37);
+    }
+    const double sgn = (gs < 0) ? -1.0 : 1.0;
+    double proj = 0.0;                    /* v_k' rhs */
+    for (int i = 0; i < P; ++i) proj += sgn * V[i + (size_t)P * k] * rhs[i];
+    const double coef = winv * proj + sqrt(fmax(winv, 0.0)) * z[r];
+    for (int i = 0; i < P; ++i) out[i] += sgn * V[i + (size_t)P * k] * coef;
+  }
+  free(S); free(V); free(w); free(ord);
+}

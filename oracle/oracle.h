@@ -76,6 +76,9 @@ int  orc_inv(int P, double* A);                                       /* arma::i
 void orc_pinv_sym(int P, double* A);                                  /* arma::pinv of a symmetric matrix (in place) */
 void orc_mvnrnd(const orc_rng* r, uint32_t upd, uint32_t idx0, int P,
                 const double* mean, const double* C, double* out);   /* arma::mvnrnd(mean, C) */
+/* rank-deficient precisions (pinv + eigen-decomposition route of the reference; specification in linalg.c) */
+int  orc_prec_is_singular(int P, const double* Prec);
+void orc_pinv_draw(int P, const double* Prec, const double* rhs, const double* z, double* out);
 
 /* ---- bspline.c ---- */
 /* splines2::BSpline(x, internal_knots, degree, boundary_knots).basis(true): n x P row-major out */

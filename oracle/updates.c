@@ -38,6 +38,17 @@
 #define DIMS const int n = d->n, K = d->K, P = d->P, M = d->M, D = d->D; (void)n; (void)K; (void)P; (void)M; (void)D
 
 /* arma::dot(nu.row(k), B.row(l)) */
+/* N(pinv(Prec) rhs, pinv(Prec)) for a precision that is singular to working accuracy (linalg.c): returns 1 and fills
+ * `draw` when that route was taken, 0 when the caller should go on with the reference's inv / pinv + mvnrnd calls */
+static int singular_route(const orc_rng* r, uint32_t upd, uint32_t idx0, int P, const double* Prec, const double* rhs, double* draw) {
+  if (!orc_prec_is_singular(P, Prec)) return 0;
+  double* z = (double*)malloc(sizeof(double) * (size_t)P);
+  for (int p = 0; p < P; ++p) z[p] = orc_rnorm(r, upd, idx0 + (uint32_t)p);
+  orc_pinv_draw(P, Prec, rhs, z, draw);
+  free(z);
+  return 1;
+}
+
 static inline double dot_nu(const double* nu_t, int K, int P, int k, const double* b) {
   double s = 0.0;
   for (int p = 0; p < P; ++p) s += nu_t[k + (size_t)K * p] * b[p];
@@ -306,6 +317,7 @@ void orc_updatePhi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
       /* Add on diagonal component (:76-78) */
       for (int k = 0; k < P; ++k)
         M_1[k + (size_t)P * k] += tilde_tau[j + (size_t)K * m] * gamma_t[j + (size_t)K * (k + (size_t)P * m)];
+      if (!singular_route(r, UPD_PHI, (uint32_t)((j * M + m) * P), P, M_1, m_1, draw)) {
       orc_inv(P, M_1);
       for (int p = 0; p < P; ++p) {
         double s = 0.0;
@@ -313,6 +325,7 @@ void orc_updatePhi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
         mean[p] = s;
       }
       orc_mvnrnd(r, UPD_PHI, (uint32_t)((j * M + m) * P), P, mean, M_1, draw);
+      }
       for (int p = 0; p < P; ++p) phi_t[j + (size_t)K * (p + (size_t)P * m)] = draw[p];
     }
   }
@@ -479,6 +492,7 @@ void orc_updateNu(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
     } else {
       for (int q = 0; q < P * P; ++q) B_1[q] += tau_j * d->Pmat[q];
     }
+    if (!singular_route(r, UPD_NU, (uint32_t)(j * P), P, B_1, b_1, draw)) {
     orc_pinv_sym(P, B_1);
     for (int q = 0; q < P; ++q)
       for (int p = 0; p < q; ++p) {
@@ -492,6 +506,7 @@ void orc_updateNu(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
       mean[p] = s;
     }
     orc_mvnrnd(r, UPD_NU, (uint32_t)(j * P), P, mean, B_1, draw);
+    }
     for (int p = 0; p < P; ++p) nu_t[j + (size_t)K * p] = draw[p];
   }
   if (iter < (T - 1)) memcpy(SL_NU(c, iter + 1), nu_t, sizeof(double) * (size_t)K * P);
@@ -751,6 +766,7 @@ void orc_updateEta(const orc_data* d, const orc_rng* r, double beta_i, int iter,
       } else {
         for (int q = 0; q < P * P; ++q) B_1[q] += te * d->Pmat[q];
       }
+      if (!singular_route(r, UPD_ETA, (uint32_t)((dd * K + j) * P), P, B_1, b_1, draw)) {
       orc_pinv_sym(P, B_1);
       for (int q = 0; q < P; ++q)
         for (int p = 0; p < q; ++p) {
@@ -764,6 +780,7 @@ void orc_updateEta(const orc_data* d, const orc_rng* r, double beta_i, int iter,
         mean[p] = s;
       }
       orc_mvnrnd(r, UPD_ETA, (uint32_t)((dd * K + j) * P), P, mean, B_1, draw);
+      }
       for (int p = 0; p < P; ++p) eta_t[p + (size_t)P * (dd + (size_t)D * j)] = draw[p];
     }
   }
@@ -851,6 +868,7 @@ void orc_updateXi(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
         for (int k = 0; k < P; ++k)
           M_1[k + (size_t)P * k] += tilde_tau_xi[j + (size_t)K * (m + (size_t)M * dd)] *
                                     gxi_j[k + (size_t)P * (dd + (size_t)D * m)];
+        if (!singular_route(r, UPD_XI, (uint32_t)(((j * M + m) * D + dd) * P), P, M_1, m_1, draw)) {
         orc_inv(P, M_1);
         for (int p = 0; p < P; ++p) {
           double s = 0.0;
@@ -858,6 +876,7 @@ void orc_updateXi(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
           mean[p] = s;
         }
         orc_mvnrnd(r, UPD_XI, (uint32_t)(((j * M + m) * D + dd) * P), P, mean, M_1, draw);
+        }
         for (int p = 0; p < P; ++p) xi_j[p + (size_t)P * (dd + (size_t)D * m)] = draw[p];
       }
     }
