@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbfmmm_hip.so")
+LIB_PATH = os.environ.get("BFMMM_LIB_PATH", os.path.join(_HERE, "libbfmmm_hip.so"))      # (override: diagnostic builds, tools/timeline.py)
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)

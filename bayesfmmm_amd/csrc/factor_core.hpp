@@ -20,7 +20,7 @@ namespace bfmmm {
 
 #ifdef BFMMM_TIMELINE
 static __device__ unsigned long long g_fct[8];
-#define FCT(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_fct[i] = wall_clock64(); } while (0)
+#define FCT(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_fct[i] = wall_clock64(); } while (0)      // (single-chain runs: workgroup 1 = direction 1)
 #else
 #define FCT(i) do { } while (0)
 #endif
@@ -35,8 +35,9 @@ __device__ inline double readlane_f64(double v, int lane) {     // lane is wave-
 }
 
 // wave 0: reverse Cholesky, X = U^-1 (written to LDS), L z
+// (always inlined: out of line the LDS pointers degrade to flat addresses and the recursions run 60 % slower)
 template <int PP, int BWT>
-__device__ inline bool factor_wave(double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
+__device__ __forceinline__ bool factor_wave(double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
   double s[BWT + 1], u[BWT + 1];       // s[t] = Prec(i, i + t),  u[t] = U(i, i + t)
 #pragma unroll
   for (int t = 0; t <= BWT; ++t) {
@@ -118,7 +119,7 @@ __device__ inline bool factor_wave(double* S, double* X, const double* zv, int P
 
 // Cl (optional): an LDS copy of C, Cl[q + PP * p] = C(p, q) -- may alias S, whose band has been consumed by then
 template <int PP>
-__device__ inline bool factor_core(double* S, double* X, const double* zv, int P, int bw, double* Cg, double* Lg,
+__device__ __forceinline__ bool factor_core(double* S, double* X, const double* zv, int P, int bw, double* Cg, double* Lg,
                                    double* Lz_out, int tid, double* Cl = nullptr) {
   bool bad = false;
   if (bw == 0) {
@@ -196,9 +197,12 @@ __device__ inline bool factor_core(double* S, double* X, const double* zv, int P
       default: bad = factor_wave<PP, 5>(S, X, zv, P, Lz_out, tid); break;
     }
   }
-  if (bw <= 5) {                                     // (wave 0 ran the factorisation: its verdict goes to every thread)
-    bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    if (bad) return true;
+  if (bw <= 5) {
+    // wave 0 ran the factorisation: its verdict reaches every thread through the last element of S (the band of Prec
+    // was consumed at the start of factor_wave and its parking area ends far below)
+    if (tid == 0) S[PP * PP - 1] = bad ? 1.0 : 0.0;
+    __syncthreads();
+    if (S[PP * PP - 1] != 0.0) return true;
   }
   FCT(2);
   // C = X' X on the matrix cores: tile (pt, qt) of 16 x 16, K = P rounded up to 4 (rows k > min(p, q) of X are zero)

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
   if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
     job_hyper(c);
-    TSTAMP(c, 58);
+    TSTAMP(c, 15);
     return;
   }
   // bit 4 of mode: after its chi update / residual pass a curve group also runs the Z update of the NEXT iteration

@@ -62,9 +62,13 @@ void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP
 
 constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
                                   // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
-__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int do_pg) {
-  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
-  TIMELINE(c, 1);
+template <bool BATCH>
+__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nks, int do_pg) {
+  // Chain batches (BATCH): the workgroup stages its record columns ONCE and walks the chains of the batch (the records
+  // are shared; Z / chi, the pair weights and the output tiles are per chain), so the grid has no chain dimension.
+  // The single-chain instantiation is the same code without the loop (and without the registers it keeps alive).
+  const int nch = BATCH ? c0.nch : 1;
+  TIMELINE(c0, 1);
 #ifdef BFMMM_TIMELINE
   const int wgid = blockIdx.x + gridDim.x * blockIdx.y;
   if (threadIdx.x == 0 && wgid < 1024) {
@@ -77,13 +81,18 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int do
   struct EndTrace { int w; __device__ ~EndTrace() { if (threadIdx.x == 0 && w < 1024) g_wgtrace[3 * w + 2] = wall_clock64(); } } et_{wgid};
 #endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const Dims& d = c.d;
+  const Dims& d = c0.d;
   const int n = d.n, K = d.K, MD = d.MD;
   const int ks = blockIdx.y, ct = blockIdx.x;
-  if (ct == d.CTG + 1) {            // one extra workgroup: pi / alpha_3, hidden under the contraction
-    if (ks == 0 && threadIdx.x < 256) { job_pi_alpha(c); TSTAMP(c, 46); }      // the scalar jobs are written for 256 threads
+  if (ct == d.CTG + 1) {            // extra workgroups: pi / alpha_3 of chain ks, hidden under the contraction
+    if (ks < nch && threadIdx.x < 256) {      // the scalar jobs are written for 256 threads (waves 4-7 leave)
+      const Ctx c = chain_ctx(c0, (unsigned)ks);
+      job_pi_alpha(c);
+      TSTAMP(c, 46);
+    }
     return;
   }
+  if (ks >= nks) return;            // (the grid's y extent is max(k-slices, chains))
   if (!do_pg) return;
   const bool single = ct == d.CTG;
   const int ncol = single ? d.CTS * 16 : 16;
@@ -100,198 +109,213 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int do
   double* sB = sW + (size_t)RS * KSP;        // ncol x KSP  record columns
   double* sP = sB + (size_t)ncol * KSP;      // RP x KSP  pair weights (G workgroups only)
   const int tid = threadIdx.x;
+  constexpr int UW = 12, UB = 6;
+  const int ncw = K + MD - 1;                // source columns: Z_1..Z_K, chi_1..chi_M
+  const int nB = KS * ncol;
   // staging: a thread issues all its global loads (one curve's Z / chi entries, UB record entries)
   // before its first LDS store, so the workgroup pays about one memory round trip
-  {
-    constexpr int UW = 12, UB = 6;
-    const int ncw = K + MD - 1;              // source columns: Z_1..Z_K, chi_1..chi_M
-    const int nB = KS * ncol;
-    auto loadW = [&](int il0, int cb, double (&v)[UW]) {
-      const int i = min(i0 + il0 + tid, n - 1);
+  auto loadW = [&](const double* Zq, const double* chiq, int il0, int cb, double (&v)[UW]) {
+    const int i = min(i0 + il0 + tid, n - 1);
 #pragma unroll
-      for (int u = 0; u < UW; ++u) {
-        const int col = min(cb + u, ncw - 1);
-        v[u] = (col < K) ? c.Z[i + (size_t)n * col] : c.chi[i + (size_t)n * (col - K)];
-      }
-    };
-    auto storeW = [&](int il0, int cb, const double (&v)[UW]) {
-      const int il = il0 + tid;
-      if (il >= KS) return;
-      const bool live = i0 + il < n;
+    for (int u = 0; u < UW; ++u) {
+      const int col = min(cb + u, ncw - 1);
+      v[u] = (col < K) ? Zq[i + (size_t)n * col] : chiq[i + (size_t)n * (col - K)];
+    }
+  };
+  auto storeW = [&](int il0, int cb, const double (&v)[UW]) {
+    const int il = il0 + tid;
+    if (il >= KS) return;
+    const bool live = i0 + il < n;
 #pragma unroll
-      for (int u = 0; u < UW; ++u) {
-        const int col = cb + u;
-        if (col < ncw) sW[((col < K) ? col : col + 1) * KSP + il] = live ? v[u] : 0.0;
-      }
-      if (cb == 0) { sW[ONE * KSP + il] = 1.0; sW[(K + MD) * KSP + il] = 0.0; }
-    };
-    auto loadB = [&](int base, double (&v)[UB]) {        // s-part workgroups (ncol = CTS * 16)
+    for (int u = 0; u < UW; ++u) {
+      const int col = cb + u;
+      if (col < ncw) sW[((col < K) ? col : col + 1) * KSP + il] = live ? v[u] : 0.0;
+    }
+    if (cb == 0) { sW[ONE * KSP + il] = 1.0; sW[(K + MD) * KSP + il] = 0.0; }
+  };
+  auto loadB = [&](const double* stilq, int base, double (&v)[UB]) {        // s-part workgroups (ncol = CTS * 16)
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int q = min(base + tid + PG_THREADS * u, nB - 1);
+    for (int u = 0; u < UB; ++u) {
+      const int q = min(base + tid + PG_THREADS * u, nB - 1);
+      const int il = q / ncol, cc = q - il * ncol;
+      const int i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
+      // covariate-adjusted models contract against s~_i = s_i - G_i o_i (k_curve_z, per chain) instead of s_i
+      v[u] = (d.D > 0) ? stilq[(size_t)i * d.P + min(cc, d.P - 1)] : c0.rec[(size_t)i * d.LREC + col];
+    }
+  };
+  auto storeB = [&](int base, const double (&v)[UB]) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = base + tid + PG_THREADS * u;
+      if (q < nB) {
         const int il = q / ncol, cc = q - il * ncol;
-        const int i = min(i0 + il, n - 1), col = min(col0 + cc, d.LREC - 1);
-        // covariate-adjusted models contract against s~_i = s_i - G_i o_i (k_curve_z) instead of s_i
-        v[u] = (d.D > 0) ? c.stil[(size_t)i * d.P + min(cc, d.P - 1)] : c.rec[(size_t)i * d.LREC + col];
+        sB[cc * KSP + il] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
       }
-    };
-    auto storeB = [&](int base, const double (&v)[UB]) {
+    }
+  };
+  // G workgroups (16 record columns): element (il, cc) = (tid / 16 + 32 u, tid % 16), so a load costs one
+  // multiply-add and a store a constant LDS offset
+  const int ccg = tid & 15, ilg = tid >> 4;
+  const double* srcg = c0.rec + min(col0 + ccg, d.LREC - 1);
+  const bool colok = col0 + ccg < colend;
+  auto loadG = [&](int ub0, double (&v)[UB]) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int q = base + tid + PG_THREADS * u;
-        if (q < nB) {
-          const int il = q / ncol, cc = q - il * ncol;
-          sB[cc * KSP + il] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
-        }
-      }
-    };
-    // G workgroups (16 record columns): element (il, cc) = (tid / 16 + 32 u, tid % 16), so a load costs one
-    // multiply-add and a store a constant LDS offset
-    const int ccg = tid & 15, ilg = tid >> 4;
-    const double* srcg = c.rec + min(col0 + ccg, d.LREC - 1);
-    const bool colok = col0 + ccg < colend;
-    auto loadG = [&](int ub0, double (&v)[UB]) {
+    for (int u = 0; u < UB; ++u) v[u] = srcg[(size_t)min(i0 + ilg + (PG_THREADS / 16) * (ub0 + u), n - 1) * d.LREC];
+  };
+  auto storeG = [&](int ub0, const double (&v)[UB]) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) v[u] = srcg[(size_t)min(i0 + ilg + (PG_THREADS / 16) * (ub0 + u), n - 1) * d.LREC];
-    };
-    auto storeG = [&](int ub0, const double (&v)[UB]) {
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int il = ilg + (PG_THREADS / 16) * (ub0 + u);
-        if (il < KS) sB[ccg * KSP + il] = (i0 + il < n && colok) ? v[u] : 0.0;
-      }
-    };
-    TSTAMP0(c, 40);
-    double vw[UW], vb[UB];
-    loadW(0, 0, vw);
-    if (single) loadB(0, vb); else loadG(0, vb);
-    TSTAMP0(c, 47);
-    storeW(0, 0, vw);
-    TSTAMP0(c, 48);
-    if (single) storeB(0, vb); else storeG(0, vb);
-    for (int il0 = 0; il0 < KS; il0 += PG_THREADS)
-      for (int cb = 0; cb < ncw; cb += UW) {
-        if (il0 == 0 && cb == 0) continue;
-        loadW(il0, cb, vw);
-        storeW(il0, cb, vw);
-      }
-    if (single) { for (int base = PG_THREADS * UB; base < nB; base += PG_THREADS * UB) { loadB(base, vb); storeB(base, vb); } }
-    else { for (int ub0 = UB; (PG_THREADS / 16) * ub0 < KS; ub0 += UB) { loadG(ub0, vb); storeG(ub0, vb); } }
-    TSTAMP0(c, 41);
+    for (int u = 0; u < UB; ++u) {
+      const int il = ilg + (PG_THREADS / 16) * (ub0 + u);
+      if (il < KS) sB[ccg * KSP + il] = (i0 + il < n && colok) ? v[u] : 0.0;
+    }
+  };
+  // pair slot -> (a, b) table (packed upper triangles of Z x Z and chit x chit), decoded once
+  int* ptab = (int*)(sP + (size_t)RP * KSP);
+  if (!single && tid < NP) {
+    int e = tid, off = 0, dim = K;
+    if (e >= d.NZZ) { e -= d.NZZ; off = K; dim = MD; }
+    int a = 0;
+    while (e >= dim - a) { e -= dim - a; ++a; }
+    ptab[tid] = (off + a) | ((off + a + e) << 16);
   }
-  __syncthreads();
-  TSTAMP0(c, 42);
-  if (!single) {
-    // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 16, .. of curves tx, tx + 32, ..; the
-    // slot -> (a, b) table is decoded once (packed upper triangles of Z x Z and chit x chit)
-    int* ptab = (int*)(sP + (size_t)RP * KSP);
-    if (tid < NP) {
-      int e = tid, off = 0, dim = K;
-      if (e >= d.NZZ) { e -= d.NZZ; off = K; dim = MD; }
-      int a = 0;
-      while (e >= dim - a) { e -= dim - a; ++a; }
-      ptab[tid] = (off + a) | ((off + a + e) << 16);
+  const bool shared_cols = !(single && d.D > 0);     // the staged columns are the same for every chain
+  for (int q = 0; q < nch; ++q) {
+    // the per-chain operands (only these: a whole per-chain Ctx costs a few hundred scalar registers)
+    const size_t off1 = (size_t)q * c0.chain_bytes;
+    const double* Zq = ptr_shift(c0.Z, off1);
+    const double* chiq = ptr_shift(c0.chi, off1);
+    const double* stilq = ptr_shift(c0.stil, (size_t)q * c0.chain_bytes_cov);
+    double* pgq = ptr_shift(c0.pg_part, off1);
+#ifdef BFMMM_TIMELINE
+    struct { Dyn* dyn; } c = {ptr_shift(c0.dyn, off1)};
+#endif
+    {
+      TSTAMP0(c, 40);
+      double vw[UW], vb[UB];
+      const bool stage_cols = (q == 0) || !shared_cols;
+      loadW(Zq, chiq, 0, 0, vw);
+      if (stage_cols) { if (single) loadB(stilq, 0, vb); else loadG(0, vb); }
+      TSTAMP0(c, 47);
+      storeW(0, 0, vw);
+      TSTAMP0(c, 48);
+      if (stage_cols) { if (single) storeB(0, vb); else storeG(0, vb); }
+      for (int il0 = 0; il0 < KS; il0 += PG_THREADS)
+        for (int cb = 0; cb < ncw; cb += UW) {
+          if (il0 == 0 && cb == 0) continue;
+          loadW(Zq, chiq, il0, cb, vw);
+          storeW(il0, cb, vw);
+        }
+      if (stage_cols) {
+        if (single) { for (int base = PG_THREADS * UB; base < nB; base += PG_THREADS * UB) { loadB(stilq, base, vb); storeB(base, vb); } }
+        else { for (int ub0 = UB; (PG_THREADS / 16) * ub0 < KS; ub0 += UB) { loadG(ub0, vb); storeG(ub0, vb); } }
+      }
+      TSTAMP0(c, 41);
     }
     __syncthreads();
-    const int tx = tid & 31, ty = tid >> 5;
-    for (int il0 = 0; il0 < KS; il0 += 256) {
-      for (int e = ty; e < NP; e += PG_THREADS / 32) {
-        const int pk = ptab[e], ia = pk & 0xffff, ib = pk >> 16;
+    TSTAMP0(c, 42);
+    if (!single) {
+      // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 16, .. of curves tx, tx + 32, ..
+      const int tx = tid & 31, ty = tid >> 5;
+      for (int il0 = 0; il0 < KS; il0 += 256) {
+        for (int e = ty; e < NP; e += PG_THREADS / 32) {
+          const int pk = ptab[e], ia = pk & 0xffff, ib = pk >> 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int il = il0 + tx + 32 * j;
-          if (il < KS) sP[e * KSP + il] = sW[ia * KSP + il] * sW[ib * KSP + il];
-        }
-      }
-      if (ty == 0)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[NP * KSP + il] = 0.0; }
-    }
-    __syncthreads();
-  }
-  TSTAMP0(c, 43);
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lr = lane & 15, kq = lane >> 4;
-  const int ntile = single ? d.AT * d.CTS : d.RT;
-  const double* wsrc = single ? sW : sP;
-  const int ZERO = single ? RS - 1 : RP - 1;
-  const int KQ = KS / 4;                     // steps; k-slot kq of step s is curve kq * KQ + s  (KS is a multiple of 16)
-  // each wave walks its tiles TPW at a time with independent accumulators
-  constexpr int TPW = 2;
-  constexpr int NW = PG_THREADS / 64;
-  for (int t0 = wave; t0 < ntile; t0 += NW * TPW) {
-    int tix[TPW], bcol[TPW], o1[TPW], o2[TPW];
-    bool tv[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int tt = t0 + NW * q;
-      tv[q] = tt < ntile;
-      o1[q] = o2[q] = ZERO; bcol[q] = lr; tix[q] = 0;
-      if (tv[q]) {
-        if (!single) {
-          const int row = tt * 16 + lr;
-          tix[q] = tt * d.CTG + ct;
-          if (row < d.R) { const int zz = row / d.NCC; o1[q] = zz; o2[q] = d.NZZ + (row - zz * d.NCC); }
-        } else {
-          const int at = tt / d.CTS, cs = tt - at * d.CTS;
-          const int row = at * 16 + lr;
-          tix[q] = d.RT * d.CTG + tt;
-          bcol[q] = cs * 16 + lr;
-          if (row < d.A) { const int j = row / MD; o1[q] = j; o2[q] = K + (row - j * MD); }
-        }
-      }
-    }
-    double4_t acc[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-    const v2d* pa[TPW]; const v2d* pb[TPW]; const v2d* pc[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      pa[q] = (const v2d*)(wsrc + o1[q] * KSP + kq * KQ);
-      pb[q] = (const v2d*)(wsrc + o2[q] * KSP + kq * KQ);
-      pc[q] = (const v2d*)(sB + bcol[q] * KSP + kq * KQ);
-    }
-    // The LDS pipe moves 1.5 KB per MFMA and wave -- three quarters of the time the matrix pipe needs for it -- so the
-    // two must overlap: a trip is two pairs of k-steps (12 TPW MFMAs); the operands of trip t + 1 are read into the
-    // other register set before the MFMAs of trip t are issued (the scheduling barriers keep the compiler from
-    // moving the reads back next to their uses).
-    struct OpSet { v2d wa[2][TPW], wb[2][TPW], bb[2][TPW]; };
-    auto load_trip = [&](OpSet& o, int s2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) { o.wa[u][q] = pa[q][s2 + u]; o.wb[u][q] = pb[q][s2 + u]; o.bb[u][q] = pc[q][s2 + u]; }
-    };
-    auto mfma_trip = [&](const OpSet& o, int npair) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (u < npair)
-#pragma unroll
-          for (int q = 0; q < TPW; ++q) {
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][q].x * o.wb[u][q].x, o.bb[u][q].x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][q].y * o.wb[u][q].y, o.bb[u][q].y, acc[q], 0, 0, 0);
+          for (int j = 0; j < 8; ++j) {
+            const int il = il0 + tx + 32 * j;
+            if (il < KS) sP[e * KSP + il] = sW[ia * KSP + il] * sW[ib * KSP + il];
           }
-    };
-    const int ntrip = KQ / 4;                // KS is a multiple of 16: trip t covers the step pairs 2t, 2t + 1
-    OpSet s0, s1;
-    load_trip(s0, 0);
-    for (int t = 0; t < ntrip; t += 2) {
-      if (t + 1 < ntrip) load_trip(s1, 2 * (t + 1));
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_trip(s0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < ntrip) load_trip(s0, 2 * (t + 2));
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < ntrip) mfma_trip(s1, 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        }
+        if (ty == 0)
 #pragma unroll
-    for (int q = 0; q < TPW; ++q)
-      if (tv[q]) {
-        double* out = c.pg_part + ((size_t)ks * d.NT + tix[q]) * 256 + lane;
-        out[0] = acc[q][0]; out[64] = acc[q][1]; out[128] = acc[q][2]; out[192] = acc[q][3];
+          for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[NP * KSP + il] = 0.0; }
       }
-    TSTAMP0(c, 44);
+      __syncthreads();
+    }
+    TSTAMP0(c, 43);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int ntile = single ? d.AT * d.CTS : d.RT;
+    const double* wsrc = single ? sW : sP;
+    const int ZERO = single ? RS - 1 : RP - 1;
+    const int KQ = KS / 4;                     // steps; k-slot kq of step s is curve kq * KQ + s  (KS is a multiple of 16)
+    // each wave walks its tiles TPW at a time with independent accumulators
+    constexpr int TPW = 2;
+    constexpr int NW = PG_THREADS / 64;
+    for (int t0 = wave; t0 < ntile; t0 += NW * TPW) {
+      int tix[TPW], bcol[TPW], o1[TPW], o2[TPW];
+      bool tv[TPW];
+#pragma unroll
+      for (int qq = 0; qq < TPW; ++qq) {
+        const int tt = t0 + NW * qq;
+        tv[qq] = tt < ntile;
+        o1[qq] = o2[qq] = ZERO; bcol[qq] = lr; tix[qq] = 0;
+        if (tv[qq]) {
+          if (!single) {
+            const int row = tt * 16 + lr;
+            tix[qq] = tt * d.CTG + ct;
+            if (row < d.R) { const int zz = row / d.NCC; o1[qq] = zz; o2[qq] = d.NZZ + (row - zz * d.NCC); }
+          } else {
+            const int at = tt / d.CTS, cs = tt - at * d.CTS;
+            const int row = at * 16 + lr;
+            tix[qq] = d.RT * d.CTG + tt;
+            bcol[qq] = cs * 16 + lr;
+            if (row < d.A) { const int j = row / MD; o1[qq] = j; o2[qq] = K + (row - j * MD); }
+          }
+        }
+      }
+      double4_t acc[TPW];
+#pragma unroll
+      for (int qq = 0; qq < TPW; ++qq) acc[qq] = double4_t{0.0, 0.0, 0.0, 0.0};
+      const v2d* pa[TPW]; const v2d* pb[TPW]; const v2d* pc[TPW];
+#pragma unroll
+      for (int qq = 0; qq < TPW; ++qq) {
+        pa[qq] = (const v2d*)(wsrc + o1[qq] * KSP + kq * KQ);
+        pb[qq] = (const v2d*)(wsrc + o2[qq] * KSP + kq * KQ);
+        pc[qq] = (const v2d*)(sB + bcol[qq] * KSP + kq * KQ);
+      }
+      // The LDS pipe moves 1.5 KB per MFMA and wave -- three quarters of the time the matrix pipe needs for it -- so the
+      // two must overlap: a trip is two pairs of k-steps (12 TPW MFMAs); the operands of trip t + 1 are read into the
+      // other register set before the MFMAs of trip t are issued (the scheduling barriers keep the compiler from
+      // moving the reads back next to their uses).
+      struct OpSet { v2d wa[2][TPW], wb[2][TPW], bb[2][TPW]; };
+      auto load_trip = [&](OpSet& o, int s2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int qq = 0; qq < TPW; ++qq) { o.wa[u][qq] = pa[qq][s2 + u]; o.wb[u][qq] = pb[qq][s2 + u]; o.bb[u][qq] = pc[qq][s2 + u]; }
+      };
+      auto mfma_trip = [&](const OpSet& o, int npair) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (u < npair)
+#pragma unroll
+            for (int qq = 0; qq < TPW; ++qq) {
+              acc[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][qq].x * o.wb[u][qq].x, o.bb[u][qq].x, acc[qq], 0, 0, 0);
+              acc[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.wa[u][qq].y * o.wb[u][qq].y, o.bb[u][qq].y, acc[qq], 0, 0, 0);
+            }
+      };
+      const int ntrip = KQ / 4;                // KS is a multiple of 16: trip t covers the step pairs 2t, 2t + 1
+      OpSet s0, s1;
+      load_trip(s0, 0);
+      for (int t = 0; t < ntrip; t += 2) {
+        if (t + 1 < ntrip) load_trip(s1, 2 * (t + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_trip(s0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntrip) load_trip(s0, 2 * (t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntrip) mfma_trip(s1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int qq = 0; qq < TPW; ++qq)
+        if (tv[qq]) {
+          double* out = pgq + ((size_t)ks * d.NT + tix[qq]) * 256 + lane;
+          out[0] = acc[qq][0]; out[64] = acc[qq][1]; out[128] = acc[qq][2]; out[192] = acc[qq][3];
+        }
+      TSTAMP0(c, 44);
+    }
+    if (q + 1 < nch) __syncthreads();        // the next chain overwrites sW / sP
   }
 }
 
@@ -381,26 +405,39 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi);
 // ---------------------------------------------------------------------------------------------
 template <int PP, int BW>
 __global__ __launch_bounds__(256) void k_factor(Ctx c0) {
-  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
+  // one-dimensional grid of chains x jobs with the chain index running FASTEST, so that the long factorisation workgroups
+  // of every chain of a batch are dispatched before any of the short spare jobs (workgroups start in index order)
+  const int nch_ = c0.nch;
+  const Ctx c = chain_ctx(c0, blockIdx.x % nch_);
+  const int bx = blockIdx.x / nch_, nbx = gridDim.x / nch_;      // job index / number of jobs
   TIMELINE(c, 3);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
   constexpr int W = 2 * BW + 2;     // doubles per row of an H2 block: G(p, p - BW .. p + BW), 0
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
+  if (bx >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
     const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int nzp = ((c.mask & U_Z) && d.D == 0) ? (d.n + 15) / 16 : 0;
-    if ((int)blockIdx.x < A + ndraw) job_hyper_draws(c, ((int)blockIdx.x - A) * 256);
-    else if ((int)blockIdx.x < A + ndraw + nzp) job_z_prepare(c, (int)blockIdx.x - A - ndraw);
-    else if ((int)blockIdx.x == gridDim.x - 1 && (c.mask & (U_PI | U_ALPHA3))) job_pi_prepare(c);
-    else job_chi_normals(c, (int)blockIdx.x - A - ndraw - nzp);
+#ifdef BFMMM_TIMELINE
+    const int sb_ = bx - A;       // one workgroup of each kind of spare job: start / end stamps 56 .. 63
+    const int kind_ = sb_ < ndraw ? 0 : sb_ < ndraw + nzp ? 1 : (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) ? 2 : 3;
+    const bool first_ = (sb_ == 0) || (sb_ == ndraw && nzp > 0) || kind_ == 2 || (kind_ == 3 && sb_ == ndraw + nzp);
+    if (first_ && threadIdx.x == 0) c.dyn->stamps[56 + 2 * kind_] = wall_clock64();
+#endif
+    if (bx < A + ndraw) job_hyper_draws(c, (bx - A) * 256);
+    else if (bx < A + ndraw + nzp) job_z_prepare(c, bx - A - ndraw);
+    else if (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) job_pi_prepare(c);
+    else job_chi_normals(c, bx - A - ndraw - nzp);
+#ifdef BFMMM_TIMELINE
+    if (first_ && threadIdx.x == 0) c.dyn->stamps[57 + 2 * kind_] = wall_clock64();
+#endif
     return;
   }
-  const int a = blockIdx.x;
+  const int a = bx;
   const int j = a / MD, mt = a - j * MD;
 #ifdef BFMMM_TIMELINE
-#define FST(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) c.dyn->stamps[48 + (i)] = wall_clock64(); } while (0)
+#define FST(i) do { if (bx == 1 && threadIdx.x == 0) c.dyn->stamps[48 + (i)] = wall_clock64(); } while (0)
 #else
 #define FST(i) do { } while (0)
 #endif
@@ -1293,7 +1330,8 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
   const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
   const size_t lds = std::max((size_t)(KS + 2) * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
-  hipLaunchKernelGGL(k_pair_gram, dim3(c.d.CTG + 2, do_pg ? NKS : 1, c.nch), dim3(PG_THREADS), lds, st, c, KS, do_pg);
+  if (c.nch > 1) hipLaunchKernelGGL(k_pair_gram<true>, dim3(c.d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
+  else hipLaunchKernelGGL(k_pair_gram<false>, dim3(c.d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256;
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
@@ -1302,13 +1340,13 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
 template <int PP>
 static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st) {
   switch (c.d.BW) {
-    case 0: hipLaunchKernelGGL((k_factor<PP, 0>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    case 1: hipLaunchKernelGGL((k_factor<PP, 1>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
-    default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(grid, 1, c.nch), dim3(256), lds, st, c); break;
+    case 0: hipLaunchKernelGGL((k_factor<PP, 0>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case 1: hipLaunchKernelGGL((k_factor<PP, 1>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case 2: hipLaunchKernelGGL((k_factor<PP, 2>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
   }
 }
 
@@ -1367,7 +1405,7 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
-  set_max_lds((const void*)k_pair_gram);
+  set_max_lds((const void*)k_pair_gram<false>); set_max_lds((const void*)k_pair_gram<true>);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);
   set_max_lds((const void*)k_factor<32, 2>); set_max_lds((const void*)k_factor<64, 2>);

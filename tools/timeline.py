@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Device-side timeline of one Gibbs iteration (diagnostic build with -DBFMMM_TIMELINE; 100 MHz wall clock stamps in Dyn).
+
+  python tools/timeline.py build                 # on the CPU box: builds tools/tl/libbfmmm_hip.so (travels with gpurun)
+  BFMMM_LIB_PATH=tools/tl/libbfmmm_hip.so python tools/timeline.py run [--workload warm|nu_z] [--chains C]
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build():
+    src = os.path.join(ROOT, "bayesfmmm_amd", "csrc")
+    dst = os.path.join(ROOT, "tools", "tl", "csrc")
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    # the copies include ../../include: keep the relative layout
+    inc = os.path.join(ROOT, "tools", "include")
+    if not os.path.exists(inc):
+        os.symlink(os.path.join(ROOT, "include"), inc)
+    subprocess.check_call(["make", "-s", "-j8", "-C", dst, "EXTRA=-DBFMMM_TIMELINE"])
+    print("built", os.path.join(ROOT, "tools", "tl", "libbfmmm_hip.so"))
+
+
+def run(a):
+    import bayesfmmm_amd as bf
+    from bench import make_config2
+    S = bf.sampler
+    w = make_config2()
+    T = 40
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=3, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], n_chains=a.chains)
+    pcz = a.workload == "nu_z"
+    mask = S.SWEEP_NU_Z if pcz else S.SWEEP_WARM
+    for q in range(a.chains):
+        smp.select_chain(q)
+        if pcz:
+            smp.init_state(0, 1, chain=q)
+        else:
+            smp.set_state(**w["state"])
+    smp.run(mask, T, seed=2, phi_chi_zero=pcz)
+    names = ["curve_z", "pair_gram", "pg_reduce", "factor", "sweep", "curve_chi"]
+    for q in sorted({0, a.chains - 1}):
+        smp.select_chain(q)
+        st = smp.get_state("stamps")
+        t0 = min(st[2 * k] for k in range(6) if st[2 * k] > 0)
+        print(f"chain {q}: last iteration, microseconds from the first kernel start  [start, latest workgroup start, end]")
+        order = sorted(range(6), key=lambda k: st[2 * k])
+        for k in order:
+            if st[2 * k] == 0:
+                continue
+            print(f"  {names[k]:10s} {(st[2*k]-t0)/100:8.2f} {(st[16+k]-t0)/100:8.2f} {(st[2*k+1]-t0)/100:8.2f}   span {(st[2*k+1]-st[2*k])/100:7.2f}")
+        f = st[48:55]
+        print("  factor workgroup 1 phases (us):", " ".join(f"{(f[i+1]-f[i])/100:.2f}" for i in range(6)), " total", (f[6] - f[0]) / 100)
+        try:
+            fc = smp.get_state("fct")
+            print("  factor_core of workgroup 1 (us): cholesky", (fc[0] - f[5]) / 100, " inverse", (fc[1] - fc[0]) / 100, " barrier", (fc[2] - fc[1]) / 100,
+                  " C = X'X (MFMA)", (fc[3] - fc[2]) / 100, " L store", (f[6] - fc[3]) / 100)
+        except Exception as e:
+            print("  (no fct stamps:", e, ")")
+        for kind, nm in enumerate(["hyper_draws", "z_prepare", "pi_prepare", "chi_normals"]):
+            s0, s1 = st[56 + 2 * kind], st[57 + 2 * kind]
+            if s0 > 0:
+                print(f"  spare job {nm:12s}: first workgroup {(s1 - s0) / 100:.2f} us (starts {(s0 - st[6]) / 100:.2f} us into k_factor)")
+        pg = st[40:49]
+        print("  pair_gram wg0 stamps rel:", [round((x - st[2]) / 100, 2) for x in pg if x > 0])
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cmd")
+    ap.add_argument("--workload", default="warm")
+    ap.add_argument("--chains", type=int, default=1)
+    a = ap.parse_args()
+    build() if a.cmd == "build" else run(a)
