@@ -1,7 +1,8 @@
 """Credible intervals over saved draws on the device (include/bfmmm_post.h): SigmaCI, ZCI, FMeanCI
 (src/PostProcessing.cpp:3435, :3505, :99) against the numpy restatement oracle/post_ci.py -- on the trace the package ships
 (inst/test-data/Functional_trace: the documented examples' directory) and on batches written by this library's own
-warm-start run of the package's K = 2 example (the rescale option reads the Z draws, which the shipped trace lacks)."""
+warm-start run of the package's K = 2 example.  (The rescaled paths on the shipped trace's own Z0.txt / Chi0.txt:
+tests/test_gpu_reference_functional_trace.py.)"""
 import os
 import sys
 
@@ -118,7 +119,7 @@ def test_fmeanci_rescaled(k2_batches, mode, with_x):
 @pytest.mark.parametrize("simultaneous", [False, True])
 def test_fcovci_on_the_reference_trace(simultaneous):
     """FCovCI's documented example (R/RcppExports.R: time1 = time2 = seq(0, 990, 10), l = m = 1 on Functional_trace), rescale
-    off (no Z files in the shipped trace)."""
+    off here; the default rescale = TRUE on the shipped Z0.txt is in tests/test_gpu_reference_functional_trace.py."""
     from bayesfmmm_amd import api
     f = api.ReadFieldCube(TRACE + "Phi0.txt")
     Phi = np.stack([f[l, 0] for l in range(f.shape[0])], axis=-1)
