@@ -105,6 +105,8 @@ POST_SYMBOLS = {
     "bfmmm_post_cov_bands": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_int32, C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int32,
                                        C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
     "bfmmm_FCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_HDFCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
+    "bfmmm_MVCovCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_MVMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_HDFMeanCI": (C.c_int, [C.POINTER(CiArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_ci_defaults": (None, [C.POINTER(CiArgs)]),
@@ -792,9 +794,17 @@ def FMeanCI(dir, n_files, time, basis_degree, boundary_knots, internal_knots, k,
     return d
 
 
+def _cov_x(a, keep, X):
+    if X is not None:
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        keep.append(Xf)
+        a.X, a.n_x, a.D = Xf.ctypes.data_as(c_double_p), Xf.shape[0], Xf.shape[1]
+
+
 def FCovCI(dir, n_files, time1, time2, basis_degree, boundary_knots, internal_knots, l, m, alpha=0.05, rescale=True,
-           simultaneous=False, burnin_prop=0.1, trans_mats=None):
-    """src/PostProcessing.cpp:1781 (without covariates)."""
+           simultaneous=False, burnin_prop=0.1, X=None, trans_mats=None):
+    """src/PostProcessing.cpp:1781.  With X (n_x covariate settings: the covariate-dependent covariance) the bands are
+    (n_time1, n_time2, n_x) and cov_trace (n_time1, n_time2, kept, n_x) -- the reference's list of n_x cubes."""
     a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
     t1 = np.ascontiguousarray(time1, dtype=np.float64).reshape(-1)
     t2 = np.ascontiguousarray(time2, dtype=np.float64).reshape(-1)
@@ -805,11 +815,41 @@ def FCovCI(dir, n_files, time1, time2, basis_degree, boundary_knots, internal_kn
     a.basis_degree, a.n_internal_knots = basis_degree, len(ik)
     a.boundary_knots, a.internal_knots = bk.ctypes.data_as(c_double_p), ik.ctypes.data_as(c_double_p)
     a.l, a.m, a.rescale, a.simultaneous = l, m, int(bool(rescale)), int(bool(simultaneous))
+    _cov_x(a, keep, X)
     if trans_mats is not None:
         tm = np.asfortranarray(trans_mats, dtype=np.float64)
         keep.append(tm)
         a.trans_mats = tm.ctypes.data_as(c_double_p)
     return _ci_call(_lib_entry().bfmmm_FCovCI, a, keep)
+
+
+def HDFCovCI(dir, n_files, time1, time2, basis_degree, boundary_knots, internal_knots, l, m, alpha=0.05, rescale=True,
+             simultaneous=False, burnin_prop=0.1, X=None):
+    """src/PostProcessing.cpp:2468: `time1`, `time2` n x dim matrices, `basis_degree` a vector, `boundary_knots` dim x 2,
+    `internal_knots` a list.  (The reference evaluates both bases at time1: the surface is time1 x time1.)"""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    dim = len(basis_degree)
+    t1 = np.asfortranarray(np.asarray(time1, dtype=np.float64).reshape(-1, dim))
+    t2 = np.asfortranarray(np.asarray(time2, dtype=np.float64).reshape(-1, dim))
+    bk = np.ascontiguousarray(np.asarray(boundary_knots, dtype=np.float64).reshape(dim, 2))
+    ik = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for v in internal_knots]))
+    deg = (C.c_int32 * dim)(*[int(x) for x in basis_degree])
+    nint = (C.c_int32 * dim)(*[len(v) for v in internal_knots])
+    keep += [t1, t2, bk, ik, deg, nint]
+    a.time, a.n_time, a.time2, a.n_time2 = t1.ctypes.data_as(c_double_p), t1.shape[0], t2.ctypes.data_as(c_double_p), t2.shape[0]
+    a.dim, a.basis_degree_hd, a.n_internal_hd = dim, deg, nint
+    a.boundary_knots, a.internal_knots = bk.ctypes.data_as(c_double_p), ik.ctypes.data_as(c_double_p)
+    a.l, a.m, a.rescale, a.simultaneous = l, m, int(bool(rescale)), int(bool(simultaneous))
+    _cov_x(a, keep, X)
+    return _ci_call(_lib_entry().bfmmm_HDFCovCI, a, keep)
+
+
+def MVCovCI(dir, n_files, l, m, alpha=0.05, rescale=True, burnin_prop=0.1, X=None):
+    """src/PostProcessing.cpp:3097 (multivariate model: P x P bands, pointwise)."""
+    a, keep = _ci_args(dir, n_files, alpha, burnin_prop)
+    a.l, a.m, a.rescale = l, m, int(bool(rescale))
+    _cov_x(a, keep, X)
+    return _ci_call(_lib_entry().bfmmm_MVCovCI, a, keep)
 
 
 def MVMeanCI(dir, n_files, alpha=0.05, rescale=True, burnin_prop=0.1, X=None):

@@ -572,12 +572,24 @@ extern "C" int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   return 0;
 }
 
-extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) {
+// FCovCI (src/PostProcessing.cpp:1781), HDFCovCI (:2468) and MVCovCI (:3097): credible bands of the covariance surface
+// between clusters l and m, sum_j (B1 c_lj)(B2 c_mj)' over the kept draws, where c_kj = phi_kj without covariates and
+// c_kj = phi_kj + xi_kj x_b for every row x_b of `X` (the covariate-dependent covariance of the reference's second branch:
+// :2199-2206, :2894-2901, :3375-3382).  kind: 0 functional (B-splines on time1 / time2), 1 high-dimensional (tensor-product
+// basis), 2 multivariate (identity basis, pointwise bands only).
+// Quirks of the reference that are kept: trans_mats is honoured only in FCovCI's branch WITHOUT covariates (:1927, :1992);
+// the rescale transform of the xi cubes is xi_k <- sum_b T(k, b) xi_b (:2175-2185); HDFCovCI evaluates BOTH bases at time1
+// (:2570 passes time1field twice), so its surface is n_time x n_time and time2 only has to have as many rows; CI_Lower is
+// allocated n_time2 x n_time2 (:1879): n_time > n_time2 is refused.
+static int cov_ci_impl(const bfmmm_ci_args* a, int kind, bfmmm_result** out) {
   if (!out) return bfmmm_io_fail("null argument");
-  if (ci_check(a, true)) return 1;
-  if (!a->time2 || a->n_time2 < 1) return bfmmm_io_fail("null argument");
-  if (a->X) return bfmmm_io_fail("FCovCI with covariates is not built in this library");
-  if (a->n_time > a->n_time2) return bfmmm_io_fail("FCovCI: 'time1' longer than 'time2' overruns the reference's CI_Lower (PostProcessing.cpp:1879); not supported");
+  if (ci_check(a, kind != 2)) return 1;
+  if (kind == 1 && a->dim <= 0) return bfmmm_io_fail("bfmmm_HDFCovCI: args.dim must be positive");
+  if (kind == 0 && a->dim > 0) return bfmmm_io_fail("bfmmm_FCovCI: args.dim must be 0 (bfmmm_HDFCovCI is the high-dimensional function)");
+  if (kind != 2 && (!a->time2 || a->n_time2 < 1)) return bfmmm_io_fail("null argument");
+  if (kind == 0 && a->n_time > a->n_time2) return bfmmm_io_fail("FCovCI: 'time1' longer than 'time2' overruns the reference's CI_Lower (PostProcessing.cpp:1879); not supported");
+  if (kind == 1 && a->n_time != a->n_time2) return bfmmm_io_fail("HDFCovCI: 'time1' and 'time2' must have the same number of rows (the reference evaluates both bases at 'time1', PostProcessing.cpp:2570)");
+  if (a->X && (a->n_x < 1 || a->D < 1)) return bfmmm_io_fail("null argument");
   const std::string dir = a->dir;
   std::vector<double> sig;
   int64_t d[3], nr, nc;
@@ -596,12 +608,31 @@ extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   if (a->l > K) return bfmmm_io_fail("'l' must be less than or equal to the number of clusters in the model");
   if (a->m <= 0) return bfmmm_io_fail("'m' must be positive");
   if (a->m > K) return bfmmm_io_fail("'m' must be less than or equal to the number of clusters in the model");
-  if (P != a->n_internal_knots + a->basis_degree + 1) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
+  if (kind != 2) {
+    int Pb = a->n_internal_knots + a->basis_degree + 1;
+    if (a->dim > 0) { Pb = 1; for (int j = 0; j < a->dim; ++j) Pb *= a->n_internal_hd[j] + a->basis_degree_hd[j] + 1; }
+    if (P != Pb) return bfmmm_io_fail("the saved draws do not match the basis ('basis_degree', 'internal_knots')");
+  }
   const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
   if (kept < 2) return bfmmm_io_fail("'burnin_prop' leaves fewer than two draws");
   bool rescale = a->rescale != 0;
   if (rescale && K > 2) rescale = false;
-  // Phi.slice(b) <- T Phi.slice(b) (rescale, :1884-1904) and then <- trans_mats_j Phi.slice(b) if given (:1905-1915: both apply)
+  // xi: T x K cubes P x D x M (field object (i, k) at i + n_rows * k)
+  const int D = a->X ? a->D : 0, W = a->X ? a->n_x : 1;
+  std::vector<std::vector<double>> xi;                       // [(draw) * K + k]
+  if (a->X) {
+    xi.resize((size_t)T * K);
+    for (int q = 0; q < a->n_files; ++q) {
+      std::vector<std::vector<double>> objs;
+      int64_t dx[3];
+      if (arma_load_field(dir + "Xi" + std::to_string(q) + ".txt", objs, &nr, &nc, dx)) return 1;
+      if ((int)nc != K || (int)nr < per_file) return bfmmm_io_fail("'Xi<q>.txt' does not match 'Phi<q>.txt'");
+      if (q == 0 && (int)dx[1] != D) return bfmmm_io_fail("The number of columns in 'X' must be equal to the number of covariates in the model");
+      for (int l = 0; l < per_file; ++l)
+        for (int k = 0; k < K; ++k) xi[(size_t)(q * per_file + l) * K + k] = std::move(objs[(size_t)l + (size_t)nr * k]);
+    }
+  }
+  // rescale: Phi.slice(b) <- T Phi.slice(b); xi_k <- sum_b T(k, b) xi_b.  trans_mats (FCovCI without covariates): both apply
   std::vector<double> Z, Tm, tmp((size_t)K);
   int n = 0;
   if (rescale) {
@@ -609,51 +640,103 @@ extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) {
     if (load_cat(dir, "Z", a->n_files, Z, dz)) return 1;
     n = (int)dz[0];
   }
+  const bool use_tm = a->trans_mats && kind == 0 && !a->X;
   const size_t ld = (size_t)kept * K;
   for (int j = 0; j < kept; ++j) {
     double* ph = phi[(size_t)(first + j)].data();
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 0) { if (!rescale) continue; transform_of(Z.data() + (size_t)n * K * (first + j), n, K, Tm); }
-      else { if (!a->trans_mats) continue; Tm.assign((size_t)K * K, 0.0); for (int i = 0; i < K; ++i) for (int c = 0; c < K; ++c) Tm[i + (size_t)K * c] = a->trans_mats[(size_t)j * K + i + ld * c]; }
+      else { if (!use_tm) continue; Tm.assign((size_t)K * K, 0.0); for (int i = 0; i < K; ++i) for (int c = 0; c < K; ++c) Tm[i + (size_t)K * c] = a->trans_mats[(size_t)j * K + i + ld * c]; }
       for (int b = 0; b < M; ++b)
         for (int p = 0; p < P; ++p) {
           double* col = ph + (size_t)K * (p + (size_t)P * b);
           for (int i = 0; i < K; ++i) { double s_ = 0.0; for (int c = 0; c < K; ++c) s_ += Tm[i + (size_t)K * c] * col[c]; tmp[(size_t)i] = s_; }
           for (int i = 0; i < K; ++i) col[i] = tmp[(size_t)i];
         }
+      if (pass == 0 && a->X) {
+        std::vector<std::vector<double>> old((size_t)K);
+        for (int k = 0; k < K; ++k) old[(size_t)k] = xi[(size_t)(first + j) * K + k];
+        for (int k = 0; k < K; ++k) {
+          std::vector<double>& dst = xi[(size_t)(first + j) * K + k];
+          for (size_t e = 0; e < dst.size(); ++e) {
+            double s_ = old[0][e] * Tm[k + (size_t)K * 0];
+            for (int b = 1; b < K; ++b) s_ = s_ + (old[(size_t)b][e] * Tm[k + (size_t)K * b]);
+            dst[e] = s_;
+          }
+        }
+      }
     }
   }
-  std::vector<double> cl((size_t)kept * M * P), cmv((size_t)kept * M * P);
-  for (int j = 0; j < kept; ++j)
-    for (int b = 0; b < M; ++b)
-      for (int p = 0; p < P; ++p) {
-        const double* ph = phi[(size_t)(first + j)].data();
-        cl[((size_t)j * M + b) * P + p] = ph[(a->l - 1) + (size_t)K * (p + (size_t)P * b)];
-        cmv[((size_t)j * M + b) * P + p] = ph[(a->m - 1) + (size_t)K * (p + (size_t)P * b)];
-      }
-  const int n1 = a->n_time, n2 = a->n_time2;
-  const int32_t deg = a->basis_degree, nint = a->n_internal_knots;
-  auto basis = [&](const double* t, int nt, std::vector<double>& B) {
-    std::vector<double> cm((size_t)nt * P);
-    if (bfmmm_tensor_bspline(nt, 1, t, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
-    B.resize((size_t)nt * P);
-    for (int l = 0; l < nt; ++l)
-      for (int p = 0; p < P; ++p) B[(size_t)l * P + p] = cm[(size_t)l + (size_t)nt * p];
-    return 0;
-  };
+  // bases (row-major n x P)
+  int n1 = a->n_time, n2 = a->n_time2;
   std::vector<double> B1, B2;
-  if (basis(a->time, n1, B1) || basis(a->time2, n2, B2)) return 1;
-  std::vector<double> up((size_t)n1 * n2), md((size_t)n1 * n2), lo((size_t)n1 * n2), tr((size_t)kept * n1 * n2), cube((size_t)kept * n1 * n2);
-  if (bfmmm_post_cov_bands(cl.data(), cmv.data(), kept, M, P, B1.data(), n1, B2.data(), n2, a->alpha, a->simultaneous, a->device,
-                           up.data(), md.data(), lo.data(), tr.data())) return 1;
-  for (size_t c = 0; c < (size_t)n1 * n2; ++c)
-    for (int j = 0; j < kept; ++j) cube[c + (size_t)n1 * n2 * j] = tr[(size_t)j + (size_t)kept * c];
+  if (kind == 2) {
+    n1 = n2 = P;
+    B1.assign((size_t)P * P, 0.0);
+    for (int p = 0; p < P; ++p) B1[(size_t)p * P + p] = 1.0;
+    B2 = B1;
+  } else {
+    const int32_t deg = a->basis_degree, nint = a->n_internal_knots;
+    auto basis = [&](const double* t, int nt, std::vector<double>& B) {
+      std::vector<double> cm((size_t)nt * P);
+      if (a->dim > 0 ? bfmmm_tensor_bspline(nt, a->dim, t, a->basis_degree_hd, a->boundary_knots, a->n_internal_hd, a->internal_knots, cm.data())
+                     : bfmmm_tensor_bspline(nt, 1, t, &deg, a->boundary_knots, &nint, a->internal_knots, cm.data())) return 1;
+      B.resize((size_t)nt * P);
+      for (int l = 0; l < nt; ++l)
+        for (int p = 0; p < P; ++p) B[(size_t)l * P + p] = cm[(size_t)l + (size_t)nt * p];
+      return 0;
+    };
+    if (basis(a->time, n1, B1)) return 1;
+    if (kind == 1) B2 = B1;                                   // the reference's second basis is built from time1 as well (:2570)
+    else if (basis(a->time2, n2, B2)) return 1;
+  }
+  const size_t cells = (size_t)n1 * n2;
+  const int simultaneous = (kind == 2) ? 0 : a->simultaneous;
+  std::vector<double> up(cells * W), md(cells * W), lo(cells * W), cube(cells * kept * W), tr(cells * kept);
+  std::vector<double> cl((size_t)kept * M * P), cmv((size_t)kept * M * P);
+  for (int w = 0; w < W; ++w) {
+    for (int j = 0; j < kept; ++j) {
+      const double* ph = phi[(size_t)(first + j)].data();
+      for (int b = 0; b < M; ++b)
+        for (int p = 0; p < P; ++p) {
+          double vl = ph[(a->l - 1) + (size_t)K * (p + (size_t)P * b)], vm = ph[(a->m - 1) + (size_t)K * (p + (size_t)P * b)];
+          if (a->X) {
+            const double* xl = xi[(size_t)(first + j) * K + (a->l - 1)].data();
+            const double* xm = xi[(size_t)(first + j) * K + (a->m - 1)].data();
+            double sl = 0.0, sm = 0.0;
+            for (int dd = 0; dd < D; ++dd) {
+              const double x = a->X[(size_t)w + (size_t)a->n_x * dd];
+              sl += xl[p + (size_t)P * (dd + (size_t)D * b)] * x;
+              sm += xm[p + (size_t)P * (dd + (size_t)D * b)] * x;
+            }
+            vl += sl; vm += sm;
+          }
+          cl[((size_t)j * M + b) * P + p] = vl;
+          cmv[((size_t)j * M + b) * P + p] = vm;
+        }
+    }
+    if (bfmmm_post_cov_bands(cl.data(), cmv.data(), kept, M, P, B1.data(), n1, B2.data(), n2, a->alpha, simultaneous, a->device,
+                             up.data() + cells * w, md.data() + cells * w, lo.data() + cells * w, tr.data())) return 1;
+    double* cw = cube.data() + cells * kept * w;
+    for (size_t c = 0; c < cells; ++c)
+      for (int j = 0; j < kept; ++j) cw[c + cells * j] = tr[(size_t)j + (size_t)kept * c];
+  }
   bfmmm_result* r = bfmmm_result_create();
-  put_mat(r, "CI_Upper", up, n1, n2); put_mat(r, "CI_50", md, n1, n2); put_mat(r, "CI_Lower", lo, n1, n2);
-  put_mat(r, "cov_trace", cube, n1, n2, kept);
+  if (!a->X) {
+    put_mat(r, "CI_Upper", up, n1, n2); put_mat(r, "CI_50", md, n1, n2); put_mat(r, "CI_Lower", lo, n1, n2);
+    put_mat(r, "cov_trace", cube, n1, n2, kept);
+  } else {      // cubes n1 x n2 x n_x; cov_trace: the n_x cubes of the reference's field, one after the other (n1 x n2 x kept x n_x)
+    put_mat(r, "CI_Upper", up, n1, n2, W); put_mat(r, "CI_50", md, n1, n2, W); put_mat(r, "CI_Lower", lo, n1, n2, W);
+    const int64_t dims[4] = {n1, n2, kept, W};
+    bfmmm_result_set(r, "cov_trace", cube.data(), (int64_t)cube.size(), dims, 4);
+  }
   *out = r;
   return 0;
 }
+
+extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return cov_ci_impl(a, 0, out); }
+extern "C" int bfmmm_HDFCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return cov_ci_impl(a, 1, out); }
+extern "C" int bfmmm_MVCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return cov_ci_impl(a, 2, out); }
 
 extern "C" int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   if (!out) return bfmmm_io_fail("null argument");

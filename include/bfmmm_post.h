@@ -143,9 +143,17 @@ int bfmmm_FMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
 /* HDFMeanCI (src/PostProcessing.cpp:806): FMeanCI over the tensor-product basis (args.dim > 0).  The reference's function has no
  * trans_mats argument (RcppExports.cpp:40); the field is honoured here if set. */
 int bfmmm_HDFMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);
-/* FCovCI (src/PostProcessing.cpp:1781) without covariates: "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace"
- * (n_time x n_time2 x kept).  The reference allocates CI_Lower as n_time2 x n_time2 (:1879): n_time > n_time2 is refused here. */
+/* FCovCI (src/PostProcessing.cpp:1781): "CI_Upper", "CI_50", "CI_Lower" (n_time x n_time2) and "cov_trace" (n_time x n_time2 x
+ * kept).  With X (n_x covariate settings; the covariance then depends on them through xi, :2199-2206) the bands are cubes
+ * n_time x n_time2 x n_x and "cov_trace" is n_time x n_time2 x kept x n_x (the n_x cubes of the reference's field); trans_mats
+ * is honoured only without X, as in the reference.  The reference allocates CI_Lower as n_time2 x n_time2 (:1879):
+ * n_time > n_time2 is refused here.
+ * HDFCovCI (:2468): the same over the tensor-product basis (args.dim > 0; `time`, `time2` n x dim column-major).  The reference
+ * builds BOTH bases from time1 (:2570), so the surface is evaluated on time1 x time1 and n_time2 must equal n_time.
+ * MVCovCI (:3097): the multivariate model (identity basis): P x P bands (x n_x with X), pointwise only, no trans_mats. */
 int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out);
+int bfmmm_HDFCovCI(const bfmmm_ci_args* a, bfmmm_result** out);
+int bfmmm_MVCovCI(const bfmmm_ci_args* a, bfmmm_result** out);
 /* MVMeanCI (src/PostProcessing.cpp:1410): K x P matrices and "mean_trace" (K x P x kept); with X: K x P x n_x cubes and
  * "mean_trace" as K x P x (kept n_x), the n_x cubes of the reference's field one after the other */
 int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out);

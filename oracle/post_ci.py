@@ -133,6 +133,43 @@ def f_cov_ci(Phi, B1, B2, l, m, alpha, rescale, simultaneous, burnin_prop, Z=Non
     return dict(CI_Upper=sh(up), CI_50=sh(md), CI_Lower=sh(lo), cov_trace=cov)
 
 
+def f_cov_ci_x(Phi, xi, X, B1, B2, l, m, alpha, rescale, simultaneous, burnin_prop, Z=None):
+    """The covariate branch of FCovCI (:2051-2330), HDFCovCI (:2740-3010) and MVCovCI (:3240-3405): the covariance between
+    clusters l and m at every covariate setting X[b], sum_j (B1 (phi_lj + xi_lj x_b)) (B2 (phi_mj + xi_mj x_b))'.
+    Phi (K, P, M, T); xi (P, D, M, K, T); X (n_x, D).  No trans_mats in this branch; the rescale transform acts on Phi and,
+    as xi_k <- sum_b T(k, b) xi_b (:2175-2185), on xi.  Returns bands (n1, n2, n_x) and cov_trace (n1, n2, kept, n_x)."""
+    K, P, M, T = Phi.shape
+    kept = kept_count(T, burnin_prop)
+    Phi = np.array(Phi[..., T - kept:], copy=True)
+    xi = np.array(xi[..., T - kept:], copy=True)
+    if rescale and K > 2:
+        rescale = False
+    n1, n2, nx = B1.shape[0], B2.shape[0], X.shape[0]
+    cov = np.zeros((n1, n2, kept, nx))
+    for j in range(kept):
+        if rescale:
+            Tm = transform_mat(Z[:, :, T - kept + j])
+            for b in range(M):
+                Phi[:, :, b, j] = Tm @ Phi[:, :, b, j]
+            old = xi[..., j].copy()
+            for k in range(K):
+                acc = old[..., 0] * Tm[k, 0]
+                for b in range(1, K):
+                    acc = acc + old[..., b] * Tm[k, b]
+                xi[..., k, j] = acc
+        for b in range(M):
+            for w in range(nx):
+                cl = Phi[l - 1, :, b, j] + xi[:, :, b, l - 1, j] @ X[w]
+                cm = Phi[m - 1, :, b, j] + xi[:, :, b, m - 1, j] @ X[w]
+                cov[:, :, j, w] += np.outer(B1 @ cl, B2 @ cm)
+    up, md, lo = (np.zeros((n1, n2, nx)) for _ in range(3))
+    for w in range(nx):
+        flat = cov[..., w].reshape(n1 * n2, kept, order="F").T
+        u, c, d = bands(flat, alpha, simultaneous)
+        up[..., w], md[..., w], lo[..., w] = (v.reshape(n1, n2, order="F") for v in (u, c, d))
+    return dict(CI_Upper=up, CI_50=md, CI_Lower=lo, cov_trace=cov)
+
+
 def mv_mean_ci(nu, alpha, rescale, burnin_prop, Z=None, X=None, eta=None):
     """MVMeanCI :1410-1660.  nu (K, P, T); eta (P, D, K, T); X (n_x, D)."""
     K, P, T = nu.shape
