@@ -118,6 +118,9 @@ POST_SYMBOLS = {
     "bfmmm_post_cpo": (C.c_int, [C.POINTER(PostInput), C.c_int32, c_double_p]),
     "bfmmm_ConditionalPredictiveOrdinates": (C.c_int, [C.POINTER(PostArgs), C.c_int32, C.POINTER(C.c_void_p)]),
     "bfmmm_post_last_kernel_ms": (C.c_double, []),
+    "bfmmm_FSamplePaths": (C.c_int, [C.POINTER(PostArgs), C.c_double, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "bfmmm_post_sample_paths": (C.c_int, [C.POINTER(PostInput), C.c_int32, C.c_uint64, c_double_p, c_double_p]),
+    "bfmmm_post_table_bands": (C.c_int, [c_double_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "bfmmm_MVLLik": (C.c_int, [C.POINTER(PostArgs), C.POINTER(C.c_void_p)]),
     "bfmmm_MVDIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
     "bfmmm_MVAIC": (C.c_int, [C.POINTER(PostArgs), c_double_p]),
@@ -643,6 +646,31 @@ def FLLik(dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, X
         return _result_to_dict(lib, res, None, 0)["value"]
     finally:
         lib.bfmmm_result_free(res)
+
+
+def FSamplePaths(dir, n_files, basis_degree, boundary_knots, internal_knots, time, alpha=0.05, burnin_prop=0.1, simultaneous=False,
+                 X=None, cov_adj=False, seed=1):
+    """src/PostProcessing.cpp:6599: posterior-predictive sample paths.  Returns lists over the curves: CI_Upper / CI_50 /
+    CI_Lower (vectors of n_i), Path_trace / Mean_only_Path_trace (kept x n_i matrices).  `seed`: the keyed generator of the
+    predictive noise (the reference draws it from R's stream)."""
+    lib = _lib_entry()
+    args = _PostArgs(dir, n_files, basis_degree, boundary_knots, internal_knots, time, [np.zeros(len(v)) for v in time],
+                     burnin_prop, X, cov_adj)
+    res = C.c_void_p()
+    _check(lib.bfmmm_FSamplePaths(C.byref(args.a), float(alpha), int(bool(simultaneous)), int(seed), C.byref(res)))
+    try:
+        d = _result_to_dict(lib, res, None, 0)
+    finally:
+        lib.bfmmm_result_free(res)
+    off = args.off
+    out = {}
+    for nm in ("CI_Upper", "CI_50", "CI_Lower"):
+        v = d[nm].reshape(-1)
+        out[nm] = [v[off[i]:off[i + 1]].copy() for i in range(len(off) - 1)]
+    for nm in ("Path_trace", "Mean_only_Path_trace"):
+        m = d[nm]
+        out[nm] = [m[:, off[i]:off[i + 1]].copy() for i in range(len(off) - 1)]
+    return out
 
 
 def _post_scalar(name, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj):

@@ -223,3 +223,15 @@ extern "C" int bfmmm_post_cov_bands(const double* coefL, const double* coefM, in
     return bfmmm_io_fail("bfmmm_post_cov_bands: copy back failed");
   return 0;
 }
+
+// bands of a table given as is: V is T x ncol, draw fastest (FSamplePaths' Path_trace of one curve or of all curves)
+extern "C" int bfmmm_post_table_bands(const double* V, int32_t T, int32_t ncol, double alpha, int32_t simultaneous, int32_t device,
+                                      double* upper, double* mid, double* lower) {
+  if (!V || !upper || !mid || !lower || T < 2 || ncol < 1) return bfmmm_io_fail("bfmmm_post_table_bands: bad arguments");
+  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_table_bands: at most 8192 kept draws in this build");
+  if (select_device(device, "bfmmm_post_table_bands")) return 1;
+  Bufs b;
+  double* dV;
+  if (!b.put(&dV, V, (size_t)T * ncol)) return bfmmm_io_fail("bfmmm_post_table_bands: device allocation or copy failed");
+  return table_bands(b, dV, T, ncol, alpha, simultaneous, upper, mid, lower, "bfmmm_post_table_bands");
+}

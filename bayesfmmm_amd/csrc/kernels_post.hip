@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/bfmmm_post.h"
+#include "rng.hpp"
 
 int bfmmm_io_fail(const std::string& m);      // entry_points.cpp: sets bfmmm_entry_last_error
 
@@ -362,6 +363,49 @@ __global__ __launch_bounds__(256) void k_post_cpo_reduce(PostDev a, const double
 
 float g_last_kernel_ms = 0.f;
 
+// ---- posterior-predictive sample paths (FSamplePaths, src/PostProcessing.cpp:6599-6864) ----------------------------------------
+// For curve i, kept draw t and observation l: the fitted value f_il(t) (all terms; Z_ik == 0 clusters skipped as the
+// reference does, :6797), the mean-only value (nu and eta terms, :6800-6801) and the predictive draw
+// rnorm(f_il(t), sqrt(sigma^2(t))) (:6810) -- from the keyed generator, word (seed, chain 0, iteration = draw index,
+// UPD_SAMPLE_PATH, observation index).  grid (curves, chunks of kept draws); a thread owns (observation, draw) pairs.
+// Outputs: for curve i a kept x n_i block, draw fastest, at kept * off[i].
+__global__ __launch_bounds__(256) void k_post_paths(PostDev a, unsigned long long seed, int kept, double* paths, double* mean_only) {
+  const int i = blockIdx.x;
+  const long long o = a.off[i];
+  const int ni = (int)(a.off[i + 1] - o);
+  const int K = a.K, P = a.P, M = a.M, D = a.D, W = a.W, R = K * (M + 1);
+  const int t0 = a.first_kept + blockIdx.y * a.tchunk, t1 = min(t0 + a.tchunk, a.T);
+  const long long npair = (long long)ni * (t1 - t0);
+  for (long long e = threadIdx.x; e < npair; e += 256) {
+    const int l = (int)(e % ni), t = t0 + (int)(e / ni);
+    const double* bw = a.Bc + (size_t)(o + l) * W;
+    const int st = a.bstart[o + l];
+    const double* th = a.theta + (size_t)t * R * P;
+    const double* thx = (D > 0) ? a.thetaX + (size_t)t * R * D * P : nullptr;
+    double mean = 0.0, mo = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double z = a.Z[i + (size_t)a.n * (k + (size_t)K * t)];
+      if (z != 0) {
+        for (int mt = 0; mt <= M; ++mt) {
+          const int r = k * (M + 1) + mt;
+          double dot = 0.0;
+          for (int w = 0; w < W; ++w) {
+            double cf = th[(size_t)r * P + st + w];
+            for (int dd = 0; dd < D; ++dd) cf += thx[((size_t)r * D + dd) * P + st + w] * a.X[i + (size_t)a.n * dd];
+            dot += cf * bw[w];
+          }
+          if (mt == 0) { mean = mean + z * dot; mo = mo + z * dot; }
+          else mean = mean + z * a.chi[i + (size_t)a.n * ((mt - 1) + (size_t)M * t)] * dot;
+        }
+      }
+    }
+    const size_t dst = (size_t)kept * o + (size_t)(t - a.first_kept) + (size_t)kept * l;
+    mean_only[dst] = mo;
+    const bfmmm::RngKey key = bfmmm::make_key(seed, 0u, (uint32_t)t, 0u);
+    paths[dst] = mean + sqrt(a.sigma[t]) * bfmmm::rnorm(key, bfmmm::UPD_SAMPLE_PATH, (uint32_t)(o + l));
+  }
+}
+
 struct DevBufs {
   std::vector<void*> p;
   ~DevBufs() { for (void* q : p) (void)hipFree(q); }
@@ -519,3 +563,74 @@ extern "C" int bfmmm_post_cpo(const bfmmm_post_input* in, int32_t first_kept, do
 
 // device time of the last bfmmm_post_pointwise call's two kernels (HIP events on the launch stream), for measurement
 extern "C" double bfmmm_post_last_kernel_ms(void) { return (double)g_last_kernel_ms; }
+
+// bfmmm_post_sample_paths: paths / mean_only hold, for curve i, a kept x n_i block (draw fastest) at kept * offsets[i]
+extern "C" int bfmmm_post_sample_paths(const bfmmm_post_input* in, int32_t first_kept, uint64_t seed, double* paths, double* mean_only) {
+  if (!in || !in->offsets || !in->B || !in->nu || !in->Phi || !in->Z || !in->chi || !in->sigma || !paths || !mean_only)
+    return bfmmm_io_fail("bfmmm_post_sample_paths: null argument");
+  const int n = in->n, K = in->K, P = in->P, M = in->M, D = in->X ? in->D : 0, T = in->T;
+  if (n < 1 || K < 1 || P < 1 || M < 0 || T < 1 || first_kept < 0 || first_kept >= T)
+    return bfmmm_io_fail("bfmmm_post_sample_paths: bad dimensions");
+  if ((double)T * K * (M + 1) * P * std::max(D, 1) >= 5.0e8) return bfmmm_io_fail("bfmmm_post_sample_paths: too many draws for one call: split the draws");
+  const long long n_obs = in->offsets[n];
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bfmmm_io_fail("bfmmm_post_sample_paths: no HIP device (the MI355X library has no CPU path)");
+  if (hipSetDevice(in->device) != hipSuccess) return bfmmm_io_fail("bfmmm_post_sample_paths: cannot select the device");
+  const int R = K * (M + 1), kept = T - first_kept;
+  std::vector<double> theta((size_t)T * R * P), thetaX;
+  for (int t = 0; t < T; ++t)
+    for (int k = 0; k < K; ++k)
+      for (int p = 0; p < P; ++p) {
+        theta[((size_t)t * R + k * (M + 1)) * P + p] = in->nu[k + (size_t)K * (p + (size_t)P * t)];
+        for (int m = 0; m < M; ++m)
+          theta[((size_t)t * R + k * (M + 1) + m + 1) * P + p] = in->Phi[(size_t)t * K * P * M + k + (size_t)K * (p + (size_t)P * m)];
+      }
+  if (D > 0) {
+    thetaX.assign((size_t)T * R * D * P, 0.0);
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < K; ++k)
+        for (int dd = 0; dd < D; ++dd)
+          for (int p = 0; p < P; ++p) {
+            if (in->eta) thetaX[(((size_t)t * R + k * (M + 1)) * D + dd) * P + p] = in->eta[(size_t)t * P * D * K + p + (size_t)P * (dd + (size_t)D * k)];
+            if (in->xi)
+              for (int m = 0; m < M; ++m)
+                thetaX[(((size_t)t * R + k * (M + 1) + m + 1) * D + dd) * P + p] = in->xi[((size_t)t * K + k) * P * D * M + p + (size_t)P * (dd + (size_t)D * m)];
+          }
+  }
+  int W = 1;
+  std::vector<int> first((size_t)n_obs, 0);
+  for (long long e = 0; e < n_obs; ++e) {
+    int f = -1, l = -1;
+    for (int p = 0; p < P; ++p)
+      if (in->B[(size_t)e * P + p] != 0.0) { if (f < 0) f = p; l = p; }
+    first[(size_t)e] = std::max(f, 0);
+    if (f >= 0) W = std::max(W, l - f + 1);
+  }
+  std::vector<double> Bc((size_t)n_obs * W);
+  for (long long e = 0; e < n_obs; ++e) {
+    const int st = std::min(first[(size_t)e], P - W);
+    first[(size_t)e] = st;
+    for (int w = 0; w < W; ++w) Bc[(size_t)e * W + w] = in->B[(size_t)e * P + st + w];
+  }
+  int tchunk = kept;
+  while ((long long)n * ((kept + tchunk - 1) / tchunk) < 1024 && tchunk > 8) tchunk = (tchunk + 1) / 2;
+  const int NCH = (kept + tchunk - 1) / tchunk;
+  DevBufs db;
+  PostDev a{};
+  a.W = W; a.n = n; a.K = K; a.P = P; a.M = M; a.D = D; a.T = T; a.first_kept = first_kept; a.tchunk = tchunk; a.n_obs = n_obs;
+  std::vector<long long> off(in->offsets, in->offsets + n + 1);
+  double *d_paths, *d_mo;
+  bool ok = db.put((long long**)&a.off, off.data(), off.size()) && db.put((double**)&a.Bc, Bc.data(), Bc.size()) &&
+            db.put((int**)&a.bstart, first.data(), first.size()) && db.put((double**)&a.theta, theta.data(), theta.size()) &&
+            db.put((double**)&a.Z, in->Z, (size_t)n * K * T) && db.put((double**)&a.chi, in->chi, (size_t)n * M * T) &&
+            db.put((double**)&a.sigma, in->sigma, (size_t)T) && db.put(&d_paths, (const double*)nullptr, (size_t)kept * n_obs) &&
+            db.put(&d_mo, (const double*)nullptr, (size_t)kept * n_obs);
+  if (ok && D > 0) ok = db.put((double**)&a.X, in->X, (size_t)n * D) && db.put((double**)&a.thetaX, thetaX.data(), thetaX.size());
+  if (!ok) { (void)hipGetLastError(); return bfmmm_io_fail("bfmmm_post_sample_paths: device allocation or copy failed"); }
+  hipLaunchKernelGGL(k_post_paths, dim3(n, NCH), dim3(256), 0, 0, a, (unsigned long long)seed, kept, d_paths, d_mo);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return bfmmm_io_fail("bfmmm_post_sample_paths: kernel launch failed");
+  if (hipMemcpy(paths, d_paths, sizeof(double) * (size_t)kept * n_obs, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(mean_only, d_mo, sizeof(double) * (size_t)kept * n_obs, hipMemcpyDeviceToHost) != hipSuccess)
+    return bfmmm_io_fail("bfmmm_post_sample_paths: copy back failed");
+  return 0;
+}

@@ -738,6 +738,59 @@ extern "C" int bfmmm_FCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return
 extern "C" int bfmmm_HDFCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return cov_ci_impl(a, 1, out); }
 extern "C" int bfmmm_MVCovCI(const bfmmm_ci_args* a, bfmmm_result** out) { return cov_ci_impl(a, 2, out); }
 
+// FSamplePaths (src/PostProcessing.cpp:6599-6864): posterior-predictive sample paths of every curve at its own time points
+// -- for each kept draw the fitted value plus N(0, sigma^2) noise (:6810; the noise comes from the keyed generator, the
+// reference's from R's stream) -- with pointwise (:6817-6828) or simultaneous (:6829-6855) bands per curve, the paths
+// ("Path_trace") and the mean-only paths (nu and eta terms, "Mean_only_Path_trace").  Without X the reference runs with
+// X = 0 and eta = 0; cov_adj = 0 leaves xi = 0.  Result elements are concatenated over the curves: the bands have
+// offsets[n] entries, the two traces kept x offsets[n] (curve i: a kept x n_i block, draw fastest, at kept * offsets[i]).
+// (In the simultaneous branch the reference sizes its scratch vector by the number of CURVES (:6837) and so fails when a
+// curve has more points than there are curves; here the maximum runs over the curve's own points.)
+extern "C" int bfmmm_FSamplePaths(const bfmmm_post_args* a, double alpha, int32_t simultaneous, uint64_t seed, bfmmm_result** out) {
+  if (!out || !a || !a->dir || !a->t || !a->offsets || !a->boundary_knots || (a->n_internal_knots > 0 && !a->internal_knots))
+    return bfmmm_io_fail("null argument");
+  if (a->n_files <= 0) return bfmmm_io_fail("'n_files' must be greater than 0");
+  if (alpha < 0 || alpha >= 1) return bfmmm_io_fail("'alpha' must be between 0 and 1");
+  if (a->burnin_prop < 0 || a->burnin_prop >= 1) return bfmmm_io_fail("'burnin_prop' must be between 0 and 1");
+  if (a->basis_degree < 1) return bfmmm_io_fail("'basis_degree' must be an integer greater than or equal to 1");
+  for (int i = 0; i < a->n_internal_knots; ++i) {
+    if (a->boundary_knots[0] >= a->internal_knots[i])
+      return bfmmm_io_fail("at least one element in 'internal_knots' is less than or equal to first boundary knot");
+    if (a->boundary_knots[1] <= a->internal_knots[i])
+      return bfmmm_io_fail("at least one element in 'internal_knots' is more than or equal to second boundary knot");
+  }
+  Draws dr;
+  if (load_draws(a, dr)) return 1;
+  const int n = dr.n, T = dr.T;
+  const int kept = (int)std::round(T * (1 - a->burnin_prop)), first = T - kept;
+  if (kept < 2) return bfmmm_io_fail("'burnin_prop' leaves fewer than two draws");
+  const int64_t n_obs = a->offsets[n];
+  bfmmm_post_input in{};
+  in.n = n; in.K = dr.K; in.P = dr.P; in.M = dr.M; in.D = dr.D;
+  in.offsets = a->offsets; in.y = nullptr; in.B = dr.B.data(); in.X = a->X;
+  in.T = T; in.nu = dr.nu.data(); in.Phi = dr.Phi.data(); in.Z = dr.Z.data(); in.chi = dr.chi.data(); in.sigma = dr.sigma.data();
+  in.eta = dr.eta.empty() ? nullptr : dr.eta.data();
+  in.xi = dr.xi.empty() ? nullptr : dr.xi.data();
+  in.device = a->device;
+  std::vector<double> paths((size_t)kept * n_obs), mo((size_t)kept * n_obs), up((size_t)n_obs), md((size_t)n_obs), lo((size_t)n_obs);
+  if (bfmmm_post_sample_paths(&in, first, seed, paths.data(), mo.data())) return 1;
+  if (!simultaneous) {      // every column on its own: one call for all curves
+    if (bfmmm_post_table_bands(paths.data(), kept, (int)n_obs, alpha, 0, a->device, up.data(), md.data(), lo.data())) return 1;
+  } else {
+    for (int i = 0; i < n; ++i) {
+      const int64_t o = a->offsets[i], ni = a->offsets[i + 1] - o;
+      if (ni < 1) continue;
+      if (bfmmm_post_table_bands(paths.data() + (size_t)kept * o, kept, (int)ni, alpha, 1, a->device, up.data() + o, md.data() + o, lo.data() + o))
+        return 1;
+    }
+  }
+  bfmmm_result* r = bfmmm_result_create();
+  put_mat(r, "CI_Upper", up, n_obs, -1); put_mat(r, "CI_50", md, n_obs, -1); put_mat(r, "CI_Lower", lo, n_obs, -1);
+  put_mat(r, "Path_trace", paths, kept, n_obs); put_mat(r, "Mean_only_Path_trace", mo, kept, n_obs);
+  *out = r;
+  return 0;
+}
+
 extern "C" int bfmmm_MVMeanCI(const bfmmm_ci_args* a, bfmmm_result** out) {
   if (!out) return bfmmm_io_fail("null argument");
   if (ci_check(a, false)) return 1;

@@ -24,7 +24,8 @@ enum UpdId : uint32_t {
   UPD_TAU = 13, UPD_SIGMA = 14, UPD_CHI = 15, UPD_ETA = 16, UPD_TAU_ETA = 17, UPD_XI = 18,
   UPD_DELTA_XI = 19, UPD_AXI_PROP = 20, UPD_AXI_ACC = 21, UPD_GAMMA_XI = 22,
   UPD_INIT_NU = 30, UPD_INIT_CHI = 31, UPD_INIT_PI = 32, UPD_INIT_Z = 33, UPD_INIT_PHI = 34,
-  UPD_INIT_ETA = 35, UPD_INIT_XI = 36, UPD_TT_ACC = 40
+  UPD_INIT_ETA = 35, UPD_INIT_XI = 36, UPD_TT_ACC = 40,
+  UPD_SAMPLE_PATH = 41      // posterior-predictive draws of FSamplePaths (kernels_post.hip)
 };
 
 struct RngKey {

@@ -85,6 +85,18 @@ int bfmmm_FBIC(const bfmmm_post_args* a, double* out);
 /* ConditionalPredictiveOrdinates (src/PostProcessing.cpp:6339): result element "value", one entry per curve; log_CPO = 0
  * returns exp of it */
 int bfmmm_ConditionalPredictiveOrdinates(const bfmmm_post_args* a, int32_t log_CPO, bfmmm_result** out);
+/* FSamplePaths (src/PostProcessing.cpp:6599): posterior-predictive sample paths of every curve at its own time points (a->y is
+ * not used and may be NULL) over the last round(T (1 - burnin_prop)) draws, with pointwise or simultaneous bands per curve.
+ * Result elements, concatenated over the curves: "CI_Upper", "CI_50", "CI_Lower" (offsets[n] entries), "Path_trace" and
+ * "Mean_only_Path_trace" (kept x offsets[n]: curve i is the kept x n_i block, draw fastest, at kept * offsets[i]).  The
+ * predictive noise is drawn from the keyed generator (seed, draw index, observation index); the reference uses R's stream. */
+int bfmmm_FSamplePaths(const bfmmm_post_args* a, double alpha, int32_t simultaneous, uint64_t seed, bfmmm_result** out);
+/* the device pass behind it: fitted value + noise ("paths") and the mean-only value of every (kept draw, observation) */
+int bfmmm_post_sample_paths(const bfmmm_post_input* in, int32_t first_kept, uint64_t seed, double* paths, double* mean_only);
+/* bands of a T x ncol table (draw fastest) as is: pointwise (alpha / 2, 0.5, 1 - alpha / 2) quantiles of every column, or the
+ * simultaneous band over all columns (src/PostProcessing.cpp:6829-6855) */
+int bfmmm_post_table_bands(const double* V, int32_t T, int32_t ncol, double alpha, int32_t simultaneous, int32_t device,
+                           double* upper, double* mid, double* lower);
 /* multivariate model: MVLLik (src/PostProcessing.cpp:6099), MVDIC (:5789), MVAIC (:5116), MVBIC (:5452) */
 int bfmmm_MVLLik(const bfmmm_post_args* a, bfmmm_result** out);
 int bfmmm_MVDIC(const bfmmm_post_args* a, double* out);

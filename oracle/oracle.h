@@ -45,7 +45,7 @@ enum {
   UPD_DELTA_XI = 19, UPD_AXI_PROP = 20, UPD_AXI_ACC = 21, UPD_GAMMA_XI = 22,
   UPD_INIT_NU = 30, UPD_INIT_CHI = 31, UPD_INIT_PI = 32, UPD_INIT_Z = 33, UPD_INIT_PHI = 34,
   UPD_INIT_ETA = 35, UPD_INIT_XI = 36,
-  UPD_TT_ACC = 40
+  UPD_TT_ACC = 40, UPD_SAMPLE_PATH = 41
 };
 
 typedef struct {

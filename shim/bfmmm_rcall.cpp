@@ -11,9 +11,10 @@
 //   _BayesFMMM_BHDFMMM_Nu_Z_multiple_try (28, :552), _BHDFMMM_Theta_est (32, :590), _BHDFMMM_warm_start (38, :632)
 //   _BayesFMMM_FDIC / FAIC / FBIC (10 args, :174, :194, :214), _BayesFMMM_FLLik (9, :234)  -> bfmmm_FDIC ... (bfmmm_post.h)
 //   _BayesFMMM_ConditionalPredictiveOrdinates (11), MVLLik (5), MVDIC / MVAIC / MVBIC (6), SigmaCI (4), ZCI (5), FMeanCI (13),
-//   FCovCI (15), MVMeanCI (6)                                                          -> bfmmm_post.h
+//   FCovCI (15), MVMeanCI (6), HDFMeanCI (12), HDFCovCI (14), MVCovCI (8), FSamplePaths (11)      -> bfmmm_post.h
 //   _BayesFMMM_ReadVec / ReadMat / ReadCube / ReadFieldCube / ReadFieldMat / ReadFieldVec (1 arg each, :486-541)
 //
+// All 33 entries of the reference's CallEntries[] (src/RcppExports.cpp:794-835) are registered here.
 // It is pure marshalling (no arithmetic): R lists of numeric vectors become CSR arrays, Rcpp::List arguments become
 // bfmmm_result objects, results become named R lists with the reference's shapes.  It needs <Rinternals.h> and is NOT
 // built by this repository's Makefile (the image has no R); INTEGRATION.md explains the build line.
@@ -23,6 +24,8 @@
 #include <R_ext/Rdynload.h>
 
 #include <cstring>
+#include <deque>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -31,14 +34,55 @@
 
 namespace {
 
+// Errors: the library reports through bfmmm_entry_last_error(); the shim raises them as C++ exceptions inside a
+// SHIM_BEGIN / SHIM_END pair, so that every C++ object of the entry point (the CSR copies, bfmmm_result handles held by
+// Owned) is destroyed BEFORE Rf_error's longjmp -- the role of Rcpp's BEGIN_RCPP / END_RCPP (RcppExports.cpp:359, :392).
+#define SHIM_BEGIN char* shim_msg_ = NULL; try {
+#define SHIM_END } catch (const std::exception& e_) { const size_t n_ = std::strlen(e_.what()) + 1; shim_msg_ = R_alloc(n_, 1); std::memcpy(shim_msg_, e_.what(), n_); } \
+  Rf_error("%s", shim_msg_ ? shim_msg_ : "unknown error"); return R_NilValue;
+[[noreturn]] void lib_error() { throw std::runtime_error(bfmmm_entry_last_error()); }
+
+struct Owned {                                          // a bfmmm_result freed on every path
+  bfmmm_result* r = NULL;
+  ~Owned() { if (r) bfmmm_result_free(r); }
+};
+
+// a numeric R vector / matrix as doubles: the reference's Rcpp::NumericMatrix / arma conversions coerce integer and logical
+// input (e.g. a 0/1 covariate matrix), REAL() alone would raise an R error on it
+struct Num {
+  std::vector<double> own;
+  const double* p = NULL;
+  R_xlen_t len = 0;
+  int nrow = 0, ncol = 0;
+  explicit Num(SEXP x) {
+    if (x == R_NilValue) return;
+    len = Rf_xlength(x);
+    nrow = Rf_isMatrix(x) ? Rf_nrows(x) : (int)len;
+    ncol = Rf_isMatrix(x) ? Rf_ncols(x) : 1;
+    if (TYPEOF(x) == REALSXP) { p = REAL(x); return; }
+    if (TYPEOF(x) != INTSXP && TYPEOF(x) != LGLSXP) throw std::runtime_error("a numeric argument is required");
+    SEXP c = PROTECT(Rf_coerceVector(x, REALSXP));
+    own.assign(REAL(c), REAL(c) + len);
+    UNPROTECT(1);
+    p = own.data();
+  }
+};
+
+// the coerced numeric arguments of one call (stable addresses)
+struct Inputs {
+  std::deque<Num> nums;
+  const double* num(SEXP x) { nums.emplace_back(x); return nums.back().p; }
+};
+
 struct Ragged { std::vector<double> v; std::vector<int64_t> off; };
 
 Ragged flatten(SEXP lst) {                              // R list of numeric vectors -> CSR
   Ragged r;
   r.off.push_back(0);
+  if (TYPEOF(lst) != VECSXP) throw std::runtime_error("a list of numeric vectors is required");
   for (R_xlen_t i = 0; i < Rf_xlength(lst); ++i) {
-    SEXP e = VECTOR_ELT(lst, i);
-    r.v.insert(r.v.end(), REAL(e), REAL(e) + Rf_xlength(e));
+    const Num e(VECTOR_ELT(lst, i));
+    r.v.insert(r.v.end(), e.p, e.p + e.len);
     r.off.push_back((int64_t)r.v.size());
   }
   return r;
@@ -160,8 +204,9 @@ struct Hyper {
        alpha_eta, beta_eta, alpha_0, beta_0;
 };
 
-void set_hyper(bfmmm_entry_args& a, const Hyper& h) {
-  a.c = (h.c == R_NilValue) ? NULL : REAL(h.c);
+void set_hyper(bfmmm_entry_args& a, const Hyper& h, Inputs& in) {
+  a.c = (h.c == R_NilValue) ? NULL : in.num(h.c);
+  if (h.c != R_NilValue && Rf_length(h.c) != a.K) throw std::runtime_error("number of elements of the vector 'c' must be equal to K");
   a.b = Rf_asReal(h.b);
   if (h.nu_1 != R_NilValue) a.nu_1 = Rf_asReal(h.nu_1);
   a.alpha1l = Rf_asReal(h.alpha1l); a.alpha2l = Rf_asReal(h.alpha2l);
@@ -173,18 +218,34 @@ void set_hyper(bfmmm_entry_args& a, const Hyper& h) {
   a.alpha_0 = Rf_asReal(h.alpha_0); a.beta_0 = Rf_asReal(h.beta_0);
 }
 
-void set_X(bfmmm_entry_args& a, SEXP X, SEXP covariance_adj) {
-  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+void set_X(bfmmm_entry_args& a, SEXP X, SEXP covariance_adj, Inputs& in) {
+  if (X != R_NilValue) {
+    if (Rf_nrows(X) != a.n_funct) throw std::runtime_error("'X' must be have 'n_funct' number of rows");
+    a.X = in.num(X); a.D = Rf_ncols(X);
+  }
   if (covariance_adj != R_NilValue) a.covariance_adj = Rf_asLogical(covariance_adj) ? 1 : 0;
 }
 
+// (n_funct is checked against the lists: the library trusts offsets[n_funct])
+void check_n_funct(const Ragged& Y, const Ragged& tm, int n_funct) {
+  if ((int64_t)Y.off.size() - 1 != n_funct || (int64_t)tm.off.size() - 1 != n_funct)
+    throw std::runtime_error("'Y' and 'time' must be lists of 'n_funct' elements");
+  // one time point (high-dimensional model: one row of `dim` coordinates) per observation
+  const int64_t fac = Y.v.empty() ? 1 : (int64_t)(tm.v.size() / Y.v.size());
+  for (size_t i = 0; i + 1 < Y.off.size(); ++i)
+    if (tm.off[i + 1] - tm.off[i] != fac * (Y.off[i + 1] - Y.off[i]))
+      throw std::runtime_error("every element of 'time' must hold the time points of the matching element of 'Y'");
+}
+
 void set_functional(bfmmm_entry_args& a, const Ragged& Y, const Ragged& tm, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
-                    SEXP boundary_knots, SEXP internal_knots) {
+                    SEXP boundary_knots, SEXP internal_knots, Inputs& in) {
   a.n_funct = Rf_asInteger(n_funct);
+  check_n_funct(Y, tm, a.n_funct);
+  if (Rf_length(boundary_knots) != 2) throw std::runtime_error("'boundary_knots' must have two elements");
   a.y = Y.v.data(); a.t = tm.v.data(); a.offsets = Y.off.data();
   a.basis_degree = Rf_asInteger(basis_degree); a.n_eigen = Rf_asInteger(n_eigen);
   a.n_internal_knots = Rf_length(internal_knots);
-  a.boundary_knots = REAL(boundary_knots); a.internal_knots = REAL(internal_knots);
+  a.boundary_knots = in.num(boundary_knots); a.internal_knots = in.num(internal_knots);
 }
 
 // high-dimensional model: `time` is a list of n_i x dim matrices (flattened as they are: column-major per curve),
@@ -193,24 +254,28 @@ void set_functional(bfmmm_entry_args& a, const Ragged& Y, const Ragged& tm, SEXP
 struct HDArgs { std::vector<int32_t> deg, nint; std::vector<double> bk; Ragged ik; };
 
 void set_hd(bfmmm_entry_args& a, HDArgs& h, const Ragged& Y, const Ragged& tm, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
-            SEXP boundary_knots, SEXP internal_knots) {
+            SEXP boundary_knots, SEXP internal_knots, Inputs&) {
   const int dim = Rf_length(basis_degree);
   a.n_funct = Rf_asInteger(n_funct); a.n_eigen = Rf_asInteger(n_eigen); a.dim = dim;
+  check_n_funct(Y, tm, a.n_funct);
   a.y = Y.v.data(); a.t = tm.v.data(); a.offsets = Y.off.data();
   h.ik = flatten(internal_knots);
+  const Num deg(basis_degree), bk(boundary_knots);
+  if ((int)h.ik.off.size() - 1 != dim || bk.len != 2 * (R_xlen_t)dim) throw std::runtime_error("'basis_degree', 'boundary_knots' (dim x 2) and 'internal_knots' disagree on the dimension");
   for (int j = 0; j < dim; ++j) {
-    h.deg.push_back((int32_t)REAL(basis_degree)[j]);
+    h.deg.push_back((int32_t)deg.p[j]);
     h.nint.push_back((int32_t)(h.ik.off[j + 1] - h.ik.off[j]));
-    h.bk.push_back(REAL(boundary_knots)[j]);
-    h.bk.push_back(REAL(boundary_knots)[j + dim]);
+    h.bk.push_back(bk.p[j]);
+    h.bk.push_back(bk.p[j + dim]);
   }
   a.basis_degree_hd = h.deg.data(); a.n_internal_hd = h.nint.data();
   a.boundary_knots = h.bk.data(); a.internal_knots = h.ik.v.data();
 }
 
-void set_multivariate(bfmmm_entry_args& a, SEXP Y, SEXP n_eigen) {
+void set_multivariate(bfmmm_entry_args& a, SEXP Y, SEXP n_eigen, Inputs& in) {
   a.model = 1;                                           // BFMMM_MODEL_MULTIVARIATE
-  a.y = REAL(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
+  if (!Rf_isMatrix(Y)) throw std::runtime_error("'Y' must be a matrix");
+  a.y = in.num(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
   a.n_eigen = Rf_asInteger(n_eigen);
 }
 
@@ -226,30 +291,28 @@ void set_warm(bfmmm_entry_args& a, SEXP dir, SEXP thinning_num, SEXP beta_N_t, S
 }
 
 SEXP finish(int rc, bfmmm_result* r, const std::vector<int64_t>* offsets, bfmmm_result* p1 = NULL, bfmmm_result* p2 = NULL) {
-  if (p1) bfmmm_result_free(p1);
-  if (p2) bfmmm_result_free(p2);
-  if (rc) Rf_error("%s", bfmmm_entry_last_error());      // (r is NULL on failure)
-  SEXP out = PROTECT(result_to_list(r, offsets));
-  bfmmm_result_free(r);
-  UNPROTECT(1);
-  return out;
+  Owned o1, o2, o3;
+  o1.r = p1; o2.r = p2; o3.r = r;
+  if (rc) lib_error();                                   // (r is NULL on failure)
+  return result_to_list(r, offsets);
 }
 
 SEXP read_plain(SEXP file, bool as_vector) {
-  bfmmm_result* r = NULL;
-  if (bfmmm_arma_read(CHAR(STRING_ELT(file, 0)), &r)) Rf_error("%s", bfmmm_entry_last_error());
+  SHIM_BEGIN
+  Owned o;
+  if (bfmmm_arma_read(CHAR(STRING_ELT(file, 0)), &o.r)) lib_error();
   const double* data; int64_t cnt; const int64_t* dims; int nd;
-  bfmmm_result_get(r, "value", &data, &cnt, &dims, &nd);
+  bfmmm_result_get(o.r, "value", &data, &cnt, &dims, &nd);
   const int64_t one = cnt;
-  SEXP out = PROTECT(as_vector ? array_of(data, &one, 1) : array_of(data, dims, nd));
-  bfmmm_result_free(r);
-  UNPROTECT(1);
-  return out;
+  return as_vector ? array_of(data, &one, 1) : array_of(data, dims, nd);
+  SHIM_END
 }
 
 SEXP read_field(SEXP file, bool as_vectors) {             // arma::field -> list-matrix (n_rows x n_cols)
-  bfmmm_result* r = NULL;
-  if (bfmmm_arma_read_field(CHAR(STRING_ELT(file, 0)), &r)) Rf_error("%s", bfmmm_entry_last_error());
+  SHIM_BEGIN
+  Owned o;
+  bfmmm_result*& r = o.r;
+  if (bfmmm_arma_read_field(CHAR(STRING_ELT(file, 0)), &r)) lib_error();
   const double* fd; int64_t cnt; const int64_t* dims; int nd;
   bfmmm_result_get(r, "field_dims", &fd, &cnt, &dims, &nd);
   const int64_t nr = (int64_t)fd[0], nc = (int64_t)fd[1];
@@ -263,9 +326,9 @@ SEXP read_field(SEXP file, bool as_vectors) {             // arma::field -> list
   SEXP d2 = PROTECT(Rf_allocVector(INTSXP, 2));
   INTEGER(d2)[0] = (int)nr; INTEGER(d2)[1] = (int)nc;
   Rf_setAttrib(out, R_DimSymbol, d2);
-  bfmmm_result_free(r);
   UNPROTECT(2);
   return out;
+  SHIM_END
 }
 
 }  // namespace
@@ -285,197 +348,240 @@ extern "C" {
 // ---- functional model ----------------------------------------------------------------------------------------
 SEXP _BayesFMMM_BFMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
                                         SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP X, H18) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 0);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
-  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, R_NilValue);
-  set_hyper(a, HY18);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, R_NilValue, in);
+  set_hyper(a, HY18, in);
   a.seed = seed_from_R();
   bfmmm_result* r = NULL;
   return finish(bfmmm_BFMMM_Nu_Z_multiple_try(&a, &r), r, &y.off);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
                                 SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP X,
                                 SEXP burnin_prop, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 1);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, covariance_adj);
-  set_hyper(a, HY19);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, covariance_adj, in);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
                                  SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP theta_est, SEXP X,
                                  SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
                                  SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 2);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, covariance_adj);
+  set_functional(a, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, covariance_adj, in);
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
-  set_hyper(a, HY19);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* te = list_to_result(theta_est);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
+  SHIM_END
 }
 
 // ---- multivariate model ----------------------------------------------------------------------------------------
 SEXP _BayesFMMM_BMVMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP n_eigen, SEXP X, H18) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 3);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
-  set_multivariate(a, Y, n_eigen);
-  set_X(a, X, R_NilValue);
-  set_hyper(a, HY18);
+  set_multivariate(a, Y, n_eigen, in);
+  set_X(a, X, R_NilValue, in);
+  set_hyper(a, HY18, in);
   a.seed = seed_from_R();
   bfmmm_result* r = NULL;
   return finish(bfmmm_BMVMMM_Nu_Z_multiple_try(&a, &r), r, NULL);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BMVMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP n_eigen, SEXP multiple_try, SEXP X,
                                  SEXP burnin_prop, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 4);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_multivariate(a, Y, n_eigen);
-  set_X(a, X, covariance_adj);
-  set_hyper(a, HY19);
+  set_multivariate(a, Y, n_eigen, in);
+  set_X(a, X, covariance_adj, in);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BMVMMM_Theta_est(&a, mt, &r), r, NULL, mt);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BMVMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP n_eigen, SEXP multiple_try, SEXP theta_est, SEXP X,
                                   SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
                                   SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_entry_args a;
   bfmmm_entry_defaults(&a, 5);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_multivariate(a, Y, n_eigen);
-  set_X(a, X, covariance_adj);
+  set_multivariate(a, Y, n_eigen, in);
+  set_X(a, X, covariance_adj, in);
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
-  set_hyper(a, HY19);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* te = list_to_result(theta_est);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BMVMMM_warm_start(&a, mt, te, &r), r, NULL, mt, te);
+  SHIM_END
 }
 
 // ---- high-dimensional functional model (RcppExports.cpp:552, :590, :632) -----------------------------------------
 SEXP _BayesFMMM_BHDFMMM_Nu_Z_multiple_try(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
                                           SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP X, H18) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   HDArgs h;
   bfmmm_entry_defaults(&a, 0);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
-  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, R_NilValue);
-  set_hyper(a, HY18);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, R_NilValue, in);
+  set_hyper(a, HY18, in);
   a.seed = seed_from_R();
   bfmmm_result* r = NULL;
   return finish(bfmmm_BHDFMMM_Nu_Z_multiple_try(&a, &r), r, &y.off);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BHDFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree,
                                   SEXP n_eigen, SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP X,
                                   SEXP burnin_prop, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   HDArgs h;
   bfmmm_entry_defaults(&a, 1);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.n_try = Rf_asInteger(n_try); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, covariance_adj);
-  set_hyper(a, HY19);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, covariance_adj, in);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BHDFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_BHDFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP time, SEXP n_funct, SEXP basis_degree, SEXP n_eigen,
                                    SEXP boundary_knots, SEXP internal_knots, SEXP multiple_try, SEXP theta_est, SEXP X,
                                    SEXP burnin_prop, SEXP dir, SEXP thinning_num, SEXP beta_N_t, SEXP N_t, SEXP n_temp_trans,
                                    SEXP r_stored_iters, H19, SEXP covariance_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_entry_args a;
   HDArgs h;
   bfmmm_entry_defaults(&a, 2);
   a.tot_mcmc_iters = Rf_asInteger(tot_mcmc_iters); a.K = Rf_asInteger(K);
   a.burnin_prop = Rf_asReal(burnin_prop);
-  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots);
-  set_X(a, X, covariance_adj);
+  set_hd(a, h, y, t, n_funct, basis_degree, n_eigen, boundary_knots, internal_knots, in);
+  set_X(a, X, covariance_adj, in);
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
-  set_hyper(a, HY19);
+  set_hyper(a, HY19, in);
   a.seed = seed_from_R();
   bfmmm_result* mt = list_to_result(multiple_try);
   bfmmm_result* te = list_to_result(theta_est);
   bfmmm_result* r = NULL;
   return finish(bfmmm_BHDFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
+  SHIM_END
 }
 
 // ---- likelihood-based post-processing (RcppExports.cpp:174, :194, :214, :234) -------------------------------------
 static void set_post(bfmmm_post_args& a, const Ragged& y, const Ragged& t, SEXP dir, SEXP n_files, SEXP basis_degree,
-                     SEXP boundary_knots, SEXP internal_knots, SEXP X, SEXP cov_adj) {
+                     SEXP boundary_knots, SEXP internal_knots, SEXP X, SEXP cov_adj, Inputs& in) {
   bfmmm_post_defaults(&a);
   a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files); a.basis_degree = Rf_asInteger(basis_degree);
-  a.boundary_knots = REAL(boundary_knots); a.internal_knots = REAL(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
+  if (Rf_length(boundary_knots) != 2) throw std::runtime_error("'boundary_knots' must have two elements");
+  a.boundary_knots = in.num(boundary_knots); a.internal_knots = in.num(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
+  if (y.off.size() != t.off.size() || y.v.size() != t.v.size()) throw std::runtime_error("'Y' and 'time' must have the same shape");
   a.n_funct = (int32_t)(y.off.size() - 1); a.t = t.v.data(); a.y = y.v.data(); a.offsets = y.off.data();
-  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+  if (X != R_NilValue) { a.X = in.num(X); a.D = Rf_ncols(X); }      // (the library checks its rows / columns against the saved draws)
   a.cov_adj = Rf_asLogical(cov_adj) ? 1 : 0;
 }
 
 static SEXP post_scalar(int (*fn)(const bfmmm_post_args*, double*), SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots,
                         SEXP internal_knots, SEXP time, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_post_args a;
-  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj, in);
   a.burnin_prop = Rf_asReal(burnin_prop);
   double v = 0.0;
-  if (fn(&a, &v)) Rf_error("%s", bfmmm_entry_last_error());
+  if (fn(&a, &v)) lib_error();
   return Rf_ScalarReal(v);
+  SHIM_END
 }
 
 SEXP _BayesFMMM_FDIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
                      SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   return post_scalar(bfmmm_FDIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+  SHIM_END
 }
 SEXP _BayesFMMM_FAIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
                      SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   return post_scalar(bfmmm_FAIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+  SHIM_END
 }
 SEXP _BayesFMMM_FBIC(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
                      SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   return post_scalar(bfmmm_FBIC, dir, n_files, basis_degree, boundary_knots, internal_knots, time, Y, burnin_prop, X, cov_adj);
+  SHIM_END
 }
 SEXP _BayesFMMM_FLLik(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP Y,
                       SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_post_args a;
-  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj, in);
   bfmmm_result* r = NULL;
-  if (bfmmm_FLLik(&a, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  if (bfmmm_FLLik(&a, &r)) lib_error();
   const double* d; int64_t cnt; const int64_t* dims; int nd;
   bfmmm_result_get(r, "value", &d, &cnt, &dims, &nd);
   SEXP out = PROTECT(Rf_allocVector(REALSXP, cnt));
@@ -483,10 +589,13 @@ SEXP _BayesFMMM_FLLik(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_k
   bfmmm_result_free(r);
   UNPROTECT(1);
   return out;
+  SHIM_END
 }
 
 // ---- CPO, multivariate criteria, credible intervals (RcppExports.cpp:17, :62, :78, :145, :159, :253-316) ---------------
 static SEXP value_vector(bfmmm_result* r) {
+  SHIM_BEGIN
+  Inputs in;
   const double* d; int64_t cnt; const int64_t* dims; int nd;
   bfmmm_result_get(r, "value", &d, &cnt, &dims, &nd);
   SEXP out = PROTECT(Rf_allocVector(REALSXP, cnt));
@@ -494,42 +603,53 @@ static SEXP value_vector(bfmmm_result* r) {
   bfmmm_result_free(r);
   UNPROTECT(1);
   return out;
+  SHIM_END
 }
 
 SEXP _BayesFMMM_ConditionalPredictiveOrdinates(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots,
                                                SEXP time, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj, SEXP log_CPO) {
+  SHIM_BEGIN
+  Inputs in;
   const Ragged y = flatten(Y), t = flatten(time);
   bfmmm_post_args a;
-  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj);
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj, in);
   a.burnin_prop = Rf_asReal(burnin_prop);
   bfmmm_result* r = NULL;
-  if (bfmmm_ConditionalPredictiveOrdinates(&a, Rf_asLogical(log_CPO) ? 1 : 0, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  if (bfmmm_ConditionalPredictiveOrdinates(&a, Rf_asLogical(log_CPO) ? 1 : 0, &r)) lib_error();
   return value_vector(r);
+  SHIM_END
 }
 
-static void set_post_mv(bfmmm_post_args& a, SEXP dir, SEXP n_files, SEXP Y, SEXP X, SEXP cov_adj) {
+static void set_post_mv(bfmmm_post_args& a, SEXP dir, SEXP n_files, SEXP Y, SEXP X, SEXP cov_adj, Inputs& in) {
   bfmmm_post_defaults(&a);
   a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files);
-  a.y = REAL(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
-  if (X != R_NilValue) { a.X = REAL(X); a.D = Rf_ncols(X); }
+  if (!Rf_isMatrix(Y)) throw std::runtime_error("'Y' must be a matrix");
+  a.y = in.num(Y); a.n_funct = Rf_nrows(Y); a.P = Rf_ncols(Y);
+  if (X != R_NilValue) { a.X = in.num(X); a.D = Rf_ncols(X); }
   a.cov_adj = Rf_asLogical(cov_adj) ? 1 : 0;
 }
 
 SEXP _BayesFMMM_MVLLik(SEXP dir, SEXP n_files, SEXP Y, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_post_args a;
-  set_post_mv(a, dir, n_files, Y, X, cov_adj);
+  set_post_mv(a, dir, n_files, Y, X, cov_adj, in);
   bfmmm_result* r = NULL;
-  if (bfmmm_MVLLik(&a, &r)) Rf_error("%s", bfmmm_entry_last_error());
+  if (bfmmm_MVLLik(&a, &r)) lib_error();
   return value_vector(r);
+  SHIM_END
 }
 
 static SEXP mv_scalar(int (*fn)(const bfmmm_post_args*, double*), SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_post_args a;
-  set_post_mv(a, dir, n_files, Y, X, cov_adj);
+  set_post_mv(a, dir, n_files, Y, X, cov_adj, in);
   a.burnin_prop = Rf_asReal(burnin_prop);
   double v = 0.0;
-  if (fn(&a, &v)) Rf_error("%s", bfmmm_entry_last_error());
+  if (fn(&a, &v)) lib_error();
   return Rf_ScalarReal(v);
+  SHIM_END
 }
 SEXP _BayesFMMM_MVDIC(SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) { return mv_scalar(bfmmm_MVDIC, dir, n_files, Y, burnin_prop, X, cov_adj); }
 SEXP _BayesFMMM_MVAIC(SEXP dir, SEXP n_files, SEXP Y, SEXP burnin_prop, SEXP X, SEXP cov_adj) { return mv_scalar(bfmmm_MVAIC, dir, n_files, Y, burnin_prop, X, cov_adj); }
@@ -539,77 +659,173 @@ static void set_ci(bfmmm_ci_args& a, SEXP dir, SEXP n_files, SEXP alpha, SEXP bu
   bfmmm_ci_defaults(&a);
   a.dir = CHAR(STRING_ELT(dir, 0)); a.n_files = Rf_asInteger(n_files); a.alpha = Rf_asReal(alpha); a.burnin_prop = Rf_asReal(burnin_prop);
 }
+static void set_ci_x(bfmmm_ci_args& a, SEXP X, Inputs& in) {
+  if (X != R_NilValue) { a.X = in.num(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+}
 static void set_ci_basis(bfmmm_ci_args& a, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP rescale, SEXP simultaneous,
-                         SEXP X, SEXP trans_mats) {
-  a.basis_degree = Rf_asInteger(basis_degree); a.boundary_knots = REAL(boundary_knots);
-  a.internal_knots = REAL(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
+                         SEXP X, SEXP trans_mats, Inputs& in) {
+  if (Rf_length(boundary_knots) != 2) throw std::runtime_error("'boundary_knots' must have two elements");
+  a.basis_degree = Rf_asInteger(basis_degree); a.boundary_knots = in.num(boundary_knots);
+  a.internal_knots = in.num(internal_knots); a.n_internal_knots = Rf_length(internal_knots);
   a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
-  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
-  if (trans_mats != R_NilValue) a.trans_mats = REAL(trans_mats);
+  set_ci_x(a, X, in);
+  if (trans_mats != R_NilValue) a.trans_mats = in.num(trans_mats);
+}
+// tensor-product basis arguments of the HD functions: basis_degree a vector, boundary_knots dim x 2, internal_knots a list
+struct HDCi { std::vector<int32_t> deg, nint; std::vector<double> bk; Ragged ik; };
+static void set_ci_hd(bfmmm_ci_args& a, HDCi& h, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots) {
+  const int dim = Rf_length(basis_degree);
+  h.ik = flatten(internal_knots);
+  const Num deg(basis_degree), bk(boundary_knots);
+  if ((int)h.ik.off.size() - 1 != dim || bk.len != 2 * (R_xlen_t)dim) throw std::runtime_error("'basis_degree', 'boundary_knots' (dim x 2) and 'internal_knots' disagree on the dimension");
+  for (int j = 0; j < dim; ++j) {
+    h.deg.push_back((int32_t)deg.p[j]);
+    h.nint.push_back((int32_t)(h.ik.off[j + 1] - h.ik.off[j]));
+    h.bk.push_back(bk.p[j]); h.bk.push_back(bk.p[j + dim]);
+  }
+  a.dim = dim; a.basis_degree_hd = h.deg.data(); a.n_internal_hd = h.nint.data();
+  a.boundary_knots = h.bk.data(); a.internal_knots = h.ik.v.data();
 }
 
 SEXP _BayesFMMM_SigmaCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP burnin_prop) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
   bfmmm_result* r = NULL;
   return finish(bfmmm_SigmaCI(&a, &r), r, NULL);
+  SHIM_END
 }
 SEXP _BayesFMMM_ZCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP burnin_prop) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
   a.rescale = Rf_asLogical(rescale) ? 1 : 0;
   bfmmm_result* r = NULL;
   return finish(bfmmm_ZCI(&a, &r), r, NULL);
+  SHIM_END
 }
 SEXP _BayesFMMM_FMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP k, SEXP alpha,
                         SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
-  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats);
-  a.time = REAL(time); a.n_time = Rf_length(time); a.k = Rf_asInteger(k);
+  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats, in);
+  a.time = in.num(time); a.n_time = Rf_length(time); a.k = Rf_asInteger(k);
   bfmmm_result* r = NULL;
   return finish(bfmmm_FMeanCI(&a, &r), r, NULL);
+  SHIM_END
 }
 SEXP _BayesFMMM_FCovCI(SEXP dir, SEXP n_files, SEXP time1, SEXP time2, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP l,
                        SEXP m, SEXP alpha, SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X, SEXP trans_mats) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
-  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats);
-  a.time = REAL(time1); a.n_time = Rf_length(time1); a.time2 = REAL(time2); a.n_time2 = Rf_length(time2);
+  set_ci_basis(a, basis_degree, boundary_knots, internal_knots, rescale, simultaneous, X, trans_mats, in);
+  a.time = in.num(time1); a.n_time = Rf_length(time1); a.time2 = in.num(time2); a.n_time2 = Rf_length(time2);
   a.l = Rf_asInteger(l); a.m = Rf_asInteger(m);
   bfmmm_result* r = NULL;
-  return finish(bfmmm_FCovCI(&a, &r), r, NULL);      // (with X the library reports that the covariate form is not built)
+  return finish(bfmmm_FCovCI(&a, &r), r, NULL);      // (with X: cov_trace is one n1 x n2 x kept x n_x array, see bfmmm_post.h)
+  SHIM_END
 }
 SEXP _BayesFMMM_MVMeanCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP burnin_prop, SEXP X) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
   a.rescale = Rf_asLogical(rescale) ? 1 : 0;
-  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+  set_ci_x(a, X, in);
   bfmmm_result* r = NULL;
   return finish(bfmmm_MVMeanCI(&a, &r), r, NULL);    // (with X: mean_trace is one K x P x (kept n_x) cube, see bfmmm_post.h)
+  SHIM_END
 }
 
 // HDFMeanCI (RcppExports.cpp:40, 12 arguments -- no trans_mats): time n_time x dim matrix, basis_degree a vector, boundary_knots dim x 2, internal_knots a list
 SEXP _BayesFMMM_HDFMeanCI(SEXP dir, SEXP n_files, SEXP time, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP k, SEXP alpha,
                           SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X) {
+  SHIM_BEGIN
+  Inputs in;
   bfmmm_ci_args a;
   set_ci(a, dir, n_files, alpha, burnin_prop);
-  const int dim = Rf_length(basis_degree);
-  std::vector<int32_t> deg, nint;
-  std::vector<double> bk;
-  const Ragged ik = flatten(internal_knots);
-  for (int j = 0; j < dim; ++j) {
-    deg.push_back((int32_t)REAL(basis_degree)[j]);
-    nint.push_back((int32_t)(ik.off[j + 1] - ik.off[j]));
-    bk.push_back(REAL(boundary_knots)[j]); bk.push_back(REAL(boundary_knots)[j + dim]);
-  }
-  a.dim = dim; a.basis_degree_hd = deg.data(); a.n_internal_hd = nint.data();
-  a.boundary_knots = bk.data(); a.internal_knots = ik.v.data();
-  a.time = REAL(time); a.n_time = Rf_nrows(time); a.k = Rf_asInteger(k);
+  HDCi h;
+  set_ci_hd(a, h, basis_degree, boundary_knots, internal_knots);
+  if (!Rf_isMatrix(time) || Rf_ncols(time) != a.dim) throw std::runtime_error("'time' must be a matrix with one column per dimension");
+  a.time = in.num(time); a.n_time = Rf_nrows(time); a.k = Rf_asInteger(k);
   a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
-  if (X != R_NilValue) { a.X = REAL(X); a.n_x = Rf_nrows(X); a.D = Rf_ncols(X); }
+  set_ci_x(a, X, in);
   bfmmm_result* r = NULL;
   return finish(bfmmm_HDFMeanCI(&a, &r), r, NULL);
+  SHIM_END
+}
+
+// HDFCovCI (RcppExports.cpp:103, 14 arguments), MVCovCI (:127, 8), FSamplePaths (:337, 11)
+SEXP _BayesFMMM_HDFCovCI(SEXP dir, SEXP n_files, SEXP time1, SEXP time2, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP l,
+                         SEXP m, SEXP alpha, SEXP rescale, SEXP simultaneous, SEXP burnin_prop, SEXP X) {
+  SHIM_BEGIN
+  Inputs in;
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  HDCi h;
+  set_ci_hd(a, h, basis_degree, boundary_knots, internal_knots);
+  if (!Rf_isMatrix(time1) || !Rf_isMatrix(time2) || Rf_ncols(time1) != a.dim || Rf_ncols(time2) != a.dim)
+    throw std::runtime_error("'time1' and 'time2' must be matrices with one column per dimension");
+  a.time = in.num(time1); a.n_time = Rf_nrows(time1); a.time2 = in.num(time2); a.n_time2 = Rf_nrows(time2);
+  a.l = Rf_asInteger(l); a.m = Rf_asInteger(m);
+  a.rescale = Rf_asLogical(rescale) ? 1 : 0; a.simultaneous = Rf_asLogical(simultaneous) ? 1 : 0;
+  set_ci_x(a, X, in);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_HDFCovCI(&a, &r), r, NULL);
+  SHIM_END
+}
+SEXP _BayesFMMM_MVCovCI(SEXP dir, SEXP n_files, SEXP l, SEXP m, SEXP alpha, SEXP rescale, SEXP burnin_prop, SEXP X) {
+  SHIM_BEGIN
+  Inputs in;
+  bfmmm_ci_args a;
+  set_ci(a, dir, n_files, alpha, burnin_prop);
+  a.l = Rf_asInteger(l); a.m = Rf_asInteger(m); a.rescale = Rf_asLogical(rescale) ? 1 : 0;
+  set_ci_x(a, X, in);
+  bfmmm_result* r = NULL;
+  return finish(bfmmm_MVCovCI(&a, &r), r, NULL);
+  SHIM_END
+}
+// the reference returns lists over the curves (arma::field): CI_* vectors of n_i, the traces kept x n_i matrices
+SEXP _BayesFMMM_FSamplePaths(SEXP dir, SEXP n_files, SEXP basis_degree, SEXP boundary_knots, SEXP internal_knots, SEXP time, SEXP alpha,
+                             SEXP burnin_prop, SEXP simultaneous, SEXP X, SEXP cov_adj) {
+  SHIM_BEGIN
+  Inputs in;
+  const Ragged t = flatten(time);
+  Ragged y = t;                                          // FSamplePaths has no Y: only the shape is needed
+  bfmmm_post_args a;
+  set_post(a, y, t, dir, n_files, basis_degree, boundary_knots, internal_knots, X, cov_adj, in);
+  a.y = NULL;
+  a.burnin_prop = Rf_asReal(burnin_prop);
+  Owned o;
+  if (bfmmm_FSamplePaths(&a, Rf_asReal(alpha), Rf_asLogical(simultaneous) ? 1 : 0, seed_from_R(), &o.r)) lib_error();
+  const char* names[5] = {"CI_Upper", "CI_50", "CI_Lower", "Path_trace", "Mean_only_Path_trace"};
+  const int64_t nf = (int64_t)t.off.size() - 1;
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 5));
+  for (int e = 0; e < 5; ++e) {
+    const double* data; int64_t cnt; const int64_t* dims; int nd;
+    bfmmm_result_get(o.r, names[e], &data, &cnt, &dims, &nd);
+    const int64_t kept = (e < 3) ? 1 : dims[0];
+    SEXP lst = PROTECT(Rf_allocVector(VECSXP, nf));
+    for (int64_t c = 0; c < nf; ++c) {
+      const int64_t ni = t.off[c + 1] - t.off[c];
+      const int64_t d2[2] = {kept, ni};
+      SET_VECTOR_ELT(lst, c, (e < 3) ? array_of(data + t.off[c], &ni, 1) : array_of(data + kept * t.off[c], d2, 2));
+    }
+    SET_VECTOR_ELT(out, e, lst);
+    SET_STRING_ELT(nms, e, Rf_mkChar(names[e]));
+    UNPROTECT(1);
+  }
+  Rf_setAttrib(out, R_NamesSymbol, nms);
+  UNPROTECT(2);
+  return out;
+  SHIM_END
 }
 
 // ---- readers of the on-disk batches (UserFunctions.cpp:2158-2399) -------------------------------------------------
@@ -645,6 +861,9 @@ static const R_CallMethodDef CallEntries[] = {            // as src/RcppExports.
     {"_BayesFMMM_FCovCI", (DL_FUNC)&_BayesFMMM_FCovCI, 15},
     {"_BayesFMMM_MVMeanCI", (DL_FUNC)&_BayesFMMM_MVMeanCI, 6},
     {"_BayesFMMM_HDFMeanCI", (DL_FUNC)&_BayesFMMM_HDFMeanCI, 12},
+    {"_BayesFMMM_HDFCovCI", (DL_FUNC)&_BayesFMMM_HDFCovCI, 14},
+    {"_BayesFMMM_MVCovCI", (DL_FUNC)&_BayesFMMM_MVCovCI, 8},
+    {"_BayesFMMM_FSamplePaths", (DL_FUNC)&_BayesFMMM_FSamplePaths, 11},
     {"_BayesFMMM_ReadVec", (DL_FUNC)&_BayesFMMM_ReadVec, 1},
     {"_BayesFMMM_ReadMat", (DL_FUNC)&_BayesFMMM_ReadMat, 1},
     {"_BayesFMMM_ReadCube", (DL_FUNC)&_BayesFMMM_ReadCube, 1},
