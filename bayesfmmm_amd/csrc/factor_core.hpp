@@ -239,8 +239,8 @@ __device__ __forceinline__ bool factor_core(double* S, double* X, const double* 
 // Pseudo-inverse route for a precision that is singular to working accuracy (factor_core returned true).  The reference
 // takes arma::pinv for nu and eta (UpdateNu.h:67-68, UpdateEta.h:85-86): a cluster without members leaves Prec = tau P_mat
 // of rank P - 1, pinv drops the null direction and arma::mvnrnd -- its Cholesky factorisation of the singular covariance
-// failing -- draws through the symmetric eigen-decomposition.  Same law here, by the specification shared with the
-// oracle (oracle/linalg.c): Prec = V diag(w) V' by Jacobi rotations, eigenpairs by ascending w, eigenvectors signed by
+// failing -- draws through the symmetric eigen-decomposition.  Same law here, by a fixed specification (the tests' CPU
+// restatement implements the same one): Prec = V diag(w) V' by Jacobi rotations, eigenpairs by ascending w, eigenvectors signed by
 // the generic-weights rule, winv_k = 1 / w_k above Armadillo's tolerance P max|w| eps and 0 below,
 //     C = V diag(winv) V',     L = V diag(sqrt(winv)),     L z with z in index order.
 // S: the full symmetric PP x PP precision (zero beyond P), X: PP x PP scratch (V), wk: 4 PP + 2 doubles of scratch.

@@ -99,7 +99,7 @@ typedef struct {
   void* progress_user;
   /* multi-GPU multi-try: with n_devices > 0 the chains of this call are dealt round-robin over devices[0 .. n_devices)
    * (one host thread and one sampler batch per device) and the best chain is selected by the RCCL gather of
-   * bfmmm_gather_best (bfmmm.h): an all-gather of one score per device, then the winner's chain is sent over xGMI to
+   * bfmmm_gather_best of bfmmm.h: an all-gather of one score per device, then the winner's chain is sent over xGMI to
    * devices[0].  n_devices == 0: everything runs on `device`, no communicator is created. */
   const int32_t* devices;
   int32_t n_devices;
