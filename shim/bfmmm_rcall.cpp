@@ -173,6 +173,10 @@ SEXP result_to_list(const bfmmm_result* r, const std::vector<int64_t>* offsets) 
         SET_VECTOR_ELT(el, c, m);
         UNPROTECT(1);
       }
+    } else if (s == "cov_trace" && nd == 4) {            // FCovCI / HDFCovCI / MVCovCI with X: the reference's list of n_x cubes
+      const int64_t W = dims[3], len = cnt / W;
+      el = PROTECT(Rf_allocVector(VECSXP, W));
+      for (int64_t w = 0; w < W; ++w) SET_VECTOR_ELT(el, w, array_of(data + w * len, dims, 3));
     } else if (is_slot_list(s)) {
       const int64_t T = dims[nd - 1], len = cnt / T;
       el = PROTECT(Rf_allocVector(VECSXP, T));
@@ -739,7 +743,23 @@ SEXP _BayesFMMM_MVMeanCI(SEXP dir, SEXP n_files, SEXP alpha, SEXP rescale, SEXP 
   a.rescale = Rf_asLogical(rescale) ? 1 : 0;
   set_ci_x(a, X, in);
   bfmmm_result* r = NULL;
-  return finish(bfmmm_MVMeanCI(&a, &r), r, NULL);    // (with X: mean_trace is one K x P x (kept n_x) cube, see bfmmm_post.h)
+  SEXP out = PROTECT(finish(bfmmm_MVMeanCI(&a, &r), r, NULL));
+  if (X != R_NilValue) {                                 // mean_trace: K x P x (kept n_x) -> the reference's list of n_x cubes K x P x kept
+    SEXP nm = Rf_getAttrib(out, R_NamesSymbol);
+    for (R_xlen_t e = 0; e < Rf_xlength(out); ++e)
+      if (std::strcmp(CHAR(STRING_ELT(nm, e)), "mean_trace") == 0) {
+        SEXP mt = VECTOR_ELT(out, e);
+        const int* d = INTEGER(Rf_getAttrib(mt, R_DimSymbol));
+        const int64_t nx = a.n_x, kept = d[2] / nx, len = (int64_t)d[0] * d[1] * kept;
+        const int64_t d3[3] = {d[0], d[1], kept};
+        SEXP lst = PROTECT(Rf_allocVector(VECSXP, nx));
+        for (int64_t w = 0; w < nx; ++w) SET_VECTOR_ELT(lst, w, array_of(REAL(mt) + w * len, d3, 3));
+        SET_VECTOR_ELT(out, e, lst);
+        UNPROTECT(1);
+      }
+  }
+  UNPROTECT(1);
+  return out;
   SHIM_END
 }
 

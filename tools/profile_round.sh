@@ -1,18 +1,23 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   1. --kernel-trace --stats of the default bench command (graph replay, no per-kernel event pass)
+#   1. --kernel-trace --stats of the default bench command (graph replay, single-chain headline only)
 #   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on a short run, as MI355X_MICROARCH.md prescribes
+#   3. one --pmc pass with the matrix-core counters (MFMA instruction / busy cycles) for k_pair_gram / k_factor
+#   4. --kernel-trace --stats of the 8-chain batches (warm start and Nu_Z: BASELINE configs[4]) and of configs[2], [3]
 # Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profile.py condenses them into profiles/.
-set -euo pipefail
-TAG=${1:-r01}
+set -uo pipefail
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_trace.log" 2>&1
-echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_fetch.log" 2>&1
-echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-extras --profile-steps 0 > "$OUT/bench_write.log" 2>&1
-echo "write done"
-find "$OUT" -name "*.csv" | head -20
+B="--no-cpu-baseline --no-extras --profile-steps 0"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" $B > "$OUT/bench_trace.log" 2>&1 && echo "trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_fetch.log" 2>&1 && echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_write.log" 2>&1 && echo "write done"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace -d "$OUT/pmc_mfma" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_mfma.log" 2>&1 && echo "mfma done" || { echo "mfma pass failed:"; tail -5 "$OUT/bench_mfma.log"; }
+for spec in warm:8 nu_z:1 nu_z:8 config3:1 config4:1; do
+  wl=${spec%%:*}; ch=${spec##*:}
+  rocprofv3 --kernel-trace --stats -d "$OUT/${wl}_${ch}" -o run -- python3 "$ROOT/tools/prof_workload.py" --workload "$wl" --chains "$ch" --steps 300 > "$OUT/${wl}_${ch}.json" 2> "$OUT/${wl}_${ch}.err" && echo "$spec done: $(cat "$OUT/${wl}_${ch}.json")"
+done
+find "$OUT" -name "*.db" | head -20

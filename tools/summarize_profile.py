@@ -63,6 +63,35 @@ def main():
                           hbm_read_bytes_per_launch=None if f_kb is None else 2.0 * f_kb * 1024.0,
                           hbm_write_bytes_per_launch=None if w_kb is None else w_kb * 1024.0)
     json.dump(summary, open(dst / f"{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    # matrix-core counters (third pass): per launch, and the share of the kernel's busy cycles the MFMA pipe was busy
+    pm = src / "pmc_mfma" / "run_results.db"
+    if pm.exists():
+        names = ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"]
+        per = {nm: pmc_per_launch(pm, nm) for nm in names}
+        mf = {}
+        for k in ks:
+            if not k.startswith("k_"):
+                continue
+            row = {nm: per[nm].get(k) for nm in names}
+            if all(v is None for v in row.values()):
+                continue
+            busy, mbusy = row.get("SQ_BUSY_CYCLES"), row.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+            # (256 CUs x 4): the share of SIMD-cycles during which a matrix-core instruction was executing
+            row["mfma_pipe_busy_frac"] = (mbusy / (busy / 32.0 * 1024.0)) if busy and mbusy is not None else None
+            row["avg_us"] = ks[k]["avg_ns"] / 1e3
+            mf[k] = row
+        json.dump(mf, open(dst / f"{tag}_mfma_pmc.json", "w"), indent=1, sort_keys=True)
+        for k, v in mf.items():
+            print("mfma", k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+    # the other workloads of the round: per-kernel statistics
+    for sub in sorted(p for p in src.iterdir() if p.is_dir() and (p / "run_results.db").exists() and p.name not in ("trace", "pmc_fetch", "pmc_write", "pmc_mfma")):
+        ks2 = kernel_stats(sub / "run_results.db")
+        tot2 = sum(o["total_ns"] for o in ks2.values())
+        with open(dst / f"{tag.replace('_final', '')}_{sub.name}_kernel_stats.csv", "w") as f:
+            f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
+            for k, o in sorted(ks2.items(), key=lambda kv: -kv[1]["total_ns"]):
+                f.write(f"{k},{o['calls']},{o['total_ns']},{o['avg_ns']:.1f},{o['min_ns']},{o['max_ns']},{100.0 * o['total_ns'] / tot2:.2f}\n")
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"])[:12]:
         print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
 
