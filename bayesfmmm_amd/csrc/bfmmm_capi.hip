@@ -323,7 +323,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   areq(ar, &c.tvec, (size_t)d.A * P); areq(ar, &c.rvec, (size_t)d.A * P); areq(ar, &c.hq, (size_t)d.A * P);
   areq(ar, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8); areq(ar, &c.zprep, (size_t)(3 * K + 5) * n);
   areq(ar, &c.chi_norm, (size_t)n * M); areq(ar, &c.piprep, 9 * KMAX + 16); areq(ar, &c.Lz, (size_t)d.A * P);
-  areq(ar, &c.Cmat, (size_t)d.A * P * P); areq(ar, &c.Lmat, (size_t)d.A * P * P);
+  areq(ar, &c.Cmat, (size_t)d.A * P * P);
   {
     const size_t T = (size_t)h->T;
     areq(ar, &c.c_nu, T * K * P); areq(ar, &c.c_chi, T * n * M); areq(ar, &c.c_Z, T * n * K); areq(ar, &c.c_pi, T * K);
@@ -1050,7 +1050,7 @@ extern "C" int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, i
   }
   struct Arr { const char* nm; const double* p; int64_t len; };
   const Arr arrs[] = {{"rec", c.rec, (int64_t)d.n * d.LREC}, {"H", c.H, (int64_t)d.R * d.LG}, {"tvec", c.tvec, (int64_t)d.A * d.P},
-                      {"Cmat", c.Cmat, (int64_t)d.A * d.P * d.P}, {"Lmat", c.Lmat, (int64_t)d.A * d.P * d.P},
+                      {"Cmat", c.Cmat, (int64_t)d.A * d.P * d.P},
                       {"theta", c.theta, (int64_t)d.K * (d.M + 1) * d.P}};
   for (const Arr& a : arrs)
     if (s == a.nm) {

@@ -319,29 +319,30 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
   }
 }
 
-// one thread per element of every output tile; fixed summation order over the k-slices
-// (four interleaved partial sums, combined in a fixed order)
+// four lanes per element of every output tile (lane g sums the k-slices g, g + 4, ..: the same four interleaved partial sums
+// as ever, combined in the same fixed order), so that the 25 dependent-latency loads of an element shrink to 7
 __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 2);
   const Dims& d = c.d;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= d.NT * 256) return;
-  const int t = gid >> 8, q = gid & 255;
+  const int gid4 = blockIdx.x * 256 + threadIdx.x;
+  const int gid = gid4 >> 2, g = gid4 & 3;
+  const bool live = gid < d.NT * 256;
+  const int gc = live ? gid : 0;
+  const int t = gc >> 8, q = gc & 255;
   const int r = q >> 6, lane = q & 63;
   const int rit = (lane >> 4) + 4 * r, cit = lane & 15;   // D layout of v_mfma_f64_16x16x4_f64
   const double* src = c.pg_part + (size_t)t * 256 + q;
   const size_t stride = (size_t)d.NT * 256;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int ks = 0;
-  for (; ks + 4 <= NKS; ks += 4) {
-    s0 += src[(size_t)(ks + 0) * stride];
-    s1 += src[(size_t)(ks + 1) * stride];
-    s2 += src[(size_t)(ks + 2) * stride];
-    s3 += src[(size_t)(ks + 3) * stride];
-  }
-  for (; ks < NKS; ++ks) s0 += src[(size_t)ks * stride];
-  const double s = (s0 + s1) + (s2 + s3);
+  double sg = 0.0;
+  const int nfull = NKS & ~3;                             // slices 0 .. nfull-1 go to the four interleaved sums
+  for (int ks = g; ks < nfull; ks += 4) sg += src[(size_t)ks * stride];
+  if (g == 0)
+    for (int ks = nfull; ks < NKS; ++ks) sg += src[(size_t)ks * stride];
+  // (s0 + s1) + (s2 + s3), s_g on lane g of the quad
+  const double s01 = sg + __shfl_xor(sg, 1, 4);
+  const double s = s01 + __shfl_xor(s01, 2, 4);
+  if (!live || g != 0) return;
   const int n_pair_tiles = d.RT * d.CTG;
   if (t < n_pair_tiles) {
     const int rt = t / d.CTG, ct = t - rt * d.CTG;
@@ -580,12 +581,13 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c0) {
   build_prec(false);
   FST(5);
   double* wkp = dsc + 16;             // 4 PP + 2 doubles: scratch of the pseudo-inverse route
-  if (factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P, c.Lz + (size_t)a * P, tid,
-                      nullptr)) {
+  // (the factor L itself is not stored: the sweep needs only C_a and L_a z_a, and the store sat at the end of this kernel's
+  //  critical path)
+  if (factor_core<PP>(S, X, zv, P, d.BWP, c.Cmat + (size_t)a * P * P, nullptr, c.Lz + (size_t)a * P, tid, nullptr)) {
     // singular to working accuracy (e.g. a cluster without members: Prec = tau P_mat): arma::pinv + the eigen route of
     // arma::mvnrnd in the reference (UpdateNu.h:67-69), factor_pinv here
     build_prec(true);
-    factor_pinv<PP>(S, X, zv, P, c.Cmat + (size_t)a * P * P, c.Lmat + (size_t)a * P * P, c.Lz + (size_t)a * P, tid, wkp);
+    factor_pinv<PP>(S, X, zv, P, c.Cmat + (size_t)a * P * P, nullptr, c.Lz + (size_t)a * P, tid, wkp);
   }
   FST(6);
 }
@@ -1333,7 +1335,7 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   if (c.nch > 1) hipLaunchKernelGGL(k_pair_gram<true>, dim3(c.d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
   else hipLaunchKernelGGL(k_pair_gram<false>, dim3(c.d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
   if (!do_pg) return;
-  const int nthreads = c.d.NT * 256;
+  const int nthreads = c.d.NT * 256 * 4;        // four lanes per element
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
 }
 

@@ -116,7 +116,6 @@ struct Ctx {
   double* chi_norm;             // n x M  standard normals of this iteration's chi update (z_proposal.hpp)
   double* piprep;               // tables of the next iteration's pi / alpha_3 job (scalar_jobs.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
-  double* Lmat;                 // A x P x P        its lower Cholesky factor
   const double* Pmat;           // P x P penalty
   // ---- covariate adjustment (D > 0): eta_j[:,d] is direction (j, 0, d), xi_jm[:,d] is (j, m+1, d), weight
   //      w = Z_ij * chit_{i,mt} * X_id.  The Phi / nu block sees them as a per-curve offset o_i; they are
@@ -163,7 +162,7 @@ struct Ctx {
 // per-chain pointers of Ctx (everything but the shared data rec, ni, Pmat, X)
 #define BFMMM_CHAIN_PTRS(X_)                                                                                         \
   X_(dyn) X_(Z) X_(chi) X_(theta) X_(delta) X_(Aa) X_(gamma) X_(logz_part) X_(rss_part) X_(pg_part) X_(H) X_(H2)       \
-  X_(tvec) X_(rvec) X_(hq) X_(Lz) X_(gstd) X_(zprep) X_(chi_norm) X_(piprep) X_(Cmat) X_(Lmat)                        \
+  X_(tvec) X_(rvec) X_(hq) X_(Lz) X_(gstd) X_(zprep) X_(chi_norm) X_(piprep) X_(Cmat)                        \
   X_(c_nu) X_(c_chi) X_(c_Z) X_(c_pi) X_(c_alpha3) X_(c_delta) X_(c_A) X_(c_sigma) X_(c_tau) X_(c_gamma) X_(c_Phi) X_(c_loglik)
 #define BFMMM_CHAIN_PTRS_COV(X_)                                                                                     \
   X_(thetaX) X_(tau_eta) X_(gamma_xi) X_(delta_xi) X_(A_xi) X_(stil) X_(yyp_part) X_(cfull) X_(gfull) X_(w2_part)      \
