@@ -76,6 +76,7 @@ struct bfmmm_handle {
   // raw inputs kept on the device for bfmmm_get_basis
   double* d_t = nullptr; double* d_y = nullptr; int64_t* d_off = nullptr; double* d_knots = nullptr; int n_knots = 0;
   std::vector<void*> allocs;
+  uint32_t* status_host = nullptr;     // pinned: the chains' status words after a run (one asynchronous copy, no extra round trip)
   size_t pg_part_doubles = 0;
   // graph cache for the last (mask, md, seed, chain)
   hipGraphExec_t gexec = nullptr;      // one iteration
@@ -473,6 +474,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL, h->gexecR, h->gexecFR})
     if (g) (void)hipGraphExecDestroy(g);
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->status_host) (void)hipHostFree(h->status_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->evA) (void)hipEventDestroy(h->evA);
@@ -716,6 +718,18 @@ extern "C" int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint3
   return 0;
 }
 
+// The per-run fields of every chain's Dyn, set on the stream (no host round trip before a run).
+__global__ void k_run_begin(Ctx c0, uint32_t first_iter, uint32_t slot_base, uint32_t tt_step, double beta, int state_dirty) {
+  if (threadIdx.x != 0) return;
+  Dyn* dyn = chain_ctx(c0, blockIdx.x).dyn;
+  dyn->iter = first_iter; dyn->slot = first_iter - slot_base; dyn->slot_base = slot_base; dyn->tt_step = tt_step;
+  dyn->beta = beta; dyn->status = 0;
+  dyn->pend_dir = -1;
+  dyn->ll_pending = 0;
+  if (state_dirty) { dyn->zprep_valid = 0; dyn->piprep_valid = 0; }
+  dyn->znorm_valid = 0;
+}
+
 // ---- iteration driver -------------------------------------------------------------------------
 struct Plan {
   bool z, pg, factor, chi;
@@ -781,17 +795,10 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   c.defer_loglik = (c.d.D == 0) ? 1 : 0;
   c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
-  Dyn dyn;
   if (!prepare_only) {
-    for (int q = 0; q < h->nch; ++q) {          // every chain of the batch starts the run at the same iteration
-      if (dyn_get(h, dyn, q)) return 1;
-      dyn.iter = (uint32_t)first_iter; dyn.slot = (uint32_t)(first_iter - h->slot_base); dyn.slot_base = (uint32_t)h->slot_base; dyn.tt_step = tt_step; dyn.beta = beta; dyn.status = 0;
-      dyn.pend_dir = -1;
-      dyn.ll_pending = 0;
-      if (h->state_dirty) { dyn.zprep_valid = 0; dyn.piprep_valid = 0; }
-      dyn.znorm_valid = 0;
-      if (dyn_put(h, dyn, q)) return 1;
-    }
+    // every chain of the batch starts the run at the same iteration
+    hipLaunchKernelGGL(k_run_begin, dim3(h->nch), dim3(64), 0, h->st, h->c, (uint32_t)first_iter, (uint32_t)h->slot_base, tt_step, beta,
+                       h->state_dirty ? 1 : 0);
     h->state_dirty = false;
     for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
     HIPCHK(hipEventRecord(h->ev0, h->st));
@@ -870,6 +877,10 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if (!(mask & U_Z)) launch_fill_slots(c, c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   if (!plan.chi_update) launch_fill_slots(c, c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
+  if (!h->status_host) HIPCHK(hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * (size_t)h->nch, hipHostMallocDefault));
+  // the chains' status words: one strided copy queued behind the run
+  HIPCHK(hipMemcpy2DAsync(h->status_host, sizeof(uint32_t), &h->c.dyn->status, h->nch > 1 ? h->c.chain_bytes : sizeof(uint32_t), sizeof(uint32_t),
+                          (size_t)h->nch, hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS (5 A P doubles + A^2 ints must fit 160 KB)"); }
   HIPCHK(hipGetLastError());
@@ -878,11 +889,10 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->fam_ms[FAM_TOTAL] = ms;
   h->fam_launches[FAM_TOTAL] = n_iters;
   for (int q = 0; q < h->nch; ++q) {
-    if (dyn_get(h, dyn, q)) return 1;
-    if (dyn.status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
-    if (dyn.status & 1u)
-      return fail("a conditional precision matrix was not positive definite (the reference would take the pinv / "
-                  "eigen-decomposition fallback here; not supported on the device)");
+    const uint32_t status = h->status_host[q];
+    if (status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
+    if (status & 1u)
+      return fail("bfmmm_run: a conditional precision matrix was not positive definite");
   }
   return 0;
 }

@@ -401,8 +401,8 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi);
 //   give both the reference's covariance C and its Cholesky factor L; no dense inverse is formed
 //   by elimination.  The direction's normal variates z and L z are produced here as well, so the
 //   sequential sweep only has to apply C.
-// A non-positive pivot sets dyn->status bit 0 (the reference would take arma::pinv / the
-// eigen-decomposition fallback of mvnrnd there).
+// A pivot below 1e-12 of the largest diagonal entry sends the direction down the reference's arma::pinv / eigen-decomposition
+// route instead (factor_pinv, factor_core.hpp).
 // ---------------------------------------------------------------------------------------------
 template <int PP, int BW>
 __global__ __launch_bounds__(256) void k_factor(Ctx c0) {

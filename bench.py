@@ -136,7 +136,7 @@ def pmc_summary():
 
 
 KERNELS_OF = {"sweep": ["k_sweep_fast", "k_sweep", "k_sweep_diag"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
-              "pair_gram": ["k_pair_gram", "k_pg_reduce"], "factor": ["k_factor"]}
+              "pair_gram": ["k_pair_gram"], "factor": ["k_factor"]}
 
 
 def measured_bytes(pm, fam):
