@@ -63,9 +63,12 @@ void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP
 constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
                                   // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
 template <bool BATCH>
-__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nks, int do_pg) {
-  // Chain batches (BATCH): the workgroup stages its record columns ONCE and walks the chains of the batch (the records
-  // are shared; Z / chi, the pair weights and the output tiles are per chain), so the grid has no chain dimension.
+__global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nks, int do_pg, int G) {
+  // Chain batches (BATCH): the workgroup stages its record columns ONCE and walks the chains of the batch in groups of G
+  // (the records are shared; Z / chi, the pair weights and the output tiles are per chain), so the grid has no chain
+  // dimension.  The weights of a whole group are requested together (one memory round trip per group, not per chain) and
+  // its (chain, row tile) items are dealt to the eight waves together: in the Nu_Z stage a chain has ONE row tile, and a
+  // group of eight chains keeps all eight waves on the matrix cores.
   // The single-chain instantiation is the same code without the loop (and without the registers it keeps alive).
   const int nch = BATCH ? c0.nch : 1;
   TIMELINE(c0, 1);
@@ -105,9 +108,11 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
   // MFMA k-slot kq of step s is curve kq * KS/4 + s: a lane's operands of two consecutive steps are then adjacent,
   // so one 16-byte LDS read feeds two MFMAs.
   const int KSP = KS + 2;                    // even (16-byte alignment of the rows) and 2 mod 8 (row starts spread over banks)
-  double* sW = smem;                         // RS x KSP  raw weights: Z_1..Z_K | 1, chi_1..chi_M | 0
-  double* sB = sW + (size_t)RS * KSP;        // ncol x KSP  record columns
-  double* sP = sB + (size_t)ncol * KSP;      // RP x KSP  pair weights (G workgroups only)
+  const int GG = BATCH ? G : 1;              // chains staged together
+  const int TB = RS + (single ? 0 : RP);     // table rows of a chain
+  double* sB = smem;                         // ncol x KSP  record columns
+  double* sW = sB + (size_t)ncol * KSP;      // chain g of the group at + g TB KSP:  RS x KSP  raw weights: Z_1..Z_K | 1, chi_1..chi_M | 0
+  double* sP = sW + (size_t)RS * KSP;        //                                      RP x KSP  pair weights (G workgroups only)
   const int tid = threadIdx.x;
   constexpr int UW = 12, UB = 6;
   const int ncw = K + MD - 1;                // source columns: Z_1..Z_K, chi_1..chi_M
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
     }
   };
   // pair slot -> (a, b) table (packed upper triangles of Z x Z and chit x chit), decoded once
-  int* ptab = (int*)(sP + (size_t)RP * KSP);
+  int* ptab = (int*)(sW + (size_t)GG * TB * KSP);
   if (!single && tid < NP) {
     int e = tid, off = 0, dim = K;
     if (e >= d.NZZ) { e -= d.NZZ; off = K; dim = MD; }
@@ -179,13 +184,13 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
     ptab[tid] = (off + a) | ((off + a + e) << 16);
   }
   const bool shared_cols = !(single && d.D > 0);     // the staged columns are the same for every chain
-  for (int q = 0; q < nch; ++q) {
+  for (int q = 0; q < nch; q += GG) {
+    const int gc = BATCH ? min(GG, nch - q) : 1;          // chains of this group
     // the per-chain operands (only these: a whole per-chain Ctx costs a few hundred scalar registers)
     const size_t off1 = (size_t)q * c0.chain_bytes;
     const double* Zq = ptr_shift(c0.Z, off1);
     const double* chiq = ptr_shift(c0.chi, off1);
     const double* stilq = ptr_shift(c0.stil, (size_t)q * c0.chain_bytes_cov);
-    double* pgq = ptr_shift(c0.pg_part, off1);
 #ifdef BFMMM_TIMELINE
     struct { Dyn* dyn; } c = {ptr_shift(c0.dyn, off1)};
 #endif
@@ -193,12 +198,44 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       TSTAMP0(c, 40);
       double vw[UW], vb[UB];
       const bool stage_cols = (q == 0) || !shared_cols;
-      loadW(Zq, chiq, 0, 0, vw);
+      // BATCH: element e = tid + 512 u of the group's (chain, column, curve) items, curve fastest (gc ncw KS <= 512 UW)
+      const int nitem = gc * ncw * KS;
+      const bool grp = BATCH && GG > 1;
+      if (grp) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int e = min(tid + PG_THREADS * u, nitem - 1);
+          const int ci = e / KS, il = e - ci * KS;
+          const int g = ci / ncw, col = ci - g * ncw;
+          const int i = min(i0 + il, n - 1);
+          const size_t offg = (size_t)g * c0.chain_bytes;
+          vw[u] = (col < K) ? ptr_shift(Zq, offg)[i + (size_t)n * col] : ptr_shift(chiq, offg)[i + (size_t)n * (col - K)];
+        }
+      } else {
+        loadW(Zq, chiq, 0, 0, vw);
+      }
       if (stage_cols) { if (single) loadB(stilq, 0, vb); else loadG(0, vb); }
       TSTAMP0(c, 47);
-      storeW(0, 0, vw);
+      if (grp) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int e = tid + PG_THREADS * u;
+          if (e < nitem) {
+            const int ci = e / KS, il = e - ci * KS;
+            const int g = ci / ncw, col = ci - g * ncw;
+            sW[((size_t)g * TB + ((col < K) ? col : col + 1)) * KSP + il] = (i0 + il < n) ? vw[u] : 0.0;
+          }
+        }
+        for (int x = tid; x < gc * KS; x += PG_THREADS) {
+          const int g = x / KS, il = x - g * KS;
+          sW[((size_t)g * TB + ONE) * KSP + il] = 1.0; sW[((size_t)g * TB + K + MD) * KSP + il] = 0.0;
+        }
+      } else {
+        storeW(0, 0, vw);
+      }
       TSTAMP0(c, 48);
       if (stage_cols) { if (single) storeB(0, vb); else storeG(0, vb); }
+      if (!grp)
       for (int il0 = 0; il0 < KS; il0 += PG_THREADS)
         for (int cb = 0; cb < ncw; cb += UW) {
           if (il0 == 0 && cb == 0) continue;
@@ -217,17 +254,20 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       // pair rows: thread (tx, ty) = (tid % 32, tid / 32) fills pair slots ty, ty + 16, .. of curves tx, tx + 32, ..
       const int tx = tid & 31, ty = tid >> 5;
       for (int il0 = 0; il0 < KS; il0 += 256) {
-        for (int e = ty; e < NP; e += PG_THREADS / 32) {
-          const int pk = ptab[e], ia = pk & 0xffff, ib = pk >> 16;
+        for (int e = ty; e < NP * gc; e += PG_THREADS / 32) {
+          const int g = BATCH ? e / NP : 0, ep = e - g * NP;
+          const int pk = ptab[ep], ia = pk & 0xffff, ib = pk >> 16;
+          double* sPg = sP + (size_t)g * TB * KSP;
+          const double* sWg = sW + (size_t)g * TB * KSP;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int il = il0 + tx + 32 * j;
-            if (il < KS) sP[e * KSP + il] = sW[ia * KSP + il] * sW[ib * KSP + il];
+            if (il < KS) sPg[ep * KSP + il] = sWg[ia * KSP + il] * sWg[ib * KSP + il];
           }
         }
-        if (ty == 0)
+        if (ty < gc)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[NP * KSP + il] = 0.0; }
+          for (int j = 0; j < 8; ++j) { const int il = il0 + tx + 32 * j; if (il < KS) sP[((size_t)ty * TB + NP) * KSP + il] = 0.0; }
       }
       __syncthreads();
     }
@@ -241,13 +281,16 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
     // each wave walks its tiles TPW at a time with independent accumulators
     constexpr int TPW = 2;
     constexpr int NW = PG_THREADS / 64;
-    for (int t0 = wave; t0 < ntile; t0 += NW * TPW) {
-      int tix[TPW], bcol[TPW], o1[TPW], o2[TPW];
+    const int nitems = gc * ntile;             // (chain of the group, row tile)
+    for (int t0 = wave; t0 < nitems; t0 += NW * TPW) {
+      int tix[TPW], bcol[TPW], o1[TPW], o2[TPW], gch[TPW];
       bool tv[TPW];
 #pragma unroll
       for (int qq = 0; qq < TPW; ++qq) {
-        const int tt = t0 + NW * qq;
-        tv[qq] = tt < ntile;
+        const int it = t0 + NW * qq;
+        tv[qq] = it < nitems;
+        gch[qq] = (BATCH && tv[qq]) ? it / ntile : 0;
+        const int tt = it - gch[qq] * ntile;
         o1[qq] = o2[qq] = ZERO; bcol[qq] = lr; tix[qq] = 0;
         if (tv[qq]) {
           if (!single) {
@@ -269,8 +312,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       const v2d* pa[TPW]; const v2d* pb[TPW]; const v2d* pc[TPW];
 #pragma unroll
       for (int qq = 0; qq < TPW; ++qq) {
-        pa[qq] = (const v2d*)(wsrc + o1[qq] * KSP + kq * KQ);
-        pb[qq] = (const v2d*)(wsrc + o2[qq] * KSP + kq * KQ);
+        const double* wg = wsrc + (size_t)gch[qq] * TB * KSP;
+        pa[qq] = (const v2d*)(wg + o1[qq] * KSP + kq * KQ);
+        pb[qq] = (const v2d*)(wg + o2[qq] * KSP + kq * KQ);
         pc[qq] = (const v2d*)(sB + bcol[qq] * KSP + kq * KQ);
       }
       // The LDS pipe moves 1.5 KB per MFMA and wave -- three quarters of the time the matrix pipe needs for it -- so the
@@ -310,12 +354,12 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
 #pragma unroll
       for (int qq = 0; qq < TPW; ++qq)
         if (tv[qq]) {
-          double* out = pgq + ((size_t)ks * d.NT + tix[qq]) * 256 + lane;
+          double* out = ptr_shift(c0.pg_part, (size_t)(q + gch[qq]) * c0.chain_bytes) + ((size_t)ks * d.NT + tix[qq]) * 256 + lane;
           out[0] = acc[qq][0]; out[64] = acc[qq][1]; out[128] = acc[qq][2]; out[192] = acc[qq][3];
         }
       TSTAMP0(c, 44);
     }
-    if (q + 1 < nch) __syncthreads();        // the next chain overwrites sW / sP
+    if (q + GG < nch) __syncthreads();       // the next group overwrites sW / sP
   }
 }
 
@@ -1330,10 +1374,19 @@ __global__ void k_fill_slots(double* chain, const double* cur, size_t len, int s
 
 // ---- host launchers -------------------------------------------------------------------------
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) {
-  const int row_g = (c.d.K + c.d.MD + 1) + 16 + (c.d.NZZ + c.d.NCC + 1), row_s = (c.d.K + c.d.MD + 1) + c.d.CTS * 16;
-  const size_t lds = std::max((size_t)(KS + 2) * std::max(row_g, row_s) + 128, (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);   // + pair table
-  if (c.nch > 1) hipLaunchKernelGGL(k_pair_gram<true>, dim3(c.d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
-  else hipLaunchKernelGGL(k_pair_gram<false>, dim3(c.d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg);
+  const Dims& d = c.d;
+  const int RS = d.K + d.MD + 1, RP = d.NZZ + d.NCC + 1, ncw = d.K + d.MD - 1;
+  auto lds_doubles = [&](int G) {            // record columns + G chains' tables (G workgroups: 16 + G (RS + RP) rows; s workgroup: 16 CTS + G RS) + pair table
+    return (size_t)(KS + 2) * std::max(16 + G * (RS + RP), d.CTS * 16 + G * RS) + 128;
+  };
+  // chains staged together (k_pair_gram): as many as 144 KB of LDS and 12 staged doubles per thread allow; covariate-adjusted
+  // models stage s~_i per chain and keep one chain per group
+  int G = 1;
+  if (c.nch > 1 && d.D == 0 && d.RT < 8)      // (with eight or more row tiles per chain the waves are busy chain by chain)
+    while (G < c.nch && lds_doubles(G + 1) * sizeof(double) <= 144 * 1024 && (size_t)(G + 1) * ncw * KS <= 12 * 512) ++G;
+  const size_t lds = std::max(lds_doubles(G), (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);
+  if (c.nch > 1) hipLaunchKernelGGL(k_pair_gram<true>, dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
+  else hipLaunchKernelGGL(k_pair_gram<false>, dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256 * 4;        // four lanes per element
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
