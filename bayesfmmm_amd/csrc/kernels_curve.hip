@@ -100,8 +100,10 @@ void fetch_ztrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zphase), sizeof(unsigned long long) * 8 * 512); }
 #endif
 
-template <int BW, int LPC, bool COV>
-__global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
+// KT: compile-time bound on K (3 or KMAX).  The per-cluster arrays below are unrolled to KT, not KMAX: with K <= 3 the
+// quadratic-form registers (Q alone is KMAX^2 doubles) shrink enough for a third and fourth workgroup per CU.
+template <int BW, int LPC, bool COV, int KT>
+__global__ __launch_bounds__(256, (KT <= 3 && BW <= 5) ? 3 : 2) void k_curve_z(Ctx c0, int do_update) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 0);
 #ifdef BFMMM_TIMELINE
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
       // 2K + 2 LDS reads of a trip in flight together (sChi[M] = 0 pads an odd M; row indices stay inside direction k)
       double vb[KMAX];                 // the part without covariates
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+      for (int k = 0; k < KT; ++k) {
         vb[k] = (k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
         ucov[k] = 0.0;
         if (D > 0 && k < K && act) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
           const double c0 = sChi[m], c1 = sChi[m + 1];
           const int r0 = (m + 1), r1 = min(m + 2, M);
 #pragma unroll
-          for (int k = 0; k < KMAX; ++k)
+          for (int k = 0; k < KT; ++k)
             if (k < K) {
               const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
               vb[k] += c0 * tb[r0 * P] + c1 * tb[r1 * P];
@@ -224,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
             }
         }
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) uk[k] = vb[k] + ucov[k];
+      for (int k = 0; k < KT; ++k) uk[k] = vb[k] + ucov[k];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K) tU.row(k)[lp] = uk[k];
     }
     ZT();
@@ -250,27 +252,27 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
     __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int k = 0; k < KT; ++k) {
       av[k] = (k < K) ? sRes[k] : 0.0;
 #pragma unroll
-      for (int k2 = 0; k2 < KMAX; ++k2)
+      for (int k2 = 0; k2 < KT; ++k2)
         if (k2 >= k) Q[k][k2] = (k2 < K) ? sRes[K + tri_index(K, k, k2)] : 0.0;
     }
     ZT();
     double Zfin[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) Zfin[k] = Zold[k];
+    for (int k = 0; k < KT; ++k) Zfin[k] = Zold[k];
     bool took_new = false;
     if (do_update) {
       // quadratic form of the residual sum of squares in Z
       double q_old = cv.yy, q_new = cv.yy;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+      for (int k = 0; k < KT; ++k) {
         if (k < K) {
           q_old -= 2.0 * Zold[k] * av[k];
           q_new -= 2.0 * zp.Znew[k] * av[k];
 #pragma unroll
-          for (int k2 = 0; k2 < KMAX; ++k2) {
+          for (int k2 = 0; k2 < KT; ++k2) {
             if (k2 < K) {
               const double qq = (k2 >= k) ? Q[k][k2] : Q[k2][k];
               q_old += Zold[k] * Zold[k2] * qq;
@@ -283,26 +285,26 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
       const double z_new_lpdf = zp.pr_new - beta * (q_new / (2.0 * sigma2));
       double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K && Zold[k] <= 0) acceptance = 1;                        // UpdateMixedMembership.h:170-174
       if (zp.log_uu < acceptance) {
         took_new = true;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) Zfin[k] = zp.Znew[k];
+        for (int k = 0; k < KT; ++k) Zfin[k] = zp.Znew[k];
       }
       double* zslot = c.c_Z + (size_t)dyn->slot * n * K;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K && lp == k) { c.Z[i + (size_t)n * k] = Zfin[k]; zslot[i + (size_t)n * k] = Zfin[k]; }
     }
     if (do_update) {                                      // log Z_ik of the kept state: both were needed by the proposal densities
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K && lp == k) logz_mine = took_new ? zp.ln[k] : zp.lo[k];
     } else {
       double zarg = 1.0;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K && lp == k) zarg = Zfin[k];
       logz_mine = log(zarg);                              // one log sequence: lane k evaluates log Z_ik
     }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_curve_z(Ctx c0, int do_update) {
       // offset seen by the Phi / nu block: o = sum_k Z_k ucov_k;  s~ = s - G o;  yy~ = yy - 2 o's + o'G o
       double o = 0.0;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KT; ++k)
         if (k < K) o += Zfin[k] * ucov[k];
       tS.row(1)[lp] = o;
       __builtin_amdgcn_wave_barrier();
@@ -642,7 +644,8 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) hipLaunchKernelGGL((k_curve_z<BW, L, CV>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
+    if (which == 0) { if (K <= 3) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 3>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
+                      else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update); }  \
     else hipLaunchKernelGGL((k_curve_chi<BW, L, CV>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
   if (LPC == 32) { if (cov) LAUNCH_CURVE(32, true); else LAUNCH_CURVE(32, false); }
@@ -652,10 +655,14 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
 
 template <int BW>
 static void prepare_bw() {
-  set_max_lds((const void*)k_curve_z<BW, 32, false>);
-  set_max_lds((const void*)k_curve_z<BW, 64, false>);
-  set_max_lds((const void*)k_curve_z<BW, 32, true>);
-  set_max_lds((const void*)k_curve_z<BW, 64, true>);
+  set_max_lds((const void*)k_curve_z<BW, 32, false, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 32, false, KMAX>);
+  set_max_lds((const void*)k_curve_z<BW, 64, false, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 64, false, KMAX>);
+  set_max_lds((const void*)k_curve_z<BW, 32, true, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 32, true, KMAX>);
+  set_max_lds((const void*)k_curve_z<BW, 64, true, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 64, true, KMAX>);
   set_max_lds((const void*)k_curve_chi<BW, 32, false>);
   set_max_lds((const void*)k_curve_chi<BW, 64, false>);
   set_max_lds((const void*)k_curve_chi<BW, 32, true>);

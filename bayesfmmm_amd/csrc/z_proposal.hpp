@@ -3,8 +3,9 @@
 // the Dirichlet(a_Z_PM Z_old) proposal through K keyed gamma draws, both proposal densities, the prior terms and the
 // acceptance uniform.  None of it depends on nu / Phi / chi / sigma^2, so it can be evaluated ahead of the sweep that
 // produces those (job_z_prepare, in spare workgroups of k_factor of the PREVIOUS iteration) or in place (k_curve_z).
-// A group of GW lanes (16 or more) cooperates on a curve: lane t K + k evaluates rejection attempt t of component k,
-// lanes 0 .. K+1 the lgamma terms, lanes 0 .. 2K-1 the logs.  Every lane of the group returns the full result.
+// A group of GW >= 2K + 1 lanes cooperates on a curve: lane t K + k evaluates rejection attempt t of component k,
+// lanes 0 .. K+1 the lgamma terms, lanes 0 .. 2K the logs.  Every lane of the group returns the full result, and the
+// result does not depend on GW (the variate is the first accepted attempt of the sequence however many are tried side by side).
 #pragma once
 #include "model.hpp"
 #include "rng.hpp"
@@ -83,22 +84,22 @@ __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl
   for (int k = 0; k < KMAX; ++k) if (k < K) lB_new += __shfl(lgv, k, GW);
   lB_old -= __shfl(lgv, K, GW);
   lB_new -= __shfl(lgv, K + 1, GW);
-  // log Z_old,k on lane k, log Z_new,k on lane KMAX + k, log of the acceptance uniform on lane 2 KMAX: one log sequence
+  // log Z_old,k on lane k, log Z_new,k on lane K + k, log of the acceptance uniform on lane 2 K: one log sequence
   double larg = 1.0;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     if (k < K && gl == k) larg = Zold[k];
-    if (k < K && gl == KMAX + k) larg = out.Znew[k];
+    if (k < K && gl == K + k) larg = out.Znew[k];
   }
-  if (gl == 2 * KMAX) larg = runif(key, UPD_Z_ACC, (uint32_t)i);
+  if (gl == 2 * K) larg = runif(key, UPD_Z_ACC, (uint32_t)i);
   const double lgz = log(larg);
-  out.log_uu = __shfl(lgz, 2 * KMAX, GW);
+  out.log_uu = __shfl(lgz, 2 * K, GW);
   double pr_old = 0.0, pr_new = 0.0, dn = 0.0, dold = 0.0;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     out.lo[k] = 0.0; out.ln[k] = 0.0;
     if (k < K) {
-      const double lo = __shfl(lgz, k, GW), ln = __shfl(lgz, KMAX + k, GW);
+      const double lo = __shfl(lgz, k, GW), ln = __shfl(lgz, K + k, GW);
       out.lo[k] = lo; out.ln[k] = ln;
       pr_old += (alpha3 * pi[k] - 1.0) * lo;
       pr_new += (alpha3 * pi[k] - 1.0) * ln;
@@ -111,14 +112,18 @@ __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl
   out.lpo = dold - lB_new;
 }
 
-// Spare workgroups of k_factor (iteration t): the proposals of iteration t + 1 for 16 curves each (16 lanes per curve).
+// Spare workgroups of k_factor (iteration t): the proposals of iteration t + 1 for 256 / GW curves each (GW lanes per curve:
+// 8 when 2K + 1 <= 8, else 16 -- zprep_lanes).
 // Z, pi and alpha_3 are final for iteration t by then (k_curve_z and the pi / alpha_3 job ran before k_factor), and the
 // keyed RNG makes the variates a function of (seed, chain, t + 1) alone.  k_curve_z checks the tag before using them.
-__device__ inline void job_z_prepare(const Ctx& c, int wg) {
+__host__ __device__ inline int zprep_lanes(int K) { return (2 * K + 1 <= 8) ? 8 : 16; }
+
+template <int GW>
+__device__ inline void job_z_prepare_gw(const Ctx& c, int wg) {
   const Dims& d = c.d;
   const int n = d.n, K = d.K;
   Dyn* dyn = c.dyn;
-  const int gl = threadIdx.x & 15, i = wg * 16 + (threadIdx.x >> 4);
+  const int gl = threadIdx.x & (GW - 1), i = wg * (256 / GW) + (int)(threadIdx.x / GW);
   if (wg == 0 && threadIdx.x == 0) {
     dyn->zprep_iter = dyn->iter + 1u; dyn->zprep_tt = 0u; dyn->zprep_chain = c.chain; dyn->zprep_seed = c.seed;
     dyn->zprep_valid = 1u;
@@ -129,15 +134,21 @@ __device__ inline void job_z_prepare(const Ctx& c, int wg) {
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
   ZProposal zp;
-  z_proposal<16>(c, key, i, gl, Zold, dyn->alpha3, dyn->pi, zp);
+  z_proposal<GW>(c, key, i, gl, Zold, dyn->alpha3, dyn->pi, zp);
   double* o = c.zprep + i;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
     if (k < K && gl == k) { o[(size_t)n * k] = zp.Znew[k]; o[(size_t)n * (K + k)] = zp.lo[k]; o[(size_t)n * (2 * K + k)] = zp.ln[k]; }
-  if (gl == 15) {
+  if (gl == GW - 1) {
     double* s = o + (size_t)n * 3 * K;
     s[0] = zp.pr_old; s[n] = zp.pr_new; s[(size_t)2 * n] = zp.lpn; s[(size_t)3 * n] = zp.lpo; s[(size_t)4 * n] = zp.log_uu;
   }
+}
+
+__host__ __device__ inline int zprep_curves_per_wg(int K) { return 256 / zprep_lanes(K); }
+__device__ inline void job_z_prepare(const Ctx& c, int wg) {
+  if (zprep_lanes(c.d.K) == 8) job_z_prepare_gw<8>(c, wg);
+  else job_z_prepare_gw<16>(c, wg);
 }
 
 // Spare workgroups of k_factor: the n x M standard normals of THIS iteration's chi update (UpdateChi.h:57-59), which
