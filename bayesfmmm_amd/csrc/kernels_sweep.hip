@@ -62,7 +62,7 @@ void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP
 
 constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
                                   // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
-template <bool BATCH>
+template <bool BATCH, bool GROUPS>
 __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nks, int do_pg, int G) {
   // Chain batches (BATCH): the workgroup stages its record columns ONCE and walks the chains of the batch in groups of G
   // (the records are shared; Z / chi, the pair weights and the output tiles are per chain), so the grid has no chain
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
   // MFMA k-slot kq of step s is curve kq * KS/4 + s: a lane's operands of two consecutive steps are then adjacent,
   // so one 16-byte LDS read feeds two MFMAs.
   const int KSP = KS + 2;                    // even (16-byte alignment of the rows) and 2 mod 8 (row starts spread over banks)
-  const int GG = BATCH ? G : 1;              // chains staged together
+  const int GG = GROUPS ? G : 1;             // chains staged together (GROUPS: its own instantiation, so that the plain chain loop keeps its registers)
   const int TB = RS + (single ? 0 : RP);     // table rows of a chain
   double* sB = smem;                         // ncol x KSP  record columns
   double* sW = sB + (size_t)ncol * KSP;      // chain g of the group at + g TB KSP:  RS x KSP  raw weights: Z_1..Z_K | 1, chi_1..chi_M | 0
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
   }
   const bool shared_cols = !(single && d.D > 0);     // the staged columns are the same for every chain
   for (int q = 0; q < nch; q += GG) {
-    const int gc = BATCH ? min(GG, nch - q) : 1;          // chains of this group
+    const int gc = GROUPS ? min(GG, nch - q) : 1;         // chains of this group
     // the per-chain operands (only these: a whole per-chain Ctx costs a few hundred scalar registers)
     const size_t off1 = (size_t)q * c0.chain_bytes;
     const double* Zq = ptr_shift(c0.Z, off1);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       const bool stage_cols = (q == 0) || !shared_cols;
       // BATCH: element e = tid + 512 u of the group's (chain, column, curve) items, curve fastest (gc ncw KS <= 512 UW)
       const int nitem = gc * ncw * KS;
-      const bool grp = BATCH && GG > 1;
+      constexpr bool grp = GROUPS;
       if (grp) {
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       const int tx = tid & 31, ty = tid >> 5;
       for (int il0 = 0; il0 < KS; il0 += 256) {
         for (int e = ty; e < NP * gc; e += PG_THREADS / 32) {
-          const int g = BATCH ? e / NP : 0, ep = e - g * NP;
+          const int g = GROUPS ? e / NP : 0, ep = e - g * NP;
           const int pk = ptab[ep], ia = pk & 0xffff, ib = pk >> 16;
           double* sPg = sP + (size_t)g * TB * KSP;
           const double* sWg = sW + (size_t)g * TB * KSP;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       for (int qq = 0; qq < TPW; ++qq) {
         const int it = t0 + NW * qq;
         tv[qq] = it < nitems;
-        gch[qq] = (BATCH && tv[qq]) ? it / ntile : 0;
+        gch[qq] = (GROUPS && tv[qq]) ? it / ntile : 0;
         const int tt = it - gch[qq] * ntile;
         o1[qq] = o2[qq] = ZERO; bcol[qq] = lr; tix[qq] = 0;
         if (tv[qq]) {
@@ -1386,8 +1386,9 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   if (c.nch > 1 && d.D == 0 && d.RT < 8)      // (with eight or more row tiles per chain the waves are busy chain by chain)
     while (G < c.nch && lds_doubles(G + 1) * sizeof(double) <= 144 * 1024 && (size_t)(G + 1) * ncw * KS <= 12 * 512) ++G;
   const size_t lds = std::max(lds_doubles(G), (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);
-  if (c.nch > 1) hipLaunchKernelGGL(k_pair_gram<true>, dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
-  else hipLaunchKernelGGL(k_pair_gram<false>, dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
+  if (c.nch > 1 && G > 1) hipLaunchKernelGGL((k_pair_gram<true, true>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
+  else if (c.nch > 1) hipLaunchKernelGGL((k_pair_gram<true, false>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
+  else hipLaunchKernelGGL((k_pair_gram<false, false>), dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
   if (!do_pg) return;
   const int nthreads = c.d.NT * 256 * 4;        // four lanes per element
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
@@ -1462,7 +1463,7 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
-  set_max_lds((const void*)k_pair_gram<false>); set_max_lds((const void*)k_pair_gram<true>);
+  set_max_lds((const void*)k_pair_gram<false, false>); set_max_lds((const void*)k_pair_gram<true, false>); set_max_lds((const void*)k_pair_gram<true, true>);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);
   set_max_lds((const void*)k_factor<32, 2>); set_max_lds((const void*)k_factor<64, 2>);
