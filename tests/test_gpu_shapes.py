@@ -129,3 +129,34 @@ def test_covariate_adjusted_trajectory_across_shapes(K, M, degree, n_internal, n
     for nm in names:
         err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
         assert err < 1e-6, (nm, err)
+
+
+def test_build_limits_fail_loudly():
+    """The limits of this build that the reference does not have (K <= 6, P <= 64, n_eigen <= 16, degree <= 5, D <= 8) are
+    refused at set-up with a message that names the limit -- never truncated, never run on another path."""
+    import bayesfmmm_amd as bf
+    from bayesfmmm_amd import _lib
+    sim = simulate(24, 2, 2, 3, 4, seed=3)
+
+    def make(**kw):
+        args = dict(model=bf.MODEL_FUNCTIONAL, K=2, n_eigen=2, basis_degree=3, tot_mcmc_iters=4)
+        args.update(kw)
+        ik = kw.pop("_ik", sim["internal_knots"])
+        cfg = bf.default_config(**{k: v for k, v in args.items() if not k.startswith("_")})
+        return bf.Sampler(cfg, sim["y"], sim["t"], ik, sim["boundary_knots"])
+
+    with pytest.raises(_lib.BfmmmError, match="K larger than 6"):
+        make(K=7)
+    with pytest.raises(_lib.BfmmmError, match="n_eigen larger than 16"):
+        make(n_eigen=17)
+    with pytest.raises(_lib.BfmmmError, match="basis_degree larger than 5"):
+        make(basis_degree=6)
+    with pytest.raises(_lib.BfmmmError, match="P larger than 64"):
+        make(_ik=np.linspace(0.0, 100.0, 64)[1:-1])        # 62 internal knots + degree 3 + 1 = 66 basis functions
+    rng = np.random.default_rng(1)
+    with pytest.raises(_lib.BfmmmError, match="P larger than 64"):
+        bf.Sampler(bf.default_config(model=bf.MODEL_MULTIVARIATE, K=2, n_eigen=2, tot_mcmc_iters=4), rng.standard_normal((30, 65)))
+    s = make()
+    with pytest.raises(_lib.BfmmmError, match="between 1 and 8"):
+        s.set_covariates(rng.standard_normal((sim["n"], 9)), covariance_adj=False)
+    s.close()
