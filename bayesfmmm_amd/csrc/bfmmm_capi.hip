@@ -87,6 +87,9 @@ struct bfmmm_handle {
   // the remainder of a run after the GRAPH_UNROLL-iteration graphs, as ONE graph of g_rem (fused: g_remF) iterations
   hipGraphExec_t gexecR = nullptr, gexecFR = nullptr;
   int g_rem = 0, g_remF = 0;
+  // the same set for the second half of a chain batch (run_impl: the halves run on two streams)
+  hipGraphExec_t gexecN2 = nullptr, gexecFN2 = nullptr, gexecL2 = nullptr, gexecR2 = nullptr, gexecFR2 = nullptr;
+  int g_rem2 = 0, g_remF2 = 0, g_nsub = 1;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
@@ -461,7 +464,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
     HIPCHK(copy_sync(h, cq.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
     HIPCHK(copy_sync(h, cq.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
   }
-  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR})
+  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2})
     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   h->g_valid = false;
   return 0;
@@ -471,7 +474,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL, h->gexecR, h->gexecFR})
+  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL, h->gexecR, h->gexecFR, h->gexecN2, h->gexecFN2, h->gexecL2, h->gexecR2, h->gexecFR2})
     if (g) (void)hipGraphExecDestroy(g);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->status_host) (void)hipHostFree(h->status_host);
@@ -822,21 +825,37 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
   } else if (n_iters > 0) {
-    const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain;
+    // A chain batch runs as TWO half-batches on two streams: the kernels are the same (a half is a Ctx whose per-chain pointers
+    // start at its first chain), but while one half is in its narrow kernels -- k_sweep_fast is one workgroup per chain,
+    // k_pg_reduce and the factorisations a few dozen -- the other half's wide per-curve kernels have the CUs.
+    const char* env_split = getenv("BFMMM_BATCH_SPLIT");
+    const int nsub = (h->nch >= 4 && !(env_split && atoi(env_split) == 0)) ? 2 : 1;
+    const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub;
     if (!reuse) {
-      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR})
+      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2})
         if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
-      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_valid = true;
+      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_nsub = nsub; h->g_valid = true;
+    }
+    struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; int *rem, *remF; };
+    Sub subs[2];
+    {
+      const int n0 = (nsub == 2) ? h->nch / 2 : h->nch;
+      subs[0] = Sub{c, h->st, &h->gexecN, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->g_rem, &h->g_remF};
+      subs[0].c.nch = n0;
+      if (nsub == 2) {
+        subs[1] = Sub{chain_ctx(c, (unsigned)n0), (env_split && atoi(env_split) == 2) ? h->st : h->st2, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2, &h->g_rem2, &h->g_remF2};
+        subs[1].c.nch = h->nch - n0;
+      }
     }
     // graphs are captured on demand: kind 0 = full iterations, 1 = fused bodies (no Z in front, chi + next Z at the end),
     // 2 = the closing iteration of a fused run (no Z in front, plain chi)
-    auto ensure = [&](hipGraphExec_t* g, int kind, int reps) -> int {
+    auto ensure = [&](const Sub& sb, hipGraphExec_t* g, int kind, int reps) -> int {
       if (*g) return 0;
       std::lock_guard<std::mutex> lock(g_capture_mutex);
       hipGraph_t graph = nullptr;
-      HIPCHK(hipStreamBeginCapture(h->st, hipStreamCaptureModeRelaxed));
-      for (int r = 0; r < reps; ++r) launch_iteration(h, c, plan, NKS, KS, h->st, nullptr, kind != 0, kind == 1);
-      const hipError_t ec = hipStreamEndCapture(h->st, &graph);      // always leaves capture mode, also after a failed launch
+      HIPCHK(hipStreamBeginCapture(sb.st, hipStreamCaptureModeRelaxed));
+      for (int r = 0; r < reps; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, kind != 0, kind == 1);
+      const hipError_t ec = hipStreamEndCapture(sb.st, &graph);      // always leaves capture mode, also after a failed launch
       if (ec != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(ec); }
       const hipError_t ei = hipGraphInstantiate(g, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
@@ -845,31 +864,39 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     };
     // a run of nrep repetitions = nrep / GRAPH_UNROLL replays of the unrolled graph + ONE graph holding the remainder
     // (re-captured only when the remainder changes), so that a short run costs two or three graph launches, not one per iteration
-    auto ensure_rem = [&](hipGraphExec_t* g, int* have, int kind, int rem) -> int {
+    auto ensure_rem = [&](const Sub& sb, hipGraphExec_t* g, int* have, int kind, int rem) -> int {
       if (rem <= 0) return 0;
       if (*g && *have != rem) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
       *have = rem;
-      return ensure(g, kind, rem);
+      return ensure(sb, g, kind, rem);
     };
     const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
     const int nrep = fuse ? n_iters - 1 : n_iters;                  // fused run: n_iters - 1 bodies + the closing iteration
     const int nfull = nrep / GRAPH_UNROLL, rem = nrep % GRAPH_UNROLL;
-    if (!fuse) {
-      if ((nfull > 0 && ensure(&h->gexecN, 0, GRAPH_UNROLL)) || ensure_rem(&h->gexecR, &h->g_rem, 0, rem)) return 1;
-    } else {
-      if ((nfull > 0 && ensure(&h->gexecFN, 1, GRAPH_UNROLL)) || ensure_rem(&h->gexecFR, &h->g_remF, 1, rem) || ensure(&h->gexecL, 2, 1)) return 1;
+    for (int s = 0; s < nsub; ++s) {
+      const Sub& sb = subs[s];
+      if (!fuse) {
+        if ((nfull > 0 && ensure(sb, sb.gN, 0, GRAPH_UNROLL)) || ensure_rem(sb, sb.gR, sb.rem, 0, rem)) return 1;
+      } else {
+        if ((nfull > 0 && ensure(sb, sb.gFN, 1, GRAPH_UNROLL)) || ensure_rem(sb, sb.gFR, sb.remF, 1, rem) || ensure(sb, sb.gL, 2, 1)) return 1;
+      }
     }
     if (prepare_only) return 0;
     HIPCHK(hipEventRecord(h->ev0, h->st));
-    if (!fuse) {
-      for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(h->gexecN, h->st));
-      if (rem > 0) HIPCHK(hipGraphLaunch(h->gexecR, h->st));
-    } else {
-      launch_curve(c, 0, plan.z_update, h->st);              // Z of the first iteration
-      for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(h->gexecFN, h->st));
-      if (rem > 0) HIPCHK(hipGraphLaunch(h->gexecFR, h->st));
-      HIPCHK(hipGraphLaunch(h->gexecL, h->st));
+    if (nsub == 2) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(h->st2, h->evA, 0)); }      // k_run_begin first
+    for (int s = 0; s < nsub; ++s) {
+      const Sub& sb = subs[s];
+      if (!fuse) {
+        for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gN, sb.st));
+        if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gR, sb.st));
+      } else {
+        launch_curve(sb.c, 0, plan.z_update, sb.st);              // Z of the first iteration
+        for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gFN, sb.st));
+        if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gFR, sb.st));
+        HIPCHK(hipGraphLaunch(*sb.gL, sb.st));
+      }
     }
+    if (nsub == 2) { HIPCHK(hipEventRecord(h->evB, h->st2)); HIPCHK(hipStreamWaitEvent(h->st, h->evB, 0)); }
   }
   if (prepare_only) return 0;
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);

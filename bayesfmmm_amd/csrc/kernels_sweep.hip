@@ -1040,8 +1040,14 @@ __device__ inline void sweep_ld8(double& r, const double* sbase, uint32_t voff) 
 template <int BW> struct SweepH { v2d h[BW + 1]; };
 
 // s_waitcnt vmcnt(N) that the loaded registers pass through (no use can be scheduled above it)
-template <int N, int BW>
+// Every wait of k_sweep_fast is a FULL wait (vmcnt(0)), whatever N0 says.  The kernel was written with counted waits (N0 = the
+// loads of the younger prefetch group, left in flight); with a second handle keeping the GPU busy on another stream, one
+// run in five of a stand-alone chain then differed in sigma^2 (a residual term computed from a prefetched H row that had not
+// arrived; tools/dbg_race.py, tests/test_gpu_concurrency.py).  With full waits -- one prefetch group in flight at a time
+// instead of two -- the runs are bit-identical under load and the kernel takes the same 22 us, so the counted waits bought nothing.
+template <int N0, int BW>
 __device__ inline void sweep_wait_h(SweepH<BW>& s) {
+  constexpr int N = 0;
   if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(N));
   if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(N));
   if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(N));
@@ -1152,7 +1158,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) :: "memory");
   }
   __syncthreads();
-  // the hand-counted waits below start from an empty queue; naming the registers that the setup loaded makes
+  // the explicit waits below start from an empty queue; naming the registers that the setup loaded makes
   // the compiler place its own (tracked) waits for them here instead of inside the loop
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_e), "+v"(hq_e), "+v"(tv_e) :: "memory");
   auto issueH = [&](SweepH<BW>& s, int a) {      // branch-free: every lane reads a valid address
@@ -1203,7 +1209,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
       // ---- critical chain: theta_a <- C_a rhs + L_a z_a
       const double lza = lz[a * P + pa], tha = th[a * P + pa];
       const double x0 = rhs[q], x1 = rhs[q + 8], x2 = rhs[q + 16], x3 = rhs[q + 24];
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(cs.v[0]), "+v"(cs.v[1]), "+v"(cs.v[2]), "+v"(cs.v[3]));   // younger: the other C set
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs.v[0]), "+v"(cs.v[1]), "+v"(cs.v[2]), "+v"(cs.v[3]));   // (full wait: see sweep_wait_h)
       double acc = (cs.v[0] * x0 + cs.v[1] * x1) + (cs.v[2] * x2 + cs.v[3] * x3);
       issueC(cs, a_refill);
       acc = dpp_add<0xB1>(acc);     // quad_perm [1,0,3,2]

@@ -16,9 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build():
+def build(sub="tl", extra="-DBFMMM_TIMELINE"):
     src = os.path.join(ROOT, "bayesfmmm_amd", "csrc")
-    dst = os.path.join(ROOT, "tools", "tl", "csrc")
+    dst = os.path.join(ROOT, "tools", sub, "csrc")
     os.makedirs(dst, exist_ok=True)
     for f in os.listdir(src):
         if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":
@@ -27,8 +27,8 @@ def build():
     inc = os.path.join(ROOT, "tools", "include")
     if not os.path.exists(inc):
         os.symlink(os.path.join(ROOT, "include"), inc)
-    subprocess.check_call(["make", "-s", "-j8", "-C", dst, "EXTRA=-DBFMMM_TIMELINE"])
-    print("built", os.path.join(ROOT, "tools", "tl", "libbfmmm_hip.so"))
+    subprocess.check_call(["make", "-s", "-j8", "-C", dst, "EXTRA=" + extra])
+    print("built", os.path.join(ROOT, "tools", sub, "libbfmmm_hip.so"))
 
 
 def run(a):
@@ -78,7 +78,9 @@ def run(a):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("cmd")
+    ap.add_argument("--sub", default="tl", help="build: tools/<sub>/ receives the variant library")
+    ap.add_argument("--extra", default="-DBFMMM_TIMELINE", help="build: extra compiler flags of the variant")
     ap.add_argument("--workload", default="warm")
     ap.add_argument("--chains", type=int, default=1)
     a = ap.parse_args()
-    build() if a.cmd == "build" else run(a)
+    build(a.sub, a.extra) if a.cmd == "build" else run(a)
