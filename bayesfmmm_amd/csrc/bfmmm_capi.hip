@@ -79,17 +79,17 @@ struct bfmmm_handle {
   uint32_t* status_host = nullptr;     // pinned: the chains' status words after a run (one asynchronous copy, no extra round trip)
   size_t pg_part_doubles = 0;
   // graph cache for the last (mask, md, seed, chain)
-  hipGraphExec_t gexec = nullptr;      // one iteration
-  hipGraphExec_t gexecN = nullptr;     // GRAPH_UNROLL iterations (amortises the fixed cost of a graph launch)
-  // fused runs (k_curve_chi of iteration i also does the Z update of iteration i + 1): k_curve_z once, then bodies
-  // [pair_gram .. chi + Z] (gexecF one, gexecFN GRAPH_UNROLL of them), then the last iteration without Z (gexecL)
-  hipGraphExec_t gexecF = nullptr, gexecFN = nullptr, gexecL = nullptr;
-  // the remainder of a run after the GRAPH_UNROLL-iteration graphs, as ONE graph of g_rem (fused: g_remF) iterations
-  hipGraphExec_t gexecR = nullptr, gexecFR = nullptr;
-  int g_rem = 0, g_remF = 0;
-  // the same set for the second half of a chain batch (run_impl: the halves run on two streams)
-  hipGraphExec_t gexecN2 = nullptr, gexecFN2 = nullptr, gexecL2 = nullptr, gexecR2 = nullptr, gexecFR2 = nullptr;
-  int g_rem2 = 0, g_remF2 = 0, g_nsub = 1;
+  // Captured graphs of a run, one set per SUB-BATCH (run_impl splits a chain batch over up to MAX_SUB streams):
+  //   gN  GRAPH_UNROLL full iterations (amortises the fixed cost of a graph launch);
+  //   fused runs (chi kernel of iteration i also runs the Z update of i + 1): gFN = GRAPH_UNROLL bodies [pair_gram .. chi + Z],
+  //   gL = the closing iteration without the Z part;
+  //   gR / gFR = the remainder of a run after the unrolled graphs, as ONE graph of rem / remF iterations
+  struct GraphSet { hipGraphExec_t gN = nullptr, gFN = nullptr, gL = nullptr, gR = nullptr, gFR = nullptr; int rem = 0, remF = 0; };
+  static constexpr int MAX_SUB = 4;
+  GraphSet gs[MAX_SUB];
+  hipStream_t sub_st[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};     // [0] = st
+  hipEvent_t sub_ev[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+  int g_nsub = 1;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int launch_error = 0;
@@ -464,8 +464,9 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
     HIPCHK(copy_sync(h, cq.delta_xi, ones.data(), sizeof(double) * K * M * D, hipMemcpyHostToDevice));
     HIPCHK(copy_sync(h, cq.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
   }
-  for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2})
-    if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+  for (auto& g_ : h->gs)
+    for (hipGraphExec_t* g : {&g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR})
+      if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   h->g_valid = false;
   return 0;
 }
@@ -474,8 +475,10 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  for (hipGraphExec_t g : {h->gexec, h->gexecN, h->gexecF, h->gexecFN, h->gexecL, h->gexecR, h->gexecFR, h->gexecN2, h->gexecFN2, h->gexecL2, h->gexecR2, h->gexecFR2})
-    if (g) (void)hipGraphExecDestroy(g);
+  for (auto& g_ : h->gs)
+    for (hipGraphExec_t g : {g_.gN, g_.gFN, g_.gL, g_.gR, g_.gFR})
+      if (g) (void)hipGraphExecDestroy(g);
+  for (int q = 1; q < bfmmm_handle::MAX_SUB; ++q) { if (h->sub_st[q]) (void)hipStreamDestroy(h->sub_st[q]); if (h->sub_ev[q]) (void)hipEventDestroy(h->sub_ev[q]); }
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->status_host) (void)hipHostFree(h->status_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -825,27 +828,30 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
   } else if (n_iters > 0) {
-    // A chain batch runs as TWO half-batches on two streams: the kernels are the same (a half is a Ctx whose per-chain pointers
-    // start at its first chain), but while one half is in its narrow kernels -- k_sweep_fast is one workgroup per chain,
-    // k_pg_reduce and the factorisations a few dozen -- the other half's wide per-curve kernels have the CUs.
+    // A chain batch runs as SUB-BATCHES on separate streams: the kernels are the same (a sub-batch is a Ctx whose per-chain
+    // pointers start at its first chain), but while one sub-batch is in its narrow kernels -- k_sweep_fast is one workgroup per
+    // chain, k_pg_reduce and the factorisations a few dozen -- the others' wide per-curve kernels have the CUs.
     const char* env_split = getenv("BFMMM_BATCH_SPLIT");
-    const int nsub = (h->nch >= 4 && !(env_split && atoi(env_split) == 0)) ? 2 : 1;
+    int nsub = (h->nch >= 4) ? 2 : 1;
+    if (env_split) nsub = std::max(1, std::min({atoi(env_split), (int)bfmmm_handle::MAX_SUB, h->nch / 2}));
     const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub;
     if (!reuse) {
-      for (hipGraphExec_t* g : {&h->gexec, &h->gexecN, &h->gexecF, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2})
-        if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+      for (auto& g_ : h->gs)
+        for (hipGraphExec_t* g : {&g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR})
+          if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
       h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_nsub = nsub; h->g_valid = true;
     }
     struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; int *rem, *remF; };
-    Sub subs[2];
-    {
-      const int n0 = (nsub == 2) ? h->nch / 2 : h->nch;
-      subs[0] = Sub{c, h->st, &h->gexecN, &h->gexecFN, &h->gexecL, &h->gexecR, &h->gexecFR, &h->g_rem, &h->g_remF};
-      subs[0].c.nch = n0;
-      if (nsub == 2) {
-        subs[1] = Sub{chain_ctx(c, (unsigned)n0), (env_split && atoi(env_split) == 2) ? h->st : h->st2, &h->gexecN2, &h->gexecFN2, &h->gexecL2, &h->gexecR2, &h->gexecFR2, &h->g_rem2, &h->g_remF2};
-        subs[1].c.nch = h->nch - n0;
-      }
+    Sub subs[bfmmm_handle::MAX_SUB];
+    h->sub_st[0] = h->st;
+    for (int q = 0, q0 = 0; q < nsub; ++q) {
+      const int cnt = h->nch / nsub + (q < h->nch % nsub ? 1 : 0);
+      if (!h->sub_st[q]) HIPCHK(hipStreamCreateWithFlags(&h->sub_st[q], hipStreamNonBlocking));
+      if (!h->sub_ev[q]) HIPCHK(hipEventCreateWithFlags(&h->sub_ev[q], hipEventDisableTiming));
+      bfmmm_handle::GraphSet& g_ = h->gs[q];
+      subs[q] = Sub{chain_ctx(c, (unsigned)q0), h->sub_st[q], &g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR, &g_.rem, &g_.remF};
+      subs[q].c.nch = cnt;
+      q0 += cnt;
     }
     // graphs are captured on demand: kind 0 = full iterations, 1 = fused bodies (no Z in front, chi + next Z at the end),
     // 2 = the closing iteration of a fused run (no Z in front, plain chi)
@@ -883,7 +889,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     }
     if (prepare_only) return 0;
     HIPCHK(hipEventRecord(h->ev0, h->st));
-    if (nsub == 2) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(h->st2, h->evA, 0)); }      // k_run_begin first
+    for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(subs[q].st, h->evA, 0)); }      // k_run_begin first
     for (int s = 0; s < nsub; ++s) {
       const Sub& sb = subs[s];
       if (!fuse) {
@@ -896,7 +902,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
         HIPCHK(hipGraphLaunch(*sb.gL, sb.st));
       }
     }
-    if (nsub == 2) { HIPCHK(hipEventRecord(h->evB, h->st2)); HIPCHK(hipStreamWaitEvent(h->st, h->evB, 0)); }
+    for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->sub_ev[q], subs[q].st)); HIPCHK(hipStreamWaitEvent(h->st, h->sub_ev[q], 0)); }
   }
   if (prepare_only) return 0;
   if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
