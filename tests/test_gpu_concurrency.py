@@ -22,7 +22,7 @@ def _state(sim, seed):
     return {nm: oracle_slot(ch, nm, 0) for nm in STATE_NAMES}
 
 
-@pytest.mark.parametrize("sweep", ["warm", "nu_z"])
+@pytest.mark.parametrize("sweep", ["warm", "nu_z", "cov"])
 def test_chain_is_bit_identical_under_concurrent_load(sweep):
     import bayesfmmm_amd as bf
     S = bf.sampler
@@ -32,12 +32,18 @@ def test_chain_is_bit_identical_under_concurrent_load(sweep):
     st, st_big = _state(sim, 100), _state(big, 101)
     pcz = sweep == "nu_z"
     mask = S.SWEEP_NU_Z if pcz else S.SWEEP_WARM
+    X = None
+    if sweep == "cov":        # the covariate-adjusted sweep: eta / Xi block, k_loglik
+        mask = S.SWEEP_WARM | S.COV_MEAN | S.COV_XI
+        X = np.random.default_rng(2).standard_normal((sim["n"], 2))
     if pcz:
         for s_ in (st, st_big):
             s_["Phi"] = np.zeros_like(s_["Phi"]); s_["chi"] = np.zeros_like(s_["chi"])
 
     def run_once():
         a = make_sampler(sim, T)
+        if X is not None:
+            a.set_covariates(X, covariance_adj=True)
         a.set_state(**st)
         a.run(mask, 9, first_iter=0, seed=5, chain=2, phi_chi_zero=pcz)
         a.run(mask, T - 9, first_iter=9, seed=5, chain=2, phi_chi_zero=pcz)
@@ -62,7 +68,7 @@ def test_chain_is_bit_identical_under_concurrent_load(sweep):
     th = threading.Thread(target=load)
     th.start()
     try:
-        for trial in range(30):
+        for trial in range(30 if X is None else 15):
             o = run_once()
             for nm in CHAIN_NAMES:
                 np.testing.assert_array_equal(o[nm], ref[nm], err_msg=f"{sweep}: run {trial} under load differs in {nm}")
@@ -70,3 +76,42 @@ def test_chain_is_bit_identical_under_concurrent_load(sweep):
         stop.set()
         th.join()
     assert not err, err
+
+
+def test_multivariate_chain_is_bit_identical_under_concurrent_load():
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    rng = np.random.default_rng(6)
+    n, P, K, M, T = 300, 12, 3, 2, 12
+    Y = rng.standard_normal((n, P))
+    big = simulate_functional(n=3000, M=3, sigma_sq=0.01, seed=5)
+    st_big = _state(big, 101)
+
+    def run_once():
+        a = bf.Sampler(bf.default_config(model=bf.MODEL_MULTIVARIATE, K=K, n_eigen=M, tot_mcmc_iters=T), Y)
+        a.init_state(1, 17, chain=0)
+        a.run(S.SWEEP_WARM, T, seed=17, chain=0)
+        out = {nm: a.get_chain(nm) for nm in CHAIN_NAMES}
+        a.close()
+        return out
+
+    ref = run_once()
+    stop = threading.Event()
+
+    def load():
+        b = make_sampler(big, 200)
+        b.set_state(**st_big)
+        while not stop.is_set():
+            b.run(S.SWEEP_WARM, 150, first_iter=0, seed=1, chain=0)
+        b.close()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for trial in range(20):
+            o = run_once()
+            for nm in CHAIN_NAMES:
+                np.testing.assert_array_equal(o[nm], ref[nm], err_msg=f"multivariate: run {trial} under load differs in {nm}")
+    finally:
+        stop.set()
+        th.join()
