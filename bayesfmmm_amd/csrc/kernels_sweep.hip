@@ -1231,7 +1231,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
         //      the next direction's rows then publish the next rhs
         sweep_wait_h<0, BW>(h_cur);                  // the youngest group (issued one step ago)
         const int target = 4 * (st + 1);
-        while (*(volatile int*)flag < target) { }
+        // (a workgroup-scope atomic load, not a volatile one: the address-space inference leaves volatile accesses generic,
+        //  and a FLAT load of the flag goes through the vector-memory path on every poll)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
         if (next_rows) {
           r_e -= band_dot(h_cur, dl_w + p);
           if (rk == st + 1) rhs[p] = f * (r_e + hq_e);
