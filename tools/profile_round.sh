@@ -16,6 +16,9 @@ rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 "$ROOT/bench.
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_fetch.log" 2>&1 && echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_write.log" 2>&1 && echo "write done"
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace -d "$OUT/pmc_mfma" -o run -- python3 "$ROOT/bench.py" --steps 100 --warmup 20 $B > "$OUT/bench_mfma.log" 2>&1 && echo "mfma done" || { echo "mfma pass failed:"; tail -5 "$OUT/bench_mfma.log"; }
+# (chain batches normally run as two half-batches on two streams; the per-kernel averages below are taken with the batch on ONE
+#  stream, BFMMM_BATCH_SPLIT=1, so that a kernel's duration is not stretched by the other half's kernels sharing the CUs)
+export BFMMM_BATCH_SPLIT=1
 for spec in warm:8 nu_z:1 nu_z:8 config3:1 config4:1; do
   wl=${spec%%:*}; ch=${spec##*:}
   rocprofv3 --kernel-trace --stats -d "$OUT/${wl}_${ch}" -o run -- python3 "$ROOT/tools/prof_workload.py" --workload "$wl" --chains "$ch" --steps 300 > "$OUT/${wl}_${ch}.json" 2> "$OUT/${wl}_${ch}.err" && echo "$spec done: $(cat "$OUT/${wl}_${ch}.json")"
