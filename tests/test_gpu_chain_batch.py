@@ -96,7 +96,7 @@ def test_batched_chains_with_covariates_equal_standalone_bitwise():
     sim = simulate_functional(n=90, M=2, sigma_sq=0.01, seed=33)
     rng = np.random.default_rng(2)
     X = rng.standard_normal((sim["n"], 2))
-    T, NCH = 7, 3
+    T, NCH = 7, 5          # (five chains: the batch runs as two sub-batches on two streams, the second over moved covariate buffers)
     states = _states(sim, NCH)
     mask = S.SWEEP_WARM | S.COV_MEAN | S.COV_XI
     batch = make_sampler_batch(sim, T, NCH)
