@@ -1043,7 +1043,7 @@ template <int BW> struct SweepH { v2d h[BW + 1]; };
 // Every wait of k_sweep_fast is a FULL wait (vmcnt(0)), whatever N0 says.  The kernel was written with counted waits (N0 = the
 // loads of the younger prefetch group, left in flight); with a second handle keeping the GPU busy on another stream, one
 // run in five of a stand-alone chain then differed in sigma^2 (a residual term computed from a prefetched H row that had not
-// arrived; tools/dbg_race.py, tests/test_gpu_concurrency.py).  With full waits -- one prefetch group in flight at a time
+// arrived; tests/test_gpu_concurrency.py).  With full waits -- one prefetch group in flight at a time
 // instead of two -- the runs are bit-identical under load and the kernel takes the same 22 us, so the counted waits bought nothing.
 template <int N0, int BW>
 __device__ inline void sweep_wait_h(SweepH<BW>& s) {
