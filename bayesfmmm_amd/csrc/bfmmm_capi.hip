@@ -166,7 +166,9 @@ static void set_md(Dims& d, int MD) {
   d.R = d.NZZ * d.NCC;
   d.RT = (d.R + 15) / 16;
   d.AT = (d.A + 15) / 16;
-  d.CTG = (d.LG + 15) / 16;
+  // multivariate model: G_i = I, every column of the G part of a record is the same column of ones, so the pair-Gram
+  // contraction computes ONE column tile and the reduction writes the (scalar) block value to all P columns of H
+  d.CTG = d.mv ? 1 : (d.LG + 15) / 16;
   d.CTS = (d.P + 15) / 16;
   d.NT = d.RT * d.CTG + d.AT * d.CTS;
 }

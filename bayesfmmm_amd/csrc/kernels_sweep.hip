@@ -380,9 +380,22 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
   const size_t stride = (size_t)d.NT * 256;
   double sg = 0.0;
   const int nfull = NKS & ~3;                             // slices 0 .. nfull-1 go to the four interleaved sums
-  for (int ks = g; ks < nfull; ks += 4) sg += src[(size_t)ks * stride];
-  if (g == 0)
-    for (int ks = nfull; ks < NKS; ++ks) sg += src[(size_t)ks * stride];
+  // eight loads of a lane go out together (the slabs were written by the previous kernel: every load is a trip to memory,
+  // and a plain accumulation loop pays one trip per term); the additions keep the sequential order
+  for (int k0 = g; k0 < nfull; k0 += 32) {
+    double v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = src[(size_t)min(k0 + 4 * u, NKS - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (k0 + 4 * u < nfull) sg += v8[u];
+  }
+  {
+    double vt[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) vt[u] = src[(size_t)min(nfull + u, NKS - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (g == 0 && nfull + u < NKS) sg += vt[u];
+  }
   // (s0 + s1) + (s2 + s3), s_g on lane g of the quad
   const double s01 = sg + __shfl_xor(sg, 1, 4);
   const double s = s01 + __shfl_xor(s01, 2, 4);
@@ -391,7 +404,15 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
   if (t < n_pair_tiles) {
     const int rt = t / d.CTG, ct = t - rt * d.CTG;
     const int row = rt * 16 + rit, col = ct * 16 + cit;
-    if (row < d.R && col < d.LG) {
+    if (d.mv) {
+      // G_i = I: the block is s I (BW = 0: H2 rows are [G(p, p), 0])
+      // (the 16 columns of the tile are the same column of ones: every lane of a row holds the same sum and takes its share
+      //  of the P columns)
+      if (row < d.R) {
+        double* h2 = c.H2 + (size_t)row * d.P * 2;
+        for (int p0 = cit; p0 < d.P; p0 += 16) { c.H[(size_t)row * d.LG + p0] = s; h2[2 * p0] = s; }
+      }
+    } else if (row < d.R && col < d.LG) {
       c.H[(size_t)row * d.LG + col] = s;
       // row-major copy for the sweep: entry k of row p is G(p, p + k - BW)
       const int dd = col / d.P, p0 = col - dd * d.P, W = 2 * d.BW + 2;

@@ -74,7 +74,7 @@ struct Dims {
   int A;                // directions = K * MD
   int NZZ, NCC, R;      // pair rows: K(K+1)/2 * MD(MD+1)/2
   int RT, AT;           // 16-row tiles of pair rows / of single-weight rows
-  int CTG, CTS;         // 16-col tiles over the G part / the s part of a record
+  int CTG, CTS;         // 16-col tiles over the G part (multivariate model: 1, the columns are identical) / the s part of a record
   int NT;               // total output tiles of the pair-Gram kernel = RT*CTG + AT*CTS
   int NWG;              // workgroups (= K-slices) of the pair-Gram kernel
   int mv;               // multivariate model flags (prior (1/tau) I, tau stored inverted, ...)
