@@ -25,6 +25,7 @@ int curve_blocks(int n, int P);
 void prepare_curve_kernels();
 void prepare_sweep_kernels();
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
+void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
@@ -60,8 +61,8 @@ static int fail(const std::string& msg) { g_err = msg; return 1; }
     }                                                                                               \
   } while (0)
 
-enum { FAM_TOTAL = 0, FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK, FAM_COUNT };
-static const char* kFamNames[FAM_COUNT] = {"total", "curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik"};
+enum { FAM_TOTAL = 0, FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK, FAM_REDUCE, FAM_COUNT };
+static const char* kFamNames[FAM_COUNT] = {"total", "curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik", "pg_reduce"};
 
 struct bfmmm_handle {
   bfmmm_config cfg;
@@ -772,6 +773,8 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   mark();
   launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
   mark();
+  if (p.pg) launch_pg_reduce(c, NKS, st);
+  mark();
   if (p.factor) launch_factor(c, st);
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
@@ -820,9 +823,9 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       const bool skip_z = pfuse && it > 0, fuse_z = pfuse && it + 1 < n_iters;
       launch_iteration(h, c, plan, NKS, KS, h->st, &evs, skip_z, fuse_z);
       HIPCHK(hipStreamSynchronize(h->st));
-      const int fams[6] = {FAM_Z, FAM_PG, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
-      const bool ran[6] = {plan.z && !skip_z, true, plan.factor, true, true, c.defer_loglik == 0};
-      for (int q = 0; q < 6; ++q) {
+      const int fams[7] = {FAM_Z, FAM_PG, FAM_REDUCE, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
+      const bool ran[7] = {plan.z && !skip_z, true, plan.pg, plan.factor, true, true, c.defer_loglik == 0};
+      for (int q = 0; q < 7; ++q) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, evs[q], evs[q + 1]);
         if (ran[q]) { h->fam_ms[fams[q]] += ms; h->fam_launches[fams[q]] += 1; }

@@ -1418,7 +1418,9 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   if (c.nch > 1 && G > 1) hipLaunchKernelGGL((k_pair_gram<true, true>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
   else if (c.nch > 1) hipLaunchKernelGGL((k_pair_gram<true, false>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
   else hipLaunchKernelGGL((k_pair_gram<false, false>), dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
-  if (!do_pg) return;
+}
+
+void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st) {
   const int nthreads = c.d.NT * 256 * 4;        // four lanes per element
   hipLaunchKernelGGL(k_pg_reduce, dim3((nthreads + 255) / 256, 1, c.nch), dim3(256), 0, st, c, NKS);
 }

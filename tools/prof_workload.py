@@ -80,7 +80,7 @@ def main():
                chain_iterations_per_s=a.chains * a.steps / dt)
     if a.eager:
         out["event_ms_per_launch"] = {nm: smp.timing(nm)[0] / max(smp.timing(nm)[1], 1)
-                                      for nm in ["curve_z", "pair_gram", "factor", "sweep", "curve_chi", "loglik"]}
+                                      for nm in ["curve_z", "pair_gram", "pg_reduce", "factor", "sweep", "curve_chi", "loglik"]}
     print(json.dumps(out))
 
 
