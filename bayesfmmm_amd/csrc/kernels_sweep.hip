@@ -510,9 +510,13 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c0) {
 #endif
   FST(0);
   const int AP = A * P, PS = P + 2 * BW + 1;
+  // diagonal model (multivariate: G_i = I, prior (1 / tau) I or diag(gamma)): the precision is a diagonal, no P x P work
+  // areas -- the launch then asks for 10 KB of LDS instead of 75, and the spare jobs of this kernel (which need none of it) fit
+  // five to a CU instead of two
+  const bool diag = (BW == 0) && d.BWP == 0;
   double* S = smem;                 // PP x PP : Prec (col-major, S[i + PP*k])
   double* X = S + PP * PP;          // PP x PP : U^-1, row-major X[i*PP + c]
-  double* thp = X + PP * PP;        // A x PS : theta_b with BW zero pads before and BW + 1 after
+  double* thp = diag ? smem : X + PP * PP;        // A x PS : theta_b with BW zero pads before and BW + 1 after
   double* part = thp + A * PS;      // A x P  : (H_ab theta_b)[p]
   double* zv = part + AP;           // PP
   double* hb2 = zv + PP;            // P x W  : rows of H_aa
@@ -624,6 +628,29 @@ __global__ __launch_bounds__(256) void k_factor(Ctx c0) {
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
   for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
+  if (diag) {
+    // C = diag(1 / d_p), chol_lower(C) = diag(1 / sqrt(d_p)), L z likewise (the same estimate + two Newton steps as
+    // factor_core's diagonal branch, so the factor is the same function of the pivot).  d_p > 0 always: the prior term is.
+    double* Cg = c.Cmat + (size_t)a * P * P;
+    for (int e = tid; e < P * P; e += 256) {
+      const int p = e % P, q = e / P;
+      double cv = 0.0;
+      if (p == q) {
+        double dk = f * hb2[p * W + BW];
+        if (mt == 0) dk += d.mv ? 1.0 / tau_j : tau_j * c.Pmat[p + (size_t)P * p];     // UpdateNu.h:197 (MV) / :66
+        else dk += tt * c.gamma[j + (size_t)K * (p + (size_t)P * (mt - 1))];            // UpdatePhi.h:76-78
+        double rk = __builtin_amdgcn_rsq(dk);
+        rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+        rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
+        if (!(dk > 0.0)) atomicOr(&c.dyn->status, 1u);
+        cv = rk * rk;
+        c.Lz[(size_t)a * P + p] = rk * zv[p];
+      }
+      Cg[q + (size_t)P * p] = cv;
+    }
+    FST(6);
+    return;
+  }
   // only the band of Prec is read by the factorisation (factor_core): (BWP + 1) x P entries
   auto build_prec = [&](bool full) {     // full: the whole symmetric matrix (pseudo-inverse route)
     for (int e = tid; e < PP * PP; e += 256) X[e] = 0.0;
@@ -1441,7 +1468,8 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
 void launch_factor(const Ctx& c, hipStream_t st) {
   const int PP = (c.d.P <= 32) ? 32 : 64;
   const int W = 2 * c.d.BW + 2, PS = c.d.P + 2 * c.d.BW + 1;
-  const size_t lds = (2 * (size_t)PP * PP + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16 + 4 * PP + 2) * sizeof(double);
+  const bool diag = c.d.BW == 0 && c.d.BWP == 0;       // no P x P work areas (k_factor)
+  const size_t lds = ((diag ? 0 : 2 * (size_t)PP * PP) + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16 + 4 * PP + 2) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int zcw = zprep_curves_per_wg(c.d.K);       // curves per workgroup of job_z_prepare (z_proposal.hpp)
   const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + zcw - 1) / zcw : 0;
