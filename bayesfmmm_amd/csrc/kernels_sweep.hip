@@ -904,8 +904,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c0, int direct) {
 // the next step requested one step ahead.  No LDS hand-off and no barrier inside the sweep.  r follows the general
 // kernel's definition (r_a = t_a - sum_b H_ab theta_b over all b).  One workgroup of 8 P threads; A <= 64.
 // ---------------------------------------------------------------------------------------------
-constexpr int DG_RPL = 8;          // directions per lane
+constexpr int DG_RPL_MAX = 8;      // directions per lane, at most (k_sweep_diag<DG_RPL>: DG_RPL = ceil(A / 8), the slots a lane really has)
 
+template <int DG_RPL>
 __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
@@ -915,7 +916,8 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   Dyn* dyn = c.dyn;
   double* red = smem;                          // 16
-  int* htab = (int*)(red + 16);                // A x A : element offset of block (b, a) in H
+  double* sH = red + 16;                       // A x A : multivariate model: the blocks are scalars, H_{b,a} = sH[b A + a] I
+  int* htab = (int*)(sH + A * A);              // A x A : element offset of block (b, a) in H
   int* sdir = htab + A * A;
   const uint32_t slot = dyn->slot;
   const uint32_t mask = c.mask;
@@ -935,7 +937,11 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   for (int x = tid; x < n_steps + 2; x += nthr) sdir[x] = step_dir(d, min(x, max(n_steps - 1, 0)), n_phi);
   const int p = min(tid >> 3, P - 1), g = tid & 7;
   const bool live = (tid >> 3) < P;
-  const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
+  double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
+  uint32_t tt_step0 = dyn->tt_step;
+  // (both are needed by one lane at the very end: requested here, with the rest of the set-up loads, or they are two trips to
+  //  memory after the last step)
+  asm volatile("" : "+v"(sig_g), "+v"(tt_step0));
   double r[DG_RPL], hq[DG_RPL], cd[DG_RPL], lz[DG_RPL], th[DG_RPL], tv[DG_RPL];
 #pragma unroll
   for (int j = 0; j < DG_RPL; ++j) {
@@ -948,9 +954,17 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   }
   __syncthreads();
   DST(1);
+  // Multivariate model (G_i = I): every block of H is a multiple of the identity, so the A^2 scalars are read ONCE into LDS
+  // and a step's H_{b,a} is an LDS read instead of a request to L2 two steps ahead (the steps of this kernel were bound by
+  // that latency: 36 steps took 39 us)
+  const bool scalar_blocks = d.mv != 0;
+  if (scalar_blocks) {
+    for (int x = tid; x < A * A; x += nthr) sH[x] = c.H[(size_t)htab[x]];
+    __syncthreads();
+  }
   // H was written by another XCD (k_pg_reduce): touch it once (one 4-byte load per 128-byte line, fire and forget) so
   // that the per-step requests are L2 hits; they are issued two steps ahead (three register sets, compile-time indexed)
-  if (n_steps > 0) {
+  if (n_steps > 0 && !scalar_blocks) {
     int w0 = 0;
     const size_t nl = ((size_t)d.R * LG * 8 + 127) / 128;
     for (size_t x = tid; x < nl; x += nthr) {
@@ -963,44 +977,57 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   double hs[3][DG_RPL];
   auto fetch = [&](auto which, int a) {       // H_{b,a}[p] for this lane's directions
     constexpr int Q = decltype(which)::value;
+    if (scalar_blocks) {      // (two loops, not a selected pointer: that would be a FLAT load behind a branch per element)
 #pragma unroll
-    for (int j = 0; j < DG_RPL; ++j) {
-      const int b = min(g + 8 * j, A - 1);
-      hs[Q][j] = c.H[(size_t)htab[b * A + a] + p];
+      for (int j = 0; j < DG_RPL; ++j) hs[Q][j] = sH[min(g + 8 * j, A - 1) * A + a];
+    } else {
+#pragma unroll
+      for (int j = 0; j < DG_RPL; ++j) hs[Q][j] = c.H[(size_t)htab[min(g + 8 * j, A - 1) * A + a] + p];
     }
   };
-  auto step = [&](int s, auto which) {
+  // a: this step's direction, a2: the direction two steps ahead (its H column is requested now).  Branch-free: the draw is
+  // evaluated for all of a lane's slots and the step's slot selected (a taken branch costs ~40 clk here, eight of them a step
+  // were half of it).
+  auto step = [&](int a, int a2, auto which) {
     constexpr int Q = decltype(which)::value;
-    const int a = __builtin_amdgcn_readfirstlane(sdir[s]);
-    fetch(std::integral_constant<int, (Q + 2) % 3>{}, __builtin_amdgcn_readfirstlane(sdir[min(s + 2, n_steps + 1)]));
+    fetch(std::integral_constant<int, (Q + 2) % 3>{}, a2);
     const int owner = a & 7, js = a >> 3;
+    const bool mine_lane = g == owner;
     double dsel = 0.0;
 #pragma unroll
-    for (int j = 0; j < DG_RPL; ++j)
-      if (j == js) {                                     // uniform: the slot of this step's direction
-        const double nw = cd[j] * (f * (r[j] + hq[j])) + lz[j];
-        if (g == owner) { dsel = nw - th[j]; th[j] = nw; }
-      }
+    for (int j = 0; j < DG_RPL; ++j) {
+      const double nw = cd[j] * (f * (r[j] + hq[j])) + lz[j];
+      const bool mine = mine_lane && j == js;
+      dsel = mine ? nw - th[j] : dsel;
+      th[j] = mine ? nw : th[j];
+    }
     dsel = dpp_add<0xB1>(dsel);
     dsel = dpp_add<0x4E>(dsel);
     const double delta = dpp_add<0x141>(dsel);           // broadcast to the 8 lanes of the coordinate
 #pragma unroll
     for (int j = 0; j < DG_RPL; ++j) {
       const double v = hs[Q][j] * delta;
-      if (g + 8 * j < A) r[j] -= v;
-      if (j == js && g == owner) hq[j] += v;
+      r[j] = (g + 8 * j < A) ? r[j] - v : r[j];
+      hq[j] = (mine_lane && j == js) ? hq[j] + v : hq[j];
     }
   };
   if (n_steps > 0) {
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
-    fetch(Q0{}, __builtin_amdgcn_readfirstlane(sdir[0]));
-    fetch(Q1{}, __builtin_amdgcn_readfirstlane(sdir[1]));
+    // the directions of the steps travel in scalar registers, read from LDS three steps ahead of their use
+    auto dir_at = [&](int s) { return __builtin_amdgcn_readfirstlane(sdir[min(s, n_steps + 1)]); };
+    int a0 = dir_at(0), a1 = dir_at(1), a2 = dir_at(2), a3 = dir_at(3), a4 = dir_at(4);
+    fetch(Q0{}, a0);
+    fetch(Q1{}, a1);
     int s = 0;
-    for (; s + 2 < n_steps; s += 3) { step(s, Q0{}); step(s + 1, Q1{}); step(s + 2, Q2{}); }
-    if (s < n_steps) { step(s, Q0{}); ++s; }
-    if (s < n_steps) { step(s, Q1{}); ++s; }
+    for (; s + 2 < n_steps; s += 3) {
+      const int b0 = dir_at(s + 5), b1 = dir_at(s + 6), b2 = dir_at(s + 7);
+      step(a0, a2, Q0{}); step(a1, a3, Q1{}); step(a2, a4, Q2{});
+      a0 = a3; a1 = a4; a2 = b0; a3 = b1; a4 = b2;
+    }
+    if (s < n_steps) { step(a0, a2, Q0{}); ++s; }
+    if (s < n_steps) { step(a1, a3, Q1{}); ++s; }
   }
   DST(3);
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:127-165 MV) ---------------------------------
@@ -1020,7 +1047,7 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
       double qs = 0.0;
       for (int w = 0; w < nthr / 64; ++w) qs += red[w];
       const double rss = (d.D > 0) ? -qs : (c.YY - qs);
-      const bool tempered = (dyn->tt_step != 0);
+      const bool tempered = (tt_step0 != 0);
       const double bb = (tempered ? (beta / 2) * rss : 0.5 * rss) + c.h.beta_0;
       const double s2 = 1.0 / (sig_g * (1.0 / bb));
       dyn->sigma2 = s2;
@@ -1482,9 +1509,19 @@ void launch_factor(const Ctx& c, hipStream_t st) {
 
 int launch_sweep(const Ctx& c, hipStream_t st) {
   const Dims& d = c.d;
-  if (d.BW == 0 && d.BWP == 0 && d.A <= 8 * DG_RPL && d.P <= 64) {        // diagonal model: independent scalar chains per coordinate
-    const size_t lds = 16 * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
-    hipLaunchKernelGGL(k_sweep_diag, dim3(1, 1, c.nch), dim3((8 * d.P + 63) / 64 * 64), lds, st, c);
+  if (d.BW == 0 && d.BWP == 0 && d.A <= 8 * DG_RPL_MAX && d.P <= 64) {        // diagonal model: independent scalar chains per coordinate
+    const size_t lds = (16 + (size_t)d.A * d.A) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
+    const dim3 grid(1, 1, c.nch), block((8 * d.P + 63) / 64 * 64);
+    switch ((d.A + 7) / 8) {
+      case 1: hipLaunchKernelGGL(k_sweep_diag<1>, grid, block, lds, st, c); break;
+      case 2: hipLaunchKernelGGL(k_sweep_diag<2>, grid, block, lds, st, c); break;
+      case 3: hipLaunchKernelGGL(k_sweep_diag<3>, grid, block, lds, st, c); break;
+      case 4: hipLaunchKernelGGL(k_sweep_diag<4>, grid, block, lds, st, c); break;
+      case 5: hipLaunchKernelGGL(k_sweep_diag<5>, grid, block, lds, st, c); break;
+      case 6: hipLaunchKernelGGL(k_sweep_diag<6>, grid, block, lds, st, c); break;
+      case 7: hipLaunchKernelGGL(k_sweep_diag<7>, grid, block, lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_diag<8>, grid, block, lds, st, c); break;
+    }
     return 0;
   }
   if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
