@@ -100,10 +100,10 @@ void fetch_ztrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zphase), sizeof(unsigned long long) * 8 * 512); }
 #endif
 
-// KT: compile-time bound on K (3 or KMAX).  The per-cluster arrays below are unrolled to KT, not KMAX: with K <= 3 the
+// KT: compile-time bound on K (4 or KMAX).  The per-cluster arrays below are unrolled to KT, not KMAX: with K <= 4 the
 // quadratic-form registers (Q alone is KMAX^2 doubles) shrink enough for a third and fourth workgroup per CU.
 template <int BW, int LPC, bool COV, int KT>
-__global__ __launch_bounds__(256, (KT <= 3 && BW <= 5) ? 3 : 2) void k_curve_z(Ctx c0, int do_update) {
+__global__ __launch_bounds__(256, (KT <= 4 && BW <= 5) ? 3 : 2) void k_curve_z(Ctx c0, int do_update) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 0);
 #ifdef BFMMM_TIMELINE
@@ -350,11 +350,11 @@ __global__ __launch_bounds__(256, (KT <= 3 && BW <= 5) ? 3 : 2) void k_curve_z(C
 // LDS per group: U[M], GU[M], C0 (1), D = s - G c0 (1), chi (M), z (M), res (M(M+1)/2 + M + 2).  Sized by the
 // actual M so that three workgroups fit a CU and the extra scalar-job workgroup never waits for a free slot.
 // ------------------------------------------------------------------------------------------------
-// SMALL: K <= 3 and M <= 8 -- the per-cluster and per-eigenfunction loops are unrolled to those bounds instead of KMAX = 6 and
+// SMALL: K <= 4 and M <= 8 -- the per-cluster and per-eigenfunction loops are unrolled to those bounds instead of KMAX = 6 and
 // MMAX = 16 (the Gauss-Seidel recursion and the residual update are MMAX^2 guarded terms otherwise): 18.7 -> 17.4 us at config 2
 template <int BW, int LPC, bool COV, bool SMALL>
 __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
-  constexpr int KT = SMALL ? 3 : KMAX, MT = SMALL ? 8 : MMAX;
+  constexpr int KT = SMALL ? 4 : KMAX, MT = SMALL ? 8 : MMAX;
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 5);
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
@@ -647,9 +647,9 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) { if (K <= 3) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 3>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
+    if (which == 0) { if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
                       else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update); }  \
-    else if (K <= 3 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
+    else if (K <= 4 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
     else hipLaunchKernelGGL((k_curve_chi<BW, L, CV, false>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
   if (LPC == 32) { if (cov) LAUNCH_CURVE(32, true); else LAUNCH_CURVE(32, false); }
@@ -659,13 +659,13 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
 
 template <int BW>
 static void prepare_bw() {
-  set_max_lds((const void*)k_curve_z<BW, 32, false, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 32, false, 4>);
   set_max_lds((const void*)k_curve_z<BW, 32, false, KMAX>);
-  set_max_lds((const void*)k_curve_z<BW, 64, false, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 64, false, 4>);
   set_max_lds((const void*)k_curve_z<BW, 64, false, KMAX>);
-  set_max_lds((const void*)k_curve_z<BW, 32, true, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 32, true, 4>);
   set_max_lds((const void*)k_curve_z<BW, 32, true, KMAX>);
-  set_max_lds((const void*)k_curve_z<BW, 64, true, 3>);
+  set_max_lds((const void*)k_curve_z<BW, 64, true, 4>);
   set_max_lds((const void*)k_curve_z<BW, 64, true, KMAX>);
   set_max_lds((const void*)k_curve_chi<BW, 32, false, true>);
   set_max_lds((const void*)k_curve_chi<BW, 32, false, false>);
