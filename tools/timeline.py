@@ -59,6 +59,8 @@ def run(a):
             if st[2 * k] == 0:
                 continue
             print(f"  {names[k]:10s} {(st[2*k]-t0)/100:8.2f} {(st[16+k]-t0)/100:8.2f} {(st[2*k+1]-t0)/100:8.2f}   span {(st[2*k+1]-st[2*k])/100:7.2f}")
+        if st[15] > 0:
+            print(f"  k_curve_chi: the scalar-job workgroup (delta, A, gamma, tau) ends {(st[15] - st[10]) / 100:.2f} us into the kernel; the kernel ends at {(st[11] - st[10]) / 100:.2f} us")
         f = st[48:55]
         print("  factor workgroup 1 phases (us):", " ".join(f"{(f[i+1]-f[i])/100:.2f}" for i in range(6)), " total", (f[6] - f[0]) / 100)
         try:
