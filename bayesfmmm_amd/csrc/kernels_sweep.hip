@@ -906,7 +906,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(Ctx c0, int direct) {
 // ---------------------------------------------------------------------------------------------
 constexpr int DG_RPL_MAX = 8;      // directions per lane, at most (k_sweep_diag<DG_RPL>: DG_RPL = ceil(A / 8), the slots a lane really has)
 
-template <int DG_RPL>
+// SCALAR_BLOCKS: a compile-time switch (the two sources of a step's H column must not meet in one load: a selected LDS-or-global
+// pointer is a FLAT load)
+template <int DG_RPL, bool SCALAR_BLOCKS>
 __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   // Multivariate model (G_i = I): every block of H is a multiple of the identity, so the A^2 scalars are read ONCE into LDS
   // and a step's H_{b,a} is an LDS read instead of a request to L2 two steps ahead (the steps of this kernel were bound by
   // that latency: 36 steps took 39 us)
-  const bool scalar_blocks = d.mv != 0;
+  constexpr bool scalar_blocks = SCALAR_BLOCKS;      // (the launcher passes d.mv)
   if (scalar_blocks) {
     for (int x = tid; x < A * A; x += nthr) sH[x] = c.H[(size_t)htab[x]];
     __syncthreads();
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   double hs[3][DG_RPL];
   auto fetch = [&](auto which, int a) {       // H_{b,a}[p] for this lane's directions
     constexpr int Q = decltype(which)::value;
-    if (scalar_blocks) {      // (two loops, not a selected pointer: that would be a FLAT load behind a branch per element)
+    if constexpr (scalar_blocks) {
 #pragma unroll
       for (int j = 0; j < DG_RPL; ++j) hs[Q][j] = sH[min(g + 8 * j, A - 1) * A + a];
     } else {
@@ -1513,14 +1515,14 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     const size_t lds = (16 + (size_t)d.A * d.A) * sizeof(double) + ((size_t)d.A * d.A + (size_t)d.K * (d.M + 1) + 8) * sizeof(int) + 16;
     const dim3 grid(1, 1, c.nch), block((8 * d.P + 63) / 64 * 64);
     switch ((d.A + 7) / 8) {
-      case 1: hipLaunchKernelGGL(k_sweep_diag<1>, grid, block, lds, st, c); break;
-      case 2: hipLaunchKernelGGL(k_sweep_diag<2>, grid, block, lds, st, c); break;
-      case 3: hipLaunchKernelGGL(k_sweep_diag<3>, grid, block, lds, st, c); break;
-      case 4: hipLaunchKernelGGL(k_sweep_diag<4>, grid, block, lds, st, c); break;
-      case 5: hipLaunchKernelGGL(k_sweep_diag<5>, grid, block, lds, st, c); break;
-      case 6: hipLaunchKernelGGL(k_sweep_diag<6>, grid, block, lds, st, c); break;
-      case 7: hipLaunchKernelGGL(k_sweep_diag<7>, grid, block, lds, st, c); break;
-      default: hipLaunchKernelGGL(k_sweep_diag<8>, grid, block, lds, st, c); break;
+      case 1: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<1, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<1, false>), grid, block, lds, st, c); break;
+      case 2: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<2, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<2, false>), grid, block, lds, st, c); break;
+      case 3: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<3, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<3, false>), grid, block, lds, st, c); break;
+      case 4: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<4, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<4, false>), grid, block, lds, st, c); break;
+      case 5: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<5, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<5, false>), grid, block, lds, st, c); break;
+      case 6: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<6, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<6, false>), grid, block, lds, st, c); break;
+      case 7: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<7, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<7, false>), grid, block, lds, st, c); break;
+      default: if (d.mv) hipLaunchKernelGGL((k_sweep_diag<8, true>), grid, block, lds, st, c); else hipLaunchKernelGGL((k_sweep_diag<8, false>), grid, block, lds, st, c); break;
     }
     return 0;
   }
