@@ -50,6 +50,22 @@ struct PostDev {
   double *llpart, *pdf_part, *fit_part;
 };
 
+// A basis row's non-zero window against a coefficient window: the row either sits in LDS (staged) or in global memory.  Two
+// functions with differently typed pointers: a pointer SELECTED between the two would be a generic one, and every load of the
+// inner loop a FLAT load.
+typedef const __attribute__((address_space(3))) double* lds_cptr;
+__device__ inline double window_dot_lds(const double* br_lds, const double* cg, int W) {
+  lds_cptr br = (lds_cptr)br_lds;
+  double f = 0.0;
+  for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+  return f;
+}
+__device__ inline double window_dot(const double* br, const double* cg, int W) {
+  double f = 0.0;
+  for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+  return f;
+}
+
 __global__ __launch_bounds__(256, 3) void k_post_pointwise(PostDev a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int i = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
@@ -155,10 +171,8 @@ __global__ __launch_bounds__(256, 3) void k_post_pointwise(PostDev a) {
         for (int j = jl; j < ni; j += JW) {
           const double yj = (j == jl) ? y0 : a.y[o + j];
           const int stj = (j == jl) ? st0 : a.bstart[o + j];
-          const double* br = staged ? sB + j * WS : a.Bc + (size_t)(o + j) * W;
           const double* cg = sC + g * CS + stj;
-          double f = 0.0;
-          for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+          const double f = staged ? window_dot_lds(sB + j * WS, cg, W) : window_dot(a.Bc + (size_t)(o + j) * W, cg, W);
           const double z = (yj - f) * isd;
           const double lt = -(0.91893853320467274178 + 0.5 * z * z + lsd);     // R::dnorm(., ., ., log = true)
           if (on) ll += lt;
@@ -277,12 +291,10 @@ __global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
     for (int e = tid; e < gn * NIP; e += 256) {
       const int g = e / NIP, j = e - g * NIP;
       if (j < ni) {
-        const double* br = staged ? sB + j * WS : a.Bc + (size_t)(o + j) * W;
         const int st = a.bstart[o + j];
         for (int mt = 0; mt < M1; ++mt) {
           const double* cg = sV + (g * M1 + mt) * CS + st;
-          double f = 0.0;
-          for (int w = 0; w < W; ++w) f += br[w] * cg[w];
+          const double f = staged ? window_dot_lds(sB + j * WS, cg, W) : window_dot(a.Bc + (size_t)(o + j) * W, cg, W);
           sU[(g * M1 + mt) * NIP + j] = (mt == 0) ? a.y[o + j] - f : f;
         }
       } else {
