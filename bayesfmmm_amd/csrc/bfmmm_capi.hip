@@ -763,8 +763,11 @@ static Plan make_plan(uint32_t mask, int MD) {
 // The scalar updates ride inside the wide kernels, so the replayed graph is a single chain of
 // seven kernels with no cross-queue dependencies.
 // skip_z: the Z update of this iteration was already done by the previous iteration's k_curve_chi (fuse_z there).
+// trail_z: the iteration ends with the stand-alone Z update of the NEXT iteration, in its lean form (the proposals were prepared
+// by this iteration's k_factor): sweeps without a chi pass cannot fuse the Z update into k_curve_chi, but they can still run
+// it in the order "first Z of the run, then bodies [pair_gram .. chi, next Z]".
 static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NKS, int KS, hipStream_t st,
-                             std::vector<hipEvent_t>* evs, bool skip_z = false, bool fuse_z = false) {
+                             std::vector<hipEvent_t>* evs, bool skip_z = false, bool fuse_z = false, bool trail_z = false) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
@@ -780,6 +783,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
   launch_curve(c, 1, (p.chi ? (p.chi_update ? 2 : 1) : 0) | (fuse_z ? 16 : 0), st);
+  if (trail_z) launch_curve(c, 0, p.z_update | 2, st);
   if (c.d.D > 0) launch_cov_block(c, st);      // eta, tau_eta, Xi, delta_xi, A_xi, gamma_xi (+ residual sums)
   mark();
   if (!c.defer_loglik) launch_loglik(c, p.use_rss_part, 0, st);      // otherwise: job_hyper + the next k_pair_gram (scalar_jobs.hpp)
@@ -865,7 +869,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       std::lock_guard<std::mutex> lock(g_capture_mutex);
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(sb.st, hipStreamCaptureModeRelaxed));
-      for (int r = 0; r < reps; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, kind != 0, kind == 1);
+      for (int r = 0; r < reps; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, kind != 0, kind == 1, kind == 3);
       const hipError_t ec = hipStreamEndCapture(sb.st, &graph);      // always leaves capture mode, also after a failed launch
       if (ec != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(ec); }
       const hipError_t ei = hipGraphInstantiate(g, graph, nullptr, nullptr, 0);
@@ -882,14 +886,20 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       return ensure(sb, g, kind, rem);
     };
     const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
-    const int nrep = fuse ? n_iters - 1 : n_iters;                  // fused run: n_iters - 1 bodies + the closing iteration
+    // sweeps whose Z update cannot ride in k_curve_chi (no chi pass: the Nu_Z stage) still run it at the END of the previous
+    // iteration's body, as the lean stand-alone kernel (kind 3 bodies)
+    const bool defer = !fuse && plan.z && plan.z_update && plan.factor && (mask & U_Z) && c.d.D == 0 && c.d.K <= 4 && c.d.BW <= 5 &&
+                       n_iters >= 2 && tt_step == 0;
+    const int body_kind = fuse ? 1 : 3;
+    const bool bodies = fuse || defer;
+    const int nrep = bodies ? n_iters - 1 : n_iters;                // fused / deferred run: n_iters - 1 bodies + the closing iteration
     const int nfull = nrep / GRAPH_UNROLL, rem = nrep % GRAPH_UNROLL;
     for (int s = 0; s < nsub; ++s) {
       const Sub& sb = subs[s];
-      if (!fuse) {
+      if (!bodies) {
         if ((nfull > 0 && ensure(sb, sb.gN, 0, GRAPH_UNROLL)) || ensure_rem(sb, sb.gR, sb.rem, 0, rem)) return 1;
       } else {
-        if ((nfull > 0 && ensure(sb, sb.gFN, 1, GRAPH_UNROLL)) || ensure_rem(sb, sb.gFR, sb.remF, 1, rem) || ensure(sb, sb.gL, 2, 1)) return 1;
+        if ((nfull > 0 && ensure(sb, sb.gFN, body_kind, GRAPH_UNROLL)) || ensure_rem(sb, sb.gFR, sb.remF, body_kind, rem) || ensure(sb, sb.gL, 2, 1)) return 1;
       }
     }
     if (prepare_only) return 0;
@@ -897,7 +907,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(subs[q].st, h->evA, 0)); }      // k_run_begin first
     for (int s = 0; s < nsub; ++s) {
       const Sub& sb = subs[s];
-      if (!fuse) {
+      if (!bodies) {
         for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gN, sb.st));
         if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gR, sb.st));
       } else {

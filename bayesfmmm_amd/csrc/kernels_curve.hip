@@ -102,8 +102,12 @@ void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 
 // KT: compile-time bound on K (4 or KMAX).  The per-cluster arrays below are unrolled to KT, not KMAX: with K <= 4 the
 // quadratic-form registers (Q alone is KMAX^2 doubles) shrink enough for a third and fourth workgroup per CU.
-template <int BW, int LPC, bool COV, int KT>
-__global__ __launch_bounds__(256, (KT <= 4 && BW <= 5) ? 3 : 2) void k_curve_z(Ctx c0, int do_update) {
+// LEAN: the launch is one whose proposals were prepared by the previous iteration's k_factor for certain (bfmmm_capi.hip runs
+// every Z update but the first of a run that way); the in-place evaluation of the proposal -- keyed gamma rejection loops,
+// lgamma, logs -- is then not compiled in, which takes the kernel from 167 to 100 VGPRs and from three to four or five
+// workgroups per CU.  Should the tag not match after all, the run fails loudly (status bit 2).
+template <int BW, int LPC, bool COV, int KT, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) void k_curve_z(Ctx c0, int do_update) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 0);
 #ifdef BFMMM_TIMELINE
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(256, (KT <= 4 && BW <= 5) ? 3 : 2) void k_curve_z(C
     const bool pre = dyn->zprep_valid && dyn->zprep_iter == dyn->iter && dyn->zprep_tt == dyn->tt_step &&
                      dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed && D == 0;
     if (pre) z_proposal_load(c, i, zp);
+    else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
     else z_proposal<LPC>(c, make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
   }
   // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
@@ -647,8 +652,9 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) { if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update);  \
-                      else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update); }  \
+    if (which == 0) { if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
+                      else if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
+                      else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1); }  \
     else if (K <= 4 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
     else hipLaunchKernelGGL((k_curve_chi<BW, L, CV, false>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
@@ -660,6 +666,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
 template <int BW>
 static void prepare_bw() {
   set_max_lds((const void*)k_curve_z<BW, 32, false, 4>);
+  if constexpr (BW <= 5) { set_max_lds((const void*)k_curve_z<BW, 32, false, 4, true>); set_max_lds((const void*)k_curve_z<BW, 64, false, 4, true>); }
   set_max_lds((const void*)k_curve_z<BW, 32, false, KMAX>);
   set_max_lds((const void*)k_curve_z<BW, 64, false, 4>);
   set_max_lds((const void*)k_curve_z<BW, 64, false, KMAX>);
