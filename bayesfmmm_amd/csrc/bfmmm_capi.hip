@@ -782,7 +782,9 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
-  launch_curve(c, 1, (p.chi ? (p.chi_update ? 2 : 1) : 0) | (fuse_z ? 16 : 0), st);
+  // (a trailing lean Z launch carries the scalar job of k_curve_chi as its first workgroup: sweeps without a chi pass -- the
+  //  only ones that run deferred -- then need no k_curve_chi launch at all)
+  if (!(trail_z && !p.chi)) launch_curve(c, 1, (p.chi ? (p.chi_update ? 2 : 1) : 0) | (fuse_z ? 16 : 0), st);
   if (trail_z) launch_curve(c, 0, p.z_update | 2, st);
   if (c.d.D > 0) launch_cov_block(c, st);      // eta, tau_eta, Xi, delta_xi, A_xi, gamma_xi (+ residual sums)
   mark();

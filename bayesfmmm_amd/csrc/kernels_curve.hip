@@ -106,10 +106,19 @@ void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 // every Z update but the first of a run that way); the in-place evaluation of the proposal -- keyed gamma rejection loops,
 // lgamma, logs -- is then not compiled in, which takes the kernel from 167 to 100 VGPRs and from three to four or five
 // workgroups per CU.  Should the tag not match after all, the run fails loudly (status bit 2).
+// A LEAN launch closes iteration t and opens t + 1: workgroup 0 runs iteration t's scalar job (delta, A, gamma, tau; it
+// advances the iteration counters at its end), so the curve workgroups take the iteration and the chain slot from the
+// snapshot the sweep left (iter_hyper + 1, slot_hyper + 1), as the fused update in k_curve_chi does; curve block b sits at
+// grid index 8 + b (workgroups 1-7 idle), on the XCD of k_curve_chi's block b.
 template <int BW, int LPC, bool COV, int KT, bool LEAN = false>
 __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) void k_curve_z(Ctx c0, int do_update) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 0);
+  if (LEAN && blockIdx.x < 8) {
+    if (blockIdx.x == 0) job_hyper(c);
+    return;
+  }
+  const int blk = LEAN ? (int)blockIdx.x - 8 : (int)blockIdx.x;
 #ifdef BFMMM_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     unsigned id, hw;
@@ -146,10 +155,11 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   T tU{gbase}, tG{gbase + (TW - 1) * K * T::STR}, tS{gbase + TW * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
   double* sChi = gbase + (TW * K + 3) * T::STR;
   double* sRes = sChi + MMAX;
-  const int i = blockIdx.x * GPB + grp;
+  const int i = blk * GPB + grp;
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
+  const uint32_t it_cur = LEAN ? dyn->iter_hyper + 1u : dyn->iter, slot_cur = LEAN ? dyn->slot_hyper + 1u : dyn->slot;
   // ---- all global loads are requested up front.  Z first: the proposal phase below needs nothing else, and loads
   //      retire in issue order, so it can start while the record, theta and chi are still on their way ----
   double Zold[KMAX];
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   //      iteration of a run, tempered sweeps, changed state) it is evaluated here, while the loads are in flight ----
   ZProposal zp;
   if (valid && do_update) {
-    const bool pre = dyn->zprep_valid && dyn->zprep_iter == dyn->iter && dyn->zprep_tt == dyn->tt_step &&
+    const bool pre = dyn->zprep_valid && dyn->zprep_iter == it_cur && dyn->zprep_tt == dyn->tt_step &&
                      dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed && D == 0;
     if (pre) z_proposal_load(c, i, zp);
     else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
 #pragma unroll
         for (int k = 0; k < KT; ++k) Zfin[k] = zp.Znew[k];
       }
-      double* zslot = c.c_Z + (size_t)dyn->slot * n * K;
+      double* zslot = c.c_Z + (size_t)slot_cur * n * K;
 #pragma unroll
       for (int k = 0; k < KT; ++k)
         if (k < K && lp == k) { c.Z[i + (size_t)n * k] = Zfin[k]; zslot[i + (size_t)n * k] = Zfin[k]; }
@@ -341,12 +351,12 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   if (threadIdx.x < K) {
     double acc = 0.0;
     for (int g = 0; g < GPB; ++g) acc += sLog[g * KMAX + threadIdx.x];
-    c.logz_part[(size_t)blockIdx.x * K + threadIdx.x] = acc;
+    c.logz_part[(size_t)blk * K + threadIdx.x] = acc;
   }
   if (D > 0 && threadIdx.x == 0) {
     double acc = 0.0;
     for (int g = 0; g < GPB; ++g) acc += sYp[g];
-    c.yyp_part[blockIdx.x] = acc;
+    c.yyp_part[blk] = acc;
   }
 }
 
@@ -647,12 +657,12 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int TW = c.d.mv ? 1 : 2;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 32 + tileE);
   else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
-  if (which == 1) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch
+  if (which == 1 || (do_update & 2)) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch (k_curve_chi, lean k_curve_z)
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) { if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
+    if (which == 0) { if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1); }  \
     else if (K <= 4 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
