@@ -115,3 +115,77 @@ def test_multivariate_chain_is_bit_identical_under_concurrent_load():
     finally:
         stop.set()
         th.join()
+
+
+def _under_load(run_once, names, trials, label):
+    """run_once() on an idle device, then `trials` times while a second handle keeps the GPU busy: all bit-identical"""
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    big = simulate_functional(n=3000, M=3, sigma_sq=0.01, seed=5)
+    st_big = _state(big, 101)
+    ref = run_once()
+    stop = threading.Event()
+
+    def load():
+        b = make_sampler(big, 200)
+        b.set_state(**st_big)
+        while not stop.is_set():
+            b.run(S.SWEEP_WARM, 150, first_iter=0, seed=1, chain=0)
+        b.close()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for trial in range(trials):
+            o = run_once()
+            for nm in names:
+                np.testing.assert_array_equal(o[nm], ref[nm], err_msg=f"{label}: run {trial} under load differs in {nm}")
+    finally:
+        stop.set()
+        th.join()
+
+
+def test_chain_batch_on_two_streams_is_bit_identical_under_concurrent_load():
+    """six Nu_Z chains as one batch: two sub-batches on two streams, the lean trailing Z kernel, grouped pair-Gram staging"""
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    sim = simulate_functional(n=500, M=3, sigma_sq=0.01, seed=3)
+    T, NCH = 14, 6
+
+    def run_once():
+        cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=sim["K"], n_eigen=sim["M"], basis_degree=3, tot_mcmc_iters=T)
+        s = bf.Sampler(cfg, sim["y"], sim["t"], sim["internal_knots"], sim["boundary_knots"], n_chains=NCH)
+        for q in range(NCH):
+            s.select_chain(q)
+            s.init_state(0, 7, chain=q)
+        s.run(S.SWEEP_NU_Z, T, seed=7, phi_chi_zero=True)
+        out = {}
+        for q in range(NCH):
+            s.select_chain(q)
+            for nm in ["nu", "Z", "pi", "tau", "sigma_sq", "loglik"]:
+                out[f"{nm}{q}"] = s.get_chain(nm)
+        s.close()
+        return out
+
+    names = [f"{nm}{q}" for q in range(NCH) for nm in ["nu", "Z", "pi", "tau", "sigma_sq", "loglik"]]
+    _under_load(run_once, names, 15, "Nu_Z batch")
+
+
+def test_general_sweep_kernel_is_bit_identical_under_concurrent_load():
+    """K = 5, M = 9, P = 30: A P = 1500 elements, beyond the register-resident sweep -- the general k_sweep and the KMAX / MMAX
+    instantiations of the per-curve kernels"""
+    import bayesfmmm_amd as bf
+    from test_gpu_shapes import simulate
+    S = bf.sampler
+    sim = simulate(64, 5, 9, 3, 26, seed=159)
+
+    def run_once():
+        cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=5, n_eigen=9, basis_degree=3, tot_mcmc_iters=8)
+        s = bf.Sampler(cfg, sim["y"], sim["t"], sim["internal_knots"], sim["boundary_knots"])
+        s.init_state(1, 5, chain=0)
+        s.run(S.SWEEP_WARM, 8, seed=5)
+        out = {nm: s.get_chain(nm) for nm in CHAIN_NAMES}
+        s.close()
+        return out
+
+    _under_load(run_once, CHAIN_NAMES, 15, "general sweep")
