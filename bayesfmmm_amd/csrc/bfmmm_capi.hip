@@ -77,6 +77,8 @@ struct bfmmm_handle {
   // raw inputs kept on the device for bfmmm_get_basis
   double* d_t = nullptr; double* d_y = nullptr; int64_t* d_off = nullptr; double* d_knots = nullptr; int n_knots = 0;
   std::vector<void*> allocs;
+  char* arena = nullptr;               // base of the per-chain arena (chain q at arena + q * c.chain_bytes)
+  char* arena_cov = nullptr;           // the same for the covariate buffers (c.chain_bytes_cov)
   uint32_t* status_host = nullptr;     // pinned: the chains' status words after a run (one asynchronous copy, no extra round trip)
   size_t pg_part_doubles = 0;
   // graph cache for the last (mask, md, seed, chain)
@@ -130,7 +132,7 @@ static int dalloc(bfmmm_handle* h, T** p, size_t count) {
 struct ArenaReq { void* slot; size_t bytes; };
 template <typename T>
 static void areq(std::vector<ArenaReq>& v, T** p, size_t count) { v.push_back({(void*)p, std::max<size_t>(count, 1) * sizeof(T)}); }
-static int arena_commit(bfmmm_handle* h, const std::vector<ArenaReq>& v, int nch, size_t* stride_out) {
+static int arena_commit(bfmmm_handle* h, const std::vector<ArenaReq>& v, int nch, size_t* stride_out, char** base_out) {
   size_t off = 0;
   std::vector<size_t> offs;
   for (const ArenaReq& r : v) { offs.push_back(off); off += (r.bytes + 255) & ~(size_t)255; }
@@ -140,6 +142,7 @@ static int arena_commit(bfmmm_handle* h, const std::vector<ArenaReq>& v, int nch
   HIPCHK(hipMemsetAsync(base, 0, off * (size_t)nch, h->st));
   for (size_t i = 0; i < v.size(); ++i) { void* q = base + offs[i]; memcpy(v[i].slot, &q, sizeof q); }
   *stride_out = off;
+  *base_out = base;
   return 0;
 }
 // the context of the selected chain (host view)
@@ -337,7 +340,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
     areq(ar, &c.c_alpha3, T); areq(ar, &c.c_delta, T * K * M); areq(ar, &c.c_A, T * K * 2); areq(ar, &c.c_sigma, T);
     areq(ar, &c.c_tau, T * K); areq(ar, &c.c_gamma, T * K * P * M); areq(ar, &c.c_Phi, T * K * P * M); areq(ar, &c.c_loglik, T);
   }
-  if (arena_commit(h, ar, n_chains, &c.chain_bytes)) return 1;
+  if (arena_commit(h, ar, n_chains, &c.chain_bytes, &h->arena)) return 1;
   c.chain_bytes_cov = 0; c.chain_id_stride = 1; c.nch = n_chains;
   double* pm;
   if (dalloc(h, &pm, (size_t)P * P)) return 1;
@@ -457,7 +460,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
   areq(ar, &c.step_part, 2 * (size_t)c.NBS * (D * P + 1)); areq(ar, &c.thetaN, K * (M + 1) * D * P); areq(ar, &c.delta_cur, P + 2);
   areq(ar, &c.c_eta, T * P * D * K); areq(ar, &c.c_xi, T * K * P * D * M); areq(ar, &c.c_tau_eta, T * K * D);
   areq(ar, &c.c_gamma_xi, T * K * P * D * M); areq(ar, &c.c_delta_xi, T * K * M * D); areq(ar, &c.c_A_xi, T * K * 2 * D);
-  if (arena_commit(h, ar, h->nch, &c.chain_bytes_cov)) { d.D = 0; return 1; }
+  if (arena_commit(h, ar, h->nch, &c.chain_bytes_cov, &h->arena_cov)) { d.D = 0; return 1; }
   // neutral state: eta = xi = 0, tau_eta = gamma_xi = delta_xi = A_xi = 1 (BFMMM.h:3705-3722, 3896-3915)
   std::vector<double> ones(std::max({K * D, K * P * D * M, K * M * D, K * 2 * D}), 1.0);
   for (int q = 0; q < h->nch; ++q) {
@@ -1150,10 +1153,22 @@ extern "C" int bfmmm_get_timing(bfmmm_handle* h, const char* name, double* ms, i
     if (r_ != ncclSuccess) {                                                                        \
       char buf_[512];                                                                               \
       snprintf(buf_, sizeof buf_, "RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #x); \
-      for (ncclComm_t cm_ : comms) if (cm_) (void)ncclCommDestroy(cm_);                             \
       return fail(buf_);                                                                            \
     }                                                                                               \
   } while (0)
+
+// what bfmmm_gather_best holds for the length of the call: the communicators and the per-device (score, id) buffers are
+// released on EVERY return path
+struct GatherGuard {
+  std::vector<ncclComm_t> comms;
+  std::vector<int> devs;
+  std::vector<double*> bufs;
+  ~GatherGuard() {
+    for (ncclComm_t cm : comms) if (cm) (void)ncclCommDestroy(cm);
+    for (size_t i = 0; i < bufs.size(); ++i)
+      if (bufs[i]) { (void)hipSetDevice(devs[i / 2]); (void)hipFree(bufs[i]); }
+  }
+};
 
 extern "C" int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, const double* scores, const int32_t* chain_ids,
                                  int* winner_out) {
@@ -1168,13 +1183,20 @@ extern "C" int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, co
     for (int g2 = 0; g2 < g; ++g2)
       if (devs[g2] == devs[g]) return fail("bfmmm_gather_best: one handle per device");
   }
-  std::vector<ncclComm_t> comms(G, nullptr);
+  GatherGuard gg;
+  gg.devs = devs;
+  gg.comms.assign(G, nullptr);
+  gg.bufs.assign(2 * (size_t)G, nullptr);
+  std::vector<ncclComm_t>& comms = gg.comms;
   NCCLCHK(ncclCommInitAll(comms.data(), G, devs.data()));
   // (score, chain index) pairs: send 2 doubles, receive 2 G
   std::vector<double*> sbuf(G, nullptr), rbuf(G, nullptr);
   for (int g = 0; g < G; ++g) {
     HIPCHK(hipSetDevice(devs[g]));
-    if (dalloc(handles[g], &sbuf[g], 2) || dalloc(handles[g], &rbuf[g], 2 * (size_t)G)) return 1;
+    HIPCHK(hipMalloc((void**)&gg.bufs[2 * g], sizeof(double) * 2));
+    HIPCHK(hipMalloc((void**)&gg.bufs[2 * g + 1], sizeof(double) * 2 * (size_t)G));
+    sbuf[g] = gg.bufs[2 * g];
+    rbuf[g] = gg.bufs[2 * g + 1];
     const double pair[2] = {scores[g], (double)chain_ids[g]};
     HIPCHK(copy_sync(handles[g], sbuf[g], pair, sizeof pair, hipMemcpyHostToDevice));
   }
@@ -1193,17 +1215,19 @@ extern "C" int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, co
       if (w < 0 || all[2 * r] > all[2 * w] || (all[2 * r] == all[2 * w] && all[2 * r + 1] < all[2 * w + 1])) w = r;
     }
     if (g == 0) winner = w;
-    else if (w != winner) { for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm); return fail("bfmmm_gather_best: ranks disagree on the winner"); }
+    else if (w != winner) return fail("bfmmm_gather_best: ranks disagree on the winner");
   }
-  if (winner < 0) { for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm); return fail("bfmmm_gather_best: no rank holds a valid chain"); }
+  if (winner < 0) return fail("bfmmm_gather_best: no rank holds a valid chain");
   if (winner != 0) {
-    const Ctx src = selc(handles[winner]), dst = selc(handles[0]);
+    bfmmm_handle* hs = handles[winner], *hd = handles[0];
+    const size_t cb = hd->c.chain_bytes, cbc = hd->c.chain_bytes_cov;
+    if (!hs->arena || !hd->arena || (cbc && (!hs->arena_cov || !hd->arena_cov))) return fail("bfmmm_gather_best: a handle has no chain arena");
     NCCLCHK(ncclGroupStart());
-    NCCLCHK(ncclSend(src.dyn, src.chain_bytes, ncclChar, 0, comms[winner], handles[winner]->st));
-    NCCLCHK(ncclRecv(dst.dyn, dst.chain_bytes, ncclChar, winner, comms[0], handles[0]->st));
-    if (src.chain_bytes_cov) {
-      NCCLCHK(ncclSend(src.thetaX, src.chain_bytes_cov, ncclChar, 0, comms[winner], handles[winner]->st));
-      NCCLCHK(ncclRecv(dst.thetaX, dst.chain_bytes_cov, ncclChar, winner, comms[0], handles[0]->st));
+    NCCLCHK(ncclSend(hs->arena + (size_t)hs->sel * cb, cb, ncclChar, 0, comms[winner], hs->st));
+    NCCLCHK(ncclRecv(hd->arena + (size_t)hd->sel * cb, cb, ncclChar, winner, comms[0], hd->st));
+    if (cbc) {
+      NCCLCHK(ncclSend(hs->arena_cov + (size_t)hs->sel * cbc, cbc, ncclChar, 0, comms[winner], hs->st));
+      NCCLCHK(ncclRecv(hd->arena_cov + (size_t)hd->sel * cbc, cbc, ncclChar, winner, comms[0], hd->st));
     }
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipSetDevice(devs[winner]));
@@ -1212,7 +1236,6 @@ extern "C" int bfmmm_gather_best(bfmmm_handle* const* handles, int n_handles, co
     HIPCHK(hipStreamSynchronize(handles[0]->st));
     handles[0]->state_dirty = true;
   }
-  for (ncclComm_t cm : comms) (void)ncclCommDestroy(cm);
   if (winner_out) *winner_out = winner;
   return 0;
 }

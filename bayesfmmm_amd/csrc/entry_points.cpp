@@ -217,40 +217,60 @@ struct DevRun {
 
 // Runs the device's chains in batches of at most max_concurrent (one batch = ONE sampler whose kernels carry the chain
 // index as a grid dimension, bfmmm_create_batch) and keeps the batch that holds the device's best chain.
+// Memory: a batch is one arena of n_chains x (state + workspace + all T chain slots) -- about 0.3 MB x T per chain at
+// n_funct = 4096, K = 3, P = 30, M = 6 -- so when the arena cannot be allocated the batch size is halved and the same
+// chains are retried in smaller batches.  Any other failure (a precision that is not positive definite, a failing
+// kernel, a failing read-back) fails the whole call, as the reference does (an exception inside one of its chains
+// aborts BFMMM_Nu_Z_multiple_try): r.err is set, nothing is kept, and run_multi_try returns the error.
 static void run_device(const bfmmm_entry_args* a, const bfmmm_config& cfg, uint32_t mask, int phi_chi_zero,
                        chain_setup_fn setup, const void* ctx, DevRun& r) {
   const int T = cfg.tot_mcmc_iters;
-  const size_t cap = (size_t)std::max(1, a->max_concurrent);
+  size_t cap = (size_t)std::max(1, a->max_concurrent);
   const uint32_t id_stride = r.chains.size() > 1 ? (uint32_t)(r.chains[1] - r.chains[0]) : 1u;
   std::vector<double> ll(T);
-  for (size_t base = 0; base < r.chains.size(); base += cap) {
+  auto fail_device = [&](bfmmm_handle* h) {
+    if (r.err.empty()) r.err = bfmmm_last_error();
+    if (r.err.empty()) r.err = "multi-try batch failed";
+    if (h) bfmmm_destroy(h);
+    if (r.best.h) bfmmm_destroy(r.best.h);
+    r.best = ChainRun();
+    r.n_ok = 0;
+  };
+  size_t base = 0;
+  while (base < r.chains.size()) {
     const int nb = (int)std::min(r.chains.size() - base, cap);
     bfmmm_handle* h = nullptr;
-    auto lib_fail = [&]() { if (r.err.empty()) r.err = bfmmm_last_error(); if (h) bfmmm_destroy(h); h = nullptr; };
-    if (make_handle(a, &cfg, r.device, nb, &h)) { lib_fail(); continue; }
-    if (attach_cov(h, a) || bfmmm_set_chain_id_stride(h, id_stride)) { lib_fail(); continue; }
-    bool ok = true;
-    for (int q = 0; q < nb && ok; ++q) ok = !bfmmm_select_chain(h, q) && !setup(h, r.chains[base + q], ctx);
-    // a failing batch loses its own chains only: the chains that did finish still compete (the reference would have
-    // returned the best of those it completed)
-    if (!ok || bfmmm_run(h, mask, 0, T, a->seed, (uint32_t)r.chains[base], phi_chi_zero, 1.0)) { lib_fail(); continue; }
-    int sel = -1;
+    if (make_handle(a, &cfg, r.device, nb, &h)) {
+      if (h) { bfmmm_destroy(h); h = nullptr; }
+      if (nb > 1 && strstr(bfmmm_last_error(), "memory")) { cap = (size_t)(nb + 1) / 2; continue; }      // smaller batches
+      return fail_device(nullptr);
+    }
+    if (attach_cov(h, a) || bfmmm_set_chain_id_stride(h, id_stride)) return fail_device(h);
+    for (int q = 0; q < nb; ++q)
+      if (bfmmm_select_chain(h, q) || setup(h, r.chains[base + q], ctx)) return fail_device(h);
+    if (bfmmm_run(h, mask, 0, T, a->seed, (uint32_t)r.chains[base], phi_chi_zero, 1.0)) return fail_device(h);
+    // score the batch into locals; r.best changes only after every chain of the batch has been read back
+    int sel = -1, n_fin = 0;
+    double sel_score = -INFINITY;
     for (int q = 0; q < nb; ++q) {
-      if (bfmmm_select_chain(h, q) || bfmmm_get_chain(h, "loglik", T, ll.data(), T)) { lib_fail(); break; }
+      if (bfmmm_select_chain(h, q) || bfmmm_get_chain(h, "loglik", T, ll.data(), T)) return fail_device(h);
       const double sc = tail_score(ll, T);
       if (!(sc == sc)) continue;                          // a chain whose log-likelihood is not a number does not compete
-      r.n_ok += 1;
+      n_fin += 1;
       // strictly larger score wins, the earlier chain on ties (the reference's `<` at UserFunctions.cpp:320)
-      if (r.best.chain < 0 || r.best.score < sc) { r.best.score = sc; r.best.chain = r.chains[base + q]; sel = q; }
+      if (sel < 0 || sel_score < sc) { sel_score = sc; sel = q; }
     }
-    if (!h) continue;
-    if (sel >= 0) {
+    r.n_ok += n_fin;
+    if (sel >= 0 && (r.best.chain < 0 || r.best.score < sel_score)) {
+      if (bfmmm_select_chain(h, sel)) return fail_device(h);
       if (r.best.h) bfmmm_destroy(r.best.h);
       r.best.h = h;
-      (void)bfmmm_select_chain(h, sel);
+      r.best.score = sel_score;
+      r.best.chain = r.chains[base + sel];
     } else {
       bfmmm_destroy(h);
     }
+    base += (size_t)nb;
   }
 }
 
@@ -266,6 +286,11 @@ static int run_multi_try(const bfmmm_entry_args* a, const bfmmm_config& cfg, uin
   if (a->n_devices > 0 && a->devices) devs.assign(a->devices, a->devices + a->n_devices);
   else devs.push_back(a->device);
   const bool use_rccl = a->n_devices > 0 && a->devices;       // an explicit device list asks for the RCCL selection
+  for (size_t i = 0; i < devs.size(); ++i) {                   // checked before any chain runs
+    if (devs[i] < 0) return efail("device indices must not be negative");
+    for (size_t j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return efail("'devices' names a device twice: one chain batch per device");
+  }
   const size_t G = std::min(devs.size(), chains.size());
   std::vector<DevRun> runs(G);
   for (size_t g = 0; g < G; ++g) {
@@ -281,9 +306,11 @@ static int run_multi_try(const bfmmm_entry_args* a, const bfmmm_config& cfg, uin
   }
   auto cleanup = [&]() { for (DevRun& r : runs) if (r.best.h) { bfmmm_destroy(r.best.h); r.best.h = nullptr; } };
   int n_ok = 0;
-  std::string first_err;
-  for (DevRun& r : runs) { n_ok += r.n_ok; if (first_err.empty()) first_err = r.err; }
-  if (n_ok == 0) { cleanup(); return efail(first_err.empty() ? "no chain produced a finite log-likelihood" : first_err); }
+  for (DevRun& r : runs) {
+    if (!r.err.empty()) { const std::string e = r.err; cleanup(); return efail(e); }      // one failing batch fails the call
+    n_ok += r.n_ok;
+  }
+  if (n_ok == 0) { cleanup(); return efail("no chain produced a finite log-likelihood"); }
   size_t w = 0;
   if (use_rccl) {
     // ranks that hold a sampler take part; the winner's chain ends up in the first of them
