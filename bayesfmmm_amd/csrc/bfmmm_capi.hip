@@ -28,6 +28,8 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
+void launch_sweep_tables(const Ctx& c, hipStream_t st);
+size_t sweep_tab_ints(int A);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
 void launch_loglik_flush(const Ctx& c, hipStream_t st);
 void launch_fill_slots(const Ctx& c, double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
@@ -95,6 +97,7 @@ struct bfmmm_handle {
   int g_nsub = 1;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
+  int64_t tab_key = -1;                // (MD, mask) the step tables of k_sweep_chain were built for
   int launch_error = 0;
   bool g_valid = false;                // the captured graphs match (g_mask, g_md, g_seed, g_chain)
   int slot_base = 0;                   // chain slot of iteration i is i - slot_base (bfmmm_set_slot_base)
@@ -320,6 +323,9 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   double* rec; int* ni;
   if (dalloc(h, &rec, (size_t)n * d.LREC) || dalloc(h, &ni, n)) return 1;
   c.rec = rec; c.ni = ni;
+  int* stab;
+  if (dalloc(h, &stab, sweep_tab_ints(K * (M + 1)))) return 1;
+  c.sweep_tab = stab;
   // per-chain buffers (one arena per chain of the batch): state, work space, chain storage
   std::vector<ArenaReq> ar;
   areq(ar, &c.dyn, 1);
@@ -816,6 +822,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
   if (!prepare_only) {
+    const int64_t tkey = ((int64_t)MD << 32) | (mask & (U_PHI | U_NU));
+    if (h->tab_key != tkey) { launch_sweep_tables(c, h->st); h->tab_key = tkey; }
     // every chain of the batch starts the run at the same iteration
     hipLaunchKernelGGL(k_run_begin, dim3(h->nch), dim3(64), 0, h->st, h->c, (uint32_t)first_iter, (uint32_t)h->slot_base, tt_step, beta,
                        h->state_dirty ? 1 : 0);

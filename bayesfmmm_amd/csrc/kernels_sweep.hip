@@ -62,6 +62,13 @@ void fetch_wgtrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP
 
 constexpr int PG_THREADS = 512;   // 8 waves, two per SIMD: a wave's LDS reads and weight products issue while the other wave's MFMAs execute
                                   // (within one wave MFMA, VALU and LDS issue strictly in order: tools/ubench_mfma.hip)
+// H2: the band blocks as k_factor and the sweep read them.  Block r holds, for every row p, the 2 BW + 2 entries
+// e(p, k) = G(p, p + k - BW) (k = 2 BW + 1: a zero pad) PIECE-major: the 16-byte piece (e(p, 2 q), e(p, 2 q + 1)) of row p sits at
+// v2d index q P + p of the block, so that threads owning consecutive rows read consecutive 16-byte pieces (a row-major block
+// made every lane of a wave-wide load touch a cache line of its own: the loads of the sweep's row threads were bound by the
+// number of lines per instruction, not by bytes).
+__host__ __device__ inline int h2_index(int P, int p, int k) { return (((k >> 1) * P + p) << 1) + (k & 1); }
+
 template <bool BATCH, bool GROUPS>
 __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nks, int do_pg, int G) {
   // Chain batches (BATCH): the workgroup stages its record columns ONCE and walks the chains of the batch in groups of G
@@ -414,11 +421,11 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
       }
     } else if (row < d.R && col < d.LG) {
       c.H[(size_t)row * d.LG + col] = s;
-      // row-major copy for the sweep: entry k of row p is G(p, p + k - BW)
+      // copy for k_factor / the sweep (h2_index): entry k of row p is G(p, p + k - BW)
       const int dd = col / d.P, p0 = col - dd * d.P, W = 2 * d.BW + 2;
       double* h2 = c.H2 + (size_t)row * d.P * W;
-      h2[p0 * W + d.BW + dd] = s;
-      if (dd > 0 && p0 + dd < d.P) h2[(p0 + dd) * W + d.BW - dd] = s;
+      h2[h2_index(d.P, p0, d.BW + dd)] = s;
+      if (dd > 0 && p0 + dd < d.P) h2[h2_index(d.P, p0 + dd, d.BW - dd)] = s;
     }
   } else {
     const int t2 = t - n_pair_tiles;
@@ -535,9 +542,9 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 4 : 1) void k_factor(Ctx c0) {
       const int e = min(tid + 256 * it, AP - 1);
       const int b = e / P, p = e - b * P;
       tval[it] = c.theta[(size_t)full_dir(d, b) * P + p];
-      const v2d* row = (const v2d*)(c.H2 + ((size_t)hrow(d, a, b) * P + p) * W);
+      const v2d* blk = (const v2d*)(c.H2 + (size_t)hrow(d, a, b) * P * W);
 #pragma unroll
-      for (int k = 0; k <= BW; ++k) hreg[it][k] = row[k];
+      for (int k = 0; k <= BW; ++k) hreg[it][k] = blk[k * P + p];
     }
   }
   const double tv0 = c.tvec[a * P + min(tid >> 3, P - 1)];      // t_a[p] of the r-reduction's first pass
@@ -584,9 +591,9 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 4 : 1) void k_factor(Ctx c0) {
       for (int it = 0; it < MAXI; ++it) {
         const int e = min(base + tid + 256 * it, AP - 1);
         const int b = e / P, p = e - b * P;
-        const v2d* row = (const v2d*)(c.H2 + ((size_t)hrow(d, a, b) * P + p) * W);
+        const v2d* blk = (const v2d*)(c.H2 + (size_t)hrow(d, a, b) * P * W);
 #pragma unroll
-        for (int k = 0; k <= BW; ++k) hreg[it][k] = row[k];
+        for (int k = 0; k <= BW; ++k) hreg[it][k] = blk[k * P + p];
       }
     }
 #pragma unroll
@@ -1084,47 +1091,61 @@ __global__ __launch_bounds__(512) void k_sweep_diag(Ctx c0) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_sweep_fast: the same sweep for P <= 32 and A*P <= 1024 (every configuration of BASELINE.json).
-// The kernel is a chain of K*M + K dependent steps on one CU, so what matters is the length of the
-// per-step dependency chain, not throughput:
-//   * thread (b, p) owns r_b[p] and (H_bb theta_b)[p] in registers and reads its 2 BW + 1 entries of
-//     the band block H_{b,a} straight from L2 into registers, two steps ahead (no LDS staging);
-//   * C_a rhs is one FMA pair per lane (16 lanes per row) and a 4-step DPP reduction: no loops, no
-//     LDS traffic besides rhs;
-//   * two LDS-only barriers per step; all indices are computed once.
-// ---------------------------------------------------------------------------------------------
-
 __device__ inline const double* ptr_off(const double* base, uint32_t byte_off) {   // uniform base + 32-bit lane offset
   return (const double*)((const char*)base + byte_off);
 }
 
-// Software-managed prefetch.  The loads below are inline assembly, so the compiler neither tracks them nor
-// inserts s_waitcnt for them (its own placement drained the queue every step); sweep_wait<N> is the matching
-// wait: "at most N younger loads may still be in flight" -- vmcnt retires in issue order.  The loaded registers
-// pass through the wait as read-write operands, so no use can be scheduled above it.
-// The destination is a read-write operand: the register stays allocated to the variable across the load (the
-// compiler believes inline assembly completes synchronously; a write-only destination that is dead until its
-// next definition could be handed out as a temporary while the load is still in flight).
-template <int IMM>
-__device__ inline void sweep_ld16(v2d& r, const double* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
-}
-__device__ inline void sweep_ld8(double& r, const double* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(r) : "v"(voff), "s"(sbase));
-}
-
+// Software-managed prefetch of the chain wave.  The loads below are inline assembly, so the compiler neither tracks them nor
+// inserts s_waitcnt for them (its own placement drained the queue every step); swc_wait_* are the matching waits: "at most N
+// younger loads may still be in flight" -- vmcnt retires in issue order, and the chain wave issues the same loads in the same
+// order at every step.  The loaded registers pass through the wait as read-write operands, so no use can be scheduled above it.
+// The destination of a load is a read-write operand too: the register stays allocated to the variable across the load (the
+// compiler believes inline assembly completes synchronously; a write-only destination that is dead until its next definition
+// could be handed out as a temporary while the load is still in flight).
 template <int BW> struct SweepH { v2d h[BW + 1]; };
 
-// s_waitcnt vmcnt(N) that the loaded registers pass through (no use can be scheduled above it)
-// Every wait of k_sweep_fast is a FULL wait (vmcnt(0)), whatever N0 says.  The kernel was written with counted waits (N0 = the
-// loads of the younger prefetch group, left in flight); with a second handle keeping the GPU busy on another stream, one
-// run in five of a stand-alone chain then differed in sigma^2 (a residual term computed from a prefetched H row that had not
-// arrived; tests/test_gpu_concurrency.py).  With full waits -- one prefetch group in flight at a time
-// instead of two -- the runs are bit-identical under load and the kernel takes the same 22 us, so the counted waits bought nothing.
-template <int N0, int BW>
-__device__ inline void sweep_wait_h(SweepH<BW>& s) {
-  constexpr int N = 0;
+// ---------------------------------------------------------------------------------------------
+// k_sweep_chain: the register-resident sweep with the dependent chain in ONE wave (round 3; replaces k_sweep_fast, whose
+// step cost ~2000 clk: two cross-wave hand-offs through LDS flags and a 14-wave barrier sat on the chain of every step).
+//
+// Wave 0 is the chain.  Lane (p, h), p = lane >> 1, h = lane & 1.  Step st with direction a = a_st:
+//   mat-vec   theta_a <- C_a rhs + L_a z_a      lane (p, h) holds C_a(p, 16 h .. 16 h + 15) in registers (prefetched two
+//             steps ahead from L2), reads rhs(16 h ..) from LDS (broadcast), 16 FMAs on four accumulators, one DPP add
+//             joins the halves; delta_st -> LDS
+//   band dot  the h = 0 lanes hold r of the direction of step st + 1, the h = 1 lanes r of the direction of step st + 2:
+//             r -= H_{., a} delta_st from prefetched rows of H; the h = 0 lanes publish the next rhs; then the h = 1 value
+//             moves to the h = 0 lane (DPP) and the h = 1 lanes pick up the row of step st + 3
+// so both hand-offs of a step (delta -> band rows, rhs -> mat-vec rows) are LDS write / read pairs of the SAME wave: LDS
+// executes a wave's operations in order, there is no flag, no poll and no barrier on the chain.
+// The other waves ("row threads", thread 64 + rk P + p owns element p of the direction updated at step rk) do what is
+// off the chain: r_rk -= H delta_s for s <= rk - 3 (the chain applies the last two deltas itself), hand the row over, and
+// the row's term of the residual sum of squares, delta'(H_aa delta - 2 r_a), one step late.
+// Hand-offs between the chain and the row threads carry their own validity: every slot (delta of step s, row of rank rk,
+// r_a before its step) is written ONCE per launch into a slot of its own that starts as a NaN with a payload no arithmetic
+// produces (SW_SENT); a reader that finds the sentinel reads again (bounded: a spin that runs out sets status bit 2 and goes
+// on, so the grid always drains).  No ordering between different LDS locations is assumed anywhere.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long SW_SENT = 0x7FF8DEADBEEF5A5AULL;
+constexpr int SWC_SPIN_LIMIT = 1 << 15;
+constexpr int SWC_THREADS = 448;            // chain wave + A ceil(P / 2) <= 384 row threads (two rows each): two waves per SIMD, 256 VGPRs
+
+__device__ inline double lds_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline bool is_sent(double v) { return (unsigned long long)__double_as_longlong(v) == SW_SENT; }
+__device__ inline double sw_sent() { return __longlong_as_double((long long)SW_SENT); }
+template <int CTRL>
+__device__ inline double dpp_get(double v) {      // the value of another lane of the quad
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+struct SwcC { v2d v[8]; };
+template <int N>
+__device__ inline void swc_wait_c(SwcC& s) {      // at most N younger loads still in flight; the registers pass through
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]), "+v"(s.v[6]), "+v"(s.v[7]) : "n"(N));
+}
+template <int N, int BW>
+__device__ inline void swc_wait_h(SweepH<BW>& s) {
   if constexpr (BW == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.h[0]) : "n"(N));
   if constexpr (BW == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.h[0]), "+v"(s.h[1]) : "n"(N));
   if constexpr (BW == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]) : "n"(N));
@@ -1132,244 +1153,376 @@ __device__ inline void sweep_wait_h(SweepH<BW>& s) {
   if constexpr (BW == 4) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]) : "n"(N));
   if constexpr (BW == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]) : "n"(N));
 }
+__device__ inline void sweep_ld16v(v2d& r, const double* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(r) : "v"(voff), "s"(sbase));
+}
 
-// Thread layout: waves 0-3 (tid < 256) run the critical chain (phase A: theta_a <- C_a rhs + L_a z_a, 8 lanes
-// per row of C_a); threads 256 + e own element e = (b, p) of the stacked residual r.  Per step st with direction a:
-//   P1  waves 0-3 : theta_a, delta_st -> LDS                       | r threads: LAGGING update r_b -= H_{b,a'} delta_{st-1}
-//   P2  r threads of the NEXT direction only: r -= H delta_st, next rhs -> LDS   (the urgent 1/A-th of the update)
-// so the bulk of the memory traffic (H blocks from L2, delta from LDS) overlaps the dependent chain instead of
-// sitting on it.  H_{b,a} rows are prefetched into registers one to two steps ahead (sweep_ld16 / sweep_wait_h).
+// Step tables of k_sweep_chain, built once per (MD, mask) of a run (bfmmm_capi.hip::run_impl), shared by the chains of a batch:
+//   ent [2 (A + 2)] int4 : what lane half h of the chain wave needs for step st (entry 2 st + h):
+//                          .x byte offset in H2 of block (a_{st + 1 + h}, a_st), .y byte offset of C_{a_st} in Cmat, .z a_st P
+//   hstp[A x A]          : hstp[b A + s] = byte offset in H2 of block (b, a_s), a_s = direction of step s
+// (their integer divisions cost the sweep kernel 1.6 us of its set-up when it built them itself)
+size_t sweep_tab_ints(int A) { return (size_t)A * A + 8 * ((size_t)A + 2); }
+__host__ __device__ inline int sweep_n_phi(const Dims& d, uint32_t mask) { return ((mask & U_PHI) && d.MD > 1) ? d.K * d.M : 0; }
+__host__ __device__ inline int sweep_n_nu(const Dims& d, uint32_t mask) { return (mask & U_NU) ? d.K : 0; }
+
+__global__ void k_sweep_tables(Ctx c, int* tab) {
+  const Dims& d = c.d;
+  const int A = d.A, P = d.P, W = 2 * d.BW + 2;
+  const int n_phi = sweep_n_phi(d, c.mask), n_steps = n_phi + sweep_n_nu(d, c.mask);
+  int4* ent = (int4*)tab;
+  int* hstp = tab + 8 * (A + 2);
+  for (int x = threadIdx.x; x < 2 * (A + 2); x += blockDim.x) {
+    const int st = x >> 1, hh = x & 1;
+    const int a = step_dir(d, min(st, max(n_steps - 1, 0)), n_phi), bb = step_dir(d, min(st + 1 + hh, max(n_steps - 1, 0)), n_phi);
+    ent[x] = make_int4(hrow(d, bb, a) * P * W * 8, a * P * P * 8, a * P, 0);
+  }
+  for (int x = threadIdx.x; x < A * A; x += blockDim.x)
+    hstp[x] = hrow(d, x / A, step_dir(d, min(x % A, max(n_steps - 1, 0)), n_phi)) * P * W * 8;
+}
+void launch_sweep_tables(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_sweep_tables, dim3(1), dim3(256), 0, st, c, (int*)c.sweep_tab); }
+
+// direction that owns rank rk: ranks follow the order of the steps (Phi sweep j outer, m inner, then the nu sweep), the
+// directions a sweep does not update come last
+__device__ inline int rank_dir(const Dims& d, int rk, int n_phi, int n_nu) {
+  const int n_steps = n_phi + n_nu;
+  if (rk < n_steps) return step_dir(d, rk, n_phi);
+  const int x = rk - n_steps;
+  if (n_phi == 0 && n_nu == 0) return x;                       // nothing is updated: rank = direction
+  if (n_nu == 0) return x * d.MD;                               // the nu directions of a Phi-only sweep
+  if (d.MD == 1) return x;                                      // (no Phi directions at all)
+  const int jx = x / (d.MD - 1);                                // the Phi directions of a nu-only sweep
+  return jx * d.MD + 1 + (x - jx * (d.MD - 1));
+}
+
 template <int BW>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
+__global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;
   constexpr int W = 2 * BW + 2;              // doubles per row of an H2 block
-  constexpr int DLS = 32 + 2 * BW + 2;       // one delta buffer: BW zero pads | 32 | BW + 2 zero pads
+  constexpr int DLS = 32 + 2 * BW + 2;       // one delta slot: BW zero pads | 32 | BW + 2 zero pads
+  constexpr int NC = 8, NH = BW + 1;         // loads per step of the chain wave: C pieces, H row pieces
   const int tid = threadIdx.x, nthr = blockDim.x;
   Dyn* dyn = c.dyn;
-  const int AP = A * P;
-  double* th = smem;                         // A x P   theta of the active directions
-  double* lz = th + AP;                      // A x P   L_a z_a
-  double* rhs = lz + AP;                     // 32 (zero beyond P)
-  double* dlp = rhs + 32;                    // 2 x DLS, by step parity
-  double* red = dlp + 2 * DLS;               // 16
-  int* htab = (int*)(red + 16);              // A x A : byte offset of block (b, a) in H2
-  int* sdir = htab + A * A;                  // directions of the steps (clamped tail), K*(M+1) + 8 entries
-  int* brank = sdir + K * (M + 1) + 8;       // direction owning rank r (ranks follow the order of the steps)
-  int* flag = brank + K * (M + 1);           // phase-A waves that have published the current step's delta
-  const uint32_t slot = dyn->slot;
+  const int AP = A * P, PH = (P + 1) >> 1;
+  const int APe = (AP + 1) & ~1;             // (16-byte alignment of what follows)
+  double* th = smem;                         // A x P   theta, direction-major (theta_0, then the new values)
+  double* lzs = th + APe;                    // A x P   L_a z_a
+  double* hqs = lzs + APe;                   // A x P   H_aa theta_a(0)
+  double* pick = hqs + APe;                  // A x P   rank-major: r of rank rk with the deltas of the steps <= rk - 3 applied
+  double* rbef = pick + APe;                 // A x P   rank-major: r of rank rk just before its step
+  double* rhs = rbef + APe;                  // 32 (zero beyond P)
+  double* dl = rhs + 32;                     // A slots of DLS: delta of step s
+  double* red = dl + A * DLS;                // 16
+  int4* ent = (int4*)(red + 16);             // 2 (A + 2): what lane half h of the chain needs for step st
+  int* hstp = (int*)(ent + 2 * (A + 2));     // A x A : hstp[b A + s] = byte offset of block (b, a_s) in H2, a_s = direction of step s
   const uint32_t mask = c.mask;
-  const double beta = dyn->beta;
-  const double f = beta / dyn->sigma2;
-  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
-  const int n_phi = ((mask & U_PHI) && MD > 1) ? K * M : 0;
-  const int n_nu = (mask & U_NU) ? K : 0;
+  const int n_phi = sweep_n_phi(d, mask), n_nu = sweep_n_nu(d, mask);
   const int n_steps = n_phi + n_nu;
-  const bool waveA = tid < 256;              // wave-uniform
-  const bool isA = tid < 8 * P;
-  const int pa = min(tid >> 3, P - 1), q = tid & 7;
-  // residual rows are owned in the ORDER OF THE STEPS: thread 256 + rk * P + p holds r_b[p] of the direction b that
-  // is updated at step rk (directions that are not updated this sweep come last).  A step only has to push its
-  // delta into the rows whose turn is still ahead -- the conditional mean of a direction never looks at r again
-  // after its own step, and the residual sum of squares is carried incrementally (see rss_acc) -- so the traffic
-  // of the off-chain updates halves and whole waves retire as the sweep advances.
-  {
-    const bool none_phi = (n_phi == 0 && MD > 1), none_nu = (n_nu == 0);
-    const int per_j = (none_phi ? MD - 1 : 0) + (none_nu ? 1 : 0);
-    for (int x = tid; x < A; x += nthr) {
-      const int jx = x / MD, mx = x - jx * MD;
-      int rk;
-      if (mx >= 1 && !none_phi) rk = jx * M + mx - 1;
-      else if (mx == 0 && !none_nu) rk = n_phi + jx;
-      else rk = n_steps + jx * per_j + ((mx >= 1) ? (none_nu ? 1 : 0) + mx - 1 : 0);
-      brank[rk] = x;
-    }
-  }
-  __syncthreads();
-  const bool isB = tid >= 256 && tid - 256 < AP;
-  const int e = min(max(tid - 256, 0), AP - 1);
-  const int rk = e / P, p = e - rk * P;
-  const int b = brank[rk];
-  uint32_t coff[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) coff[u] = (uint32_t)(pa + P * min(q + 8 * u, P - 1)) * 8u;
-  const uint32_t hoff = (uint32_t)p * (W * 8u);
-  const uint32_t cstride = (uint32_t)(P * P) * 8u;
+  const bool chainw = tid < 64;              // wave-uniform
+#ifndef SWC_NOPRIO
+  if (chainw) __builtin_amdgcn_s_setprio(3);
+#endif
+  // ---- ONE round of global loads: the run's step tables, the iteration's scalars, and every thread's rows ----
+  const int4* gent = (const int4*)c.sweep_tab;
+  const int* ghstp = c.sweep_tab + 8 * (A + 2);
+  // row thread 64 + rk PH + pp owns rows p0 = 2 pp and p0 + 1 of the direction updated at step rk
+  const bool isB = tid >= 64 && tid - 64 < A * PH;
+  const int e2i = min(max(tid - 64, 0), A * PH - 1);
+  const int rk = e2i / PH, p0 = 2 * (e2i - rk * PH);
+  const bool two = p0 + 1 < P;               // (odd P: the last thread of a rank owns one row)
+  const int p1 = two ? p0 + 1 : p0;
+  const int b = rank_dir(d, rk, n_phi, n_nu);
   const int fd = full_dir(d, b);
-  double r_e = 0.0, hq_e = 0.0, tv_e = 0.0;
-  const int eb = b * P + p;                  // element of the direction-major vectors
-  double rss_acc = 0.0;                      // this thread's share of RSS - YY
-  if (!waveA) {
-    r_e = c.rvec[eb]; hq_e = c.hq[eb]; tv_e = c.tvec[eb];
-    const double t0 = c.theta[(size_t)fd * P + p], l0 = c.Lz[eb];
-    if (isB) { th[eb] = t0; lz[eb] = l0; rss_acc = -(t0 * (tv_e + r_e)); }   // RSS(theta_0) = YY - theta_0'(t + r_0)
-  }
-  if (tid < 32) rhs[tid] = 0.0;
-  if (tid == 0) *flag = 0;
-  if (tid < 2 * DLS) dlp[tid] = 0.0;
-  for (int x = tid; x < A * A; x += nthr) htab[x] = hrow(d, x / A, x % A) * P * W * 8;
-  for (int x = tid; x < n_steps + 4; x += nthr) sdir[x] = step_dir(d, min(x, n_steps - 1), n_phi);
+  const int eb = b * P + p0, er = rk * P + p0;     // element of the direction-major / rank-major vectors
+  // the chain wave: its first table entries straight into registers, so that its first C / H loads are in flight during the set-up
+  const int hch = (tid >> 1) & 1;
+  int4 ge0 = make_int4(0, 0, 0, 0), ge1 = ge0, ge2 = ge0;
+  if (chainw && n_steps > 0) { ge0 = gent[hch]; ge1 = gent[2 + hch]; ge2 = gent[2 * min(2, n_steps + 1) + hch]; }
+  const uint32_t slot = dyn->slot;
+  const double beta = dyn->beta;
+  const double sig2 = dyn->sigma2;
   const double sig_g = (mask & U_SIGMA) ? c.gstd[hyper_gstd_count(d)] : 0.0;
-  // H2 and C were written by other XCDs (k_pg_reduce, k_factor): a first touch costs a trip to HBM, far longer
-  // than a step of the chain.  Touch both once with fire-and-forget wide loads so that the per-step register
-  // prefetch only ever sees L2 hits.
-  if (n_steps > 0) {
-    // one 4-byte load per 128-byte line is enough to pull the line in
-    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    auto touch = [&](const double* src, int count) {
-      const int nl = (count * 8 + 127) / 128;          // lines
-      const uint32_t lim = (uint32_t)count * 8u - 4u;
-      for (int x = tid; x < nl; x += 4 * nthr) {
-        const uint32_t o = (uint32_t)x * 128u, st4 = (uint32_t)nthr * 128u;
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(w0) : "v"(o), "s"(src));
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(w1) : "v"(min(o + st4, lim)), "s"(src));
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(w2) : "v"(min(o + 2 * st4, lim)), "s"(src));
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(w3) : "v"(min(o + 3 * st4, lim)), "s"(src));
-      }
-    };
-    touch(c.H2, d.R * P * W);
-    touch(c.Cmat, A * P * P);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) :: "memory");
+  double r_0 = 0.0, r_1 = 0.0, rss_acc = 0.0;      // rss_acc: this thread's share of RSS - YY
+  double hq_0 = 0.0, hq_1 = 0.0, tv_0 = 0.0, tv_1 = 0.0, t_0 = 0.0, t_1 = 0.0, l_0 = 0.0, l_1 = 0.0;
+  if (!chainw) {
+    r_0 = c.rvec[eb]; r_1 = c.rvec[b * P + p1];
+    hq_0 = c.hq[eb]; hq_1 = c.hq[b * P + p1]; tv_0 = c.tvec[eb]; tv_1 = c.tvec[b * P + p1];
+    t_0 = c.theta[(size_t)fd * P + p0]; t_1 = c.theta[(size_t)fd * P + p1]; l_0 = c.Lz[eb]; l_1 = c.Lz[b * P + p1];
+  }
+  // (the tables go through registers: two entries of each kind per thread cover A <= 21; the loops take the rest)
+  const int n_ent = 2 * (A + 2), n_hs = A * A;
+  int4 ge_a = make_int4(0, 0, 0, 0);
+  int gh_a = 0, gh_b = 0;
+  if (tid < n_ent) ge_a = gent[tid];
+  if (tid < n_hs) gh_a = ghstp[tid];
+  if (tid + nthr < n_hs) gh_b = ghstp[tid + nthr];
+  if (tid == 0) { dyn->iter_hyper = dyn->iter; dyn->slot_hyper = slot; }
+  const double f = beta / sig2;
+  // ---- LDS initialisation while the loads are in flight
+  if (tid < 32) rhs[tid] = 0.0;
+  for (int x = tid; x < A * DLS; x += nthr) {
+    const int k = x % DLS;
+    dl[x] = (k >= BW && k < BW + P) ? sw_sent() : 0.0;
+  }
+  if (tid < n_ent) ent[tid] = ge_a;
+  for (int x = tid + nthr; x < n_ent; x += nthr) ent[x] = gent[x];
+  if (tid < n_hs) hstp[tid] = gh_a;
+  if (tid + nthr < n_hs) hstp[tid + nthr] = gh_b;
+  for (int x = tid + 2 * nthr; x < n_hs; x += nthr) hstp[x] = ghstp[x];
+  if (isB) {
+    th[eb] = t_0; lzs[eb] = l_0; hqs[eb] = hq_0;
+    rss_acc = -(t_0 * (tv_0 + r_0));       // RSS(theta_0) = YY - theta_0'(t + r_0)
+    // ranks 0 .. 2 (no delta to apply first) and the directions that are not updated are handed over at once
+    const bool now = (rk <= 2 || rk >= n_steps);
+    pick[er] = now ? r_0 : sw_sent();
+    rbef[er] = (rk == 0) ? r_0 : sw_sent();
+    if (two) {
+      th[eb + 1] = t_1; lzs[eb + 1] = l_1; hqs[eb + 1] = hq_1;
+      rss_acc -= t_1 * (tv_1 + r_1);
+      pick[er + 1] = now ? r_1 : sw_sent();
+      rbef[er + 1] = (rk == 0) ? r_1 : sw_sent();
+    }
+  }
+  TSTAMP0(c, 28);
+  // the chain wave's per-lane constants and its first loads (C and H of steps 0 and 1) before the barrier
+  const int pp = tid >> 2, g = tid & 3, h = hch;
+  const int pbl = 2 * pp + (tid & 1), pb = min(pbl, P - 1);
+  const bool wr = (h == 0) && (pbl < P);
+  const int ppc = min(2 * pp, max(P - 2, 0));           // first row of the pair, clamped (a pair never leaves its matrix row)
+  uint32_t coff[NC];
+#pragma unroll
+  for (int u = 0; u < NC; ++u) coff[u] = (uint32_t)(ppc + P * min(8 * g + u, P - 1)) * 8u;     // C(q, p), C(q, p + 1) = C(p, q), C(p + 1, q)
+  const bool sel_y = (tid & 1) || (2 * pp < P && ppc < 2 * pp);      // odd P: the last row sits in the SECOND slot of the clamped pair
+  uint32_t hoffk[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) hoffk[k] = (uint32_t)(k * P + pb) * 16u;      // piece k of row pb (h2_index)
+  auto issueC = [&](SwcC& s, int cbase) {
+#ifndef SWC_NO_LOADS
+#pragma unroll
+    for (int u = 0; u < NC; ++u) sweep_ld16v(s.v[u], c.Cmat, (uint32_t)cbase + coff[u]);
+#endif
+  };
+  auto issueH = [&](SweepH<BW>& s, int hbase) {
+#ifndef SWC_NO_LOADS
+#pragma unroll
+    for (int k = 0; k < NH; ++k) sweep_ld16v(s.h[k], c.H2, (uint32_t)hbase + hoffk[k]);
+#endif
+  };
+  SwcC c0s = {}, c1s = {};
+  SweepH<BW> h0s = {}, h1s = {};
+  if (chainw && n_steps > 0) {
+    // (the compiler waits for ge0 / ge1 here; everything issued above is older and already on its way)
+    // the issue order of the steady state: C(st), H(st), C(st + 1), H(st + 1)
+    issueC(c0s, ge0.y); issueH(h0s, ge0.x); issueC(c1s, ge1.y); issueH(h1s, ge1.x);
   }
   __syncthreads();
-  // the explicit waits below start from an empty queue; naming the registers that the setup loaded makes
-  // the compiler place its own (tracked) waits for them here instead of inside the loop
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r_e), "+v"(hq_e), "+v"(tv_e) :: "memory");
-  auto issueH = [&](SweepH<BW>& s, int a) {      // branch-free: every lane reads a valid address
-    const uint32_t off = (uint32_t)htab[b * A + a] + hoff;
-    sweep_ld16<0>(s.h[0], c.H2, off);
-    if constexpr (BW >= 1) sweep_ld16<16>(s.h[1], c.H2, off);
-    if constexpr (BW >= 2) sweep_ld16<32>(s.h[2], c.H2, off);
-    if constexpr (BW >= 3) sweep_ld16<48>(s.h[3], c.H2, off);
-    if constexpr (BW >= 4) sweep_ld16<64>(s.h[4], c.H2, off);
-    if constexpr (BW >= 5) sweep_ld16<80>(s.h[5], c.H2, off);
-  };
-  auto band_dot = [&](const SweepH<BW>& s, const double* dl) {   // sum_k H(p, p + k - BW) delta[p + k - BW]
-    double dv[2 * BW + 2];
-#pragma unroll
-    for (int k = 0; k < 2 * BW + 2; ++k) dv[k] = dl[k];
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k <= BW; ++k) v += s.h[k].x * dv[2 * k] + s.h[k].y * dv[2 * k + 1];     // last .y is the zero pad
-    return v;
-  };
-  struct CSet { double v[4]; };
-  auto issueC = [&](CSet& s, int a) {
-    const uint32_t base = (uint32_t)a * cstride;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) sweep_ld8(s.v[u], c.Cmat, base + coff[u]);
-  };
-  // one step.  PAR = parity of the step (delta buffer written), `a` its direction, an = next direction (-1: none),
-  // aprev = previous direction (-1: none), a2 = direction two steps ahead (prefetch target).
-  //   cs : C_a values (waves 0-3), refilled with C_{a2}
-  //   hl : H_{b, aprev} (lagging update), refilled with H_{b, an}... see the call sites for the rotation
 #ifdef BFMMM_TIMELINE
-  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = clock64();
-#define SWT(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tlast; tlast = now_; } while (0)
   if (tid == 0) dyn->stamps[24] = wall_clock64();
-#else
-#define SWT(i) do { } while (0)
+  unsigned long long n_spin = 0;
 #endif
-  // One barrier per step.  Within a step the only hand-off that is on the dependent chain -- delta_st from the four
-  // phase-A waves to the rows of the NEXT direction -- goes through an LDS counter (each phase-A wave bumps it after
-  // its delta entries are written; LDS operations of a wave are processed in issue order), so the waves that only do
-  // off-chain work never make the chain wait for them in the middle of a step.
-  auto step = [&](int st, int par, CSet& cs, SweepH<BW>& h_lag, SweepH<BW>& h_cur, int a, int an, int aprev, int a_refill) {
-    double* dl_w = dlp + par * DLS;                  // written by phase A of this step
-    const double* dl_prev = dlp + (par ^ 1) * DLS;   // delta of the previous step
-    SWT(0);
-    if (waveA) {
-      // ---- critical chain: theta_a <- C_a rhs + L_a z_a
-      const double lza = lz[a * P + pa], tha = th[a * P + pa];
-      const double x0 = rhs[q], x1 = rhs[q + 8], x2 = rhs[q + 16], x3 = rhs[q + 24];
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs.v[0]), "+v"(cs.v[1]), "+v"(cs.v[2]), "+v"(cs.v[3]));   // (full wait: see sweep_wait_h)
-      double acc = (cs.v[0] * x0 + cs.v[1] * x1) + (cs.v[2] * x2 + cs.v[3] * x3);
-      issueC(cs, a_refill);
-      acc = dpp_add<0xB1>(acc);     // quad_perm [1,0,3,2]
-      acc = dpp_add<0x4E>(acc);     // quad_perm [2,3,0,1]
-      acc = dpp_add<0x141>(acc);    // row_half_mirror: the 8 lanes of a row now hold its sum
-      if (isA && q == 0) {
-        const double nw = acc + lza;
-        dl_w[BW + pa] = nw - tha;
-        th[a * P + pa] = nw;
-      }
-      if ((tid & 63) == 0) atomicAdd(flag, 1);       // after this wave's delta entries (same wave, LDS is in order)
-    } else {
-      const bool lag = isB && rk > st + 1 && rk < n_steps, own = isB && rk == st - 1;
-      const bool next_rows = isB && an >= 0 && (rk == st + 1 || rk == st + 2);
-      const bool wave_next = __builtin_amdgcn_ballot_w64(next_rows) != 0;
-      const bool wave_live = __builtin_amdgcn_ballot_w64(isB && rk + 1 >= st && rk < n_steps) != 0;
-      if (wave_next) {
-        // ---- the rows of the next direction (and of the one after it) take this step's delta as soon as it exists;
-        //      the next direction's rows then publish the next rhs
-        sweep_wait_h<0, BW>(h_cur);                  // the youngest group (issued one step ago)
-        const int target = 4 * (st + 1);
-        // (a workgroup-scope atomic load, not a volatile one: the address-space inference leaves volatile accesses generic,
-        //  and a FLAT load of the flag goes through the vector-memory path on every poll)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
-        if (next_rows) {
-          r_e -= band_dot(h_cur, dl_w + p);
-          if (rk == st + 1) rhs[p] = f * (r_e + hq_e);
-        }
-      }
-      if (wave_live) {
-        // ---- off the chain: the previous step's delta for the rows further ahead, and its RSS term
-        sweep_wait_h<BW + 1, BW>(h_lag);             // younger: h_cur's group
-        const double v = band_dot(h_lag, dl_prev + p);
-        if (lag && aprev >= 0) r_e -= v;
-        // RSS(theta + delta e_a) - RSS(theta) = delta'(H_aa delta - 2 r_a), r_a taken before the step
-        if (own) rss_acc += dl_prev[BW + p] * (v - 2.0 * r_e);
-        issueH(h_lag, an >= 0 ? an : a);             // becomes H_{b, a_next}
-      }
-    }
-    SWT(3);
-    lds_barrier();
-    SWT(4);
-  };
-  if (n_steps > 0) {
-    const int a0 = sdir[0];
-    if (isB && rk == 0) rhs[p] = f * (r_e + hq_e);
-    CSet c0 = {}, c1 = {};
-    SweepH<BW> h0 = {}, h1 = {};             // h0 = H_{b, a_st} for even st, h1 for odd st
+  if (n_steps > 0 && chainw) {
+    // ================= the chain wave =================
+    // mat-vec role of lane l: rows 2 pp, 2 pp + 1 (pp = l >> 2), columns q = 8 g .. 8 g + 7 (g = l & 3)
+    // band role of lane l   : row pb = 2 pp + (l & 1), rank half h = (l >> 1) & 1
+    int4 e0 = ge0, e1 = ge1, e2 = ge2;
+    // rank 0 is complete: its rhs; the h = 0 lanes then hold rank 1, the h = 1 lanes rank 2
     {
-      const int a1i = sdir[1];
-      if (waveA) { issueC(c0, a0); issueC(c1, a1i); }
-      else { issueH(h0, a0); issueH(h1, a1i); }     // same issue order as the steady state
+      const double r0 = pick[pb], hq0 = hqs[e0.z + pb];
+      if (wr) rhs[pb] = f * (r0 + hq0);
     }
-    lds_barrier();
-    int a = __builtin_amdgcn_readfirstlane(sdir[0]), a1 = __builtin_amdgcn_readfirstlane(sdir[1]);
-    int a2 = __builtin_amdgcn_readfirstlane(sdir[2]), a3 = __builtin_amdgcn_readfirstlane(sdir[3]);
-    int aprev = -1;
-    // step st (even): P1 lagging uses H_{b, a_{st-1}} = h1, then h1 <- H_{b, a_{st+1}};  P2 uses H_{b, a_st} = h0.
-    // step st+1     : P1 lagging uses h0 (H_{b, a_st}), then h0 <- H_{b, a_{st+2}};       P2 uses h1.
-    for (int st = 0; st < n_steps; st += 2) {
-      const int v4 = sdir[min(st + 4, n_steps + 2)], v5 = sdir[min(st + 5, n_steps + 3)];   // consumed after the steps
-      step(st, 0, c0, h1, h0, a, (st + 1 < n_steps) ? a1 : -1, aprev, a2);
-      if (st + 1 < n_steps) step(st + 1, 1, c1, h0, h1, a1, (st + 2 < n_steps) ? a2 : -1, a, a3);
-      aprev = a1; a = a2; a1 = a3;
-      a2 = __builtin_amdgcn_readfirstlane(v4); a3 = __builtin_amdgcn_readfirstlane(v5);
-    }
-#ifdef BFMMM_TIMELINE
-    if (tid == 0) { dyn->stamps[25] = wall_clock64(); for (int x = 0; x < 5; ++x) dyn->stamps[26 + x] = tk[x]; }
-    if (tid == 256) for (int x = 0; x < 5; ++x) dyn->stamps[10 + x] = tk[x];
+    double r = pick[min((1 + h) * P + pb, AP - 1)];
+    double lz0 = lzs[e0.z + pb], th0 = th[e0.z + pb];
+    double hq1 = hqs[e1.z + pb];                    // H_aa theta_a of the direction of step st + 1
+    asm volatile("" ::: "memory");
+    auto step = [&](int st, SwcC& cs, SweepH<BW>& hs) {
+      // ---- mat-vec operands first: rhs was written at the end of the previous step
+      const v2d* rv = (const v2d*)(rhs + 8 * g);
+      v2d x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = rv[u];
+      // ---- small reads for later in this step / the next ones (no address here depends on a read of this step)
+      const int4 e3 = ent[2 * min(st + 3, n_steps + 1) + h];
+      const double lz1 = lzs[e1.z + pb], th1 = th[e1.z + pb];
+      const double hq2 = hqs[e2.z + pb];
+      // the row the h = 1 lanes take over for this step's band dot: rank st + 2, which the row threads hand over with the
+      // deltas of the steps <= st - 1 applied (published a whole step ago); the read is checked just before its use
+#ifdef SWC_NO_HELPERS
+      const bool want_pick = false;
+#else
+      const bool want_pick = (st >= 1) && (st + 2 < n_steps);
 #endif
-    // RSS term of the last step (its delta does not have to reach any residual row any more)
-    if (!waveA) {
-      const int last = n_steps - 1;
-      if (last & 1) { sweep_wait_h<0, BW>(h1); if (isB && rk == last) rss_acc += dlp[DLS + BW + p] * (band_dot(h1, dlp + DLS + p) - 2.0 * r_e); }
-      else { sweep_wait_h<0, BW>(h0); if (isB && rk == last) rss_acc += dlp[BW + p] * (band_dot(h0, dlp + p) - 2.0 * r_e); }
+      const double* pk_ptr = pick + min((st + 2) * P + pb, AP - 1);
+      double pk = lds_ld(pk_ptr);
+      swc_wait_c<NH + NC + NH>(cs);
+      // cs.v[u] = (C(p, q), C(p + 1, q)), q = 8 g + u: four chains
+      v2d s0 = cs.v[0] * x[0].x, s1 = cs.v[1] * x[0].y;
+#pragma unroll
+      for (int u = 1; u < 4; ++u) { s0 += cs.v[2 * u] * x[u].x; s1 += cs.v[2 * u + 1] * x[u].y; }
+      issueC(cs, e2.y);
+      const v2d ss = s0 + s1;
+      // sum over the four column groups of the quad (every lane of the quad ends with the same two sums), then this lane's row
+      double a_x = ss.x, a_y = ss.y;
+      a_x += dpp_get<0xB1>(a_x); a_y += dpp_get<0xB1>(a_y);       // quad_perm [1, 0, 3, 2]
+      a_x += dpp_get<0x4E>(a_x); a_y += dpp_get<0x4E>(a_y);       // quad_perm [2, 3, 0, 1]
+      const double acc = sel_y ? a_y : a_x;
+      const double nw = acc + lz0;
+      const double dlt = nw - th0;
+      double* dls = dl + st * DLS;
+      if (wr) { dls[BW + pb] = dlt; th[e0.z + pb] = nw; }
+      asm volatile("" ::: "memory");
+      // ---- band dot: the rows of the next two directions take delta_st
+      double dv[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) dv[k] = dls[pb + k];
+      if (h == 1 && want_pick) {
+        int spins = 0;
+#pragma nounroll
+        while (is_sent(pk)) {
+          if (++spins > SWC_SPIN_LIMIT) {       // (the extra memory operation would shift the counted waits: drain)
+            atomicOr(&dyn->status, 2u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            break;
+          }
+          pk = lds_ld(pk_ptr);
+#ifdef BFMMM_TIMELINE
+          ++n_spin;
+#endif
+        }
+        r = pk;
+      }
+      swc_wait_h<NC + NH + NC, BW>(hs);
+      double v0 = hs.h[0].x * dv[0], v1 = hs.h[0].y * dv[1];
+#pragma unroll
+      for (int k = 1; k <= BW; ++k) { v0 += hs.h[k].x * dv[2 * k]; v1 += hs.h[k].y * dv[2 * k + 1]; }      // last .y is the zero pad
+      issueH(hs, e2.x);
+      r -= (v0 + v1);
+      if (wr && st + 1 < n_steps) { rhs[pb] = f * (r + hq1); rbef[(st + 1) * P + pb] = r; }
+      asm volatile("" ::: "memory");
+      // ---- the h = 1 value (rank st + 2, delta_st applied) moves to the h = 0 lane; the h = 1 lanes take the next row over
+      //      at the next step
+      const double rsw = dpp_get<0x4E>(r);            // quad_perm [2, 3, 0, 1]: lane l ^ 2 (same row, other half)
+      if (h == 0) r = rsw;
+      e0 = e1; e1 = e2; e2 = e3; lz0 = lz1; th0 = th1; hq1 = hq2;
+    };
+    for (int st = 0; st < n_steps; st += 2) {
+      step(st, c0s, h0s);
+      if (st + 1 < n_steps) step(st + 1, c1s, h1s);
     }
     // drain the prefetches of the (clamped) tail before their registers are reused
-    sweep_wait_h<0, BW>(h0);
-    sweep_wait_h<0, BW>(h1);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0.v[0]), "+v"(c0.v[1]), "+v"(c0.v[2]), "+v"(c0.v[3]), "+v"(c1.v[0]), "+v"(c1.v[1]), "+v"(c1.v[2]), "+v"(c1.v[3]) :: "memory");
+    swc_wait_c<0>(c0s); swc_wait_c<0>(c1s);
+    swc_wait_h<0, BW>(h0s); swc_wait_h<0, BW>(h1s);
+#ifdef BFMMM_TIMELINE
+    if (tid == 2) { dyn->stamps[25] = wall_clock64(); dyn->stamps[26] = n_spin; }
+#endif
+  } else if (n_steps > 0) {
+    // ================= the row threads =================
+    const bool live = isB && rk < n_steps;
+    int rk_hi = live ? rk : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rk_hi = max(rk_hi, __shfl_xor(rk_hi, o, 64));
+    int rk_lo = live ? rk : (1 << 20);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rk_lo = min(rk_lo, __shfl_xor(rk_lo, o, 64));
+    const int* hs_b = hstp + b * A;                  // hs_b[s] = byte offset of block (b, a_s) in H2
+    struct H2r { SweepH<BW> a, b; };
+    auto loadH = [&](H2r& s, int off) {
+#ifndef SWC_HELPER_NOLOAD
+      const v2d* blk = (const v2d*)((const char*)c.H2 + (uint32_t)off);
+#pragma unroll
+      for (int k = 0; k <= BW; ++k) { s.a.h[k] = blk[k * P + p0]; s.b.h[k] = blk[k * P + p1]; }
+#endif
+    };
+    // The steps the WAVE walks (wave-uniform): 0 .. rk_hi - 3 (some lane's lagging update), then rk_lo .. rk_hi (some lane's
+    // own term).  Every lane loads the rows of H_{b, a_s} for every step of the wave, one step ahead, so that the two register
+    // sets alternate without a copy; a lane uses the result when the step is one of its own: s <= rk - 3 or s == rk.
+    auto next_w = [&](int s) { return (s + 1 <= rk_hi - 3 || s + 1 >= rk_lo) ? s + 1 : rk_lo; };
+    auto process = [&](int s, const H2r& hc) {
+      const bool mine = live && (s <= rk - 3 || s == rk);
+      const double* dls = dl + s * DLS;
+      {
+        int spins = 0;
+#pragma nounroll
+        while (is_sent(lds_ld(dls + BW))) {
+#ifdef SWC_SLEEP
+          __builtin_amdgcn_s_sleep(SWC_SLEEP);
+#else
+          __builtin_amdgcn_s_sleep(1);
+#endif
+          if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, 2u); break; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      double dv[W + 1], va, vb;
+      int tries = 0;
+#pragma nounroll
+      do {
+#pragma unroll
+        for (int k = 0; k <= W; ++k) dv[k] = lds_ld(dls + p0 + k);
+        double a0 = hc.a.h[0].x * dv[0], a1 = hc.a.h[0].y * dv[1], b0 = hc.b.h[0].x * dv[1], b1 = hc.b.h[0].y * dv[2];
+#pragma unroll
+        for (int k = 1; k <= BW; ++k) {
+          a0 += hc.a.h[k].x * dv[2 * k]; a1 += hc.a.h[k].y * dv[2 * k + 1];
+          b0 += hc.b.h[k].x * dv[2 * k + 1]; b1 += hc.b.h[k].y * dv[2 * k + 2];
+        }
+        va = a0 + a1; vb = b0 + b1;
+        // a delta slot still holding the sentinel makes the sum a NaN: read again (the first element was seen, the rest of
+        // the chain's one store instruction follows within cycles)
+        bool bad = false;
+        if (va != va || vb != vb) {
+#pragma unroll
+          for (int k = 0; k <= W; ++k) bad = bad || is_sent(dv[k]);
+        }
+        if (!__builtin_amdgcn_ballot_w64(mine && bad)) break;
+      } while (++tries < SWC_SPIN_LIMIT);
+      if (mine) {
+        if (s == rk) {
+          // RSS(theta + delta e_a) - RSS(theta) = delta'(H_aa delta - 2 r_a), r_a taken before the step
+          double rb0 = lds_ld(rbef + er), rb1 = lds_ld(rbef + rk * P + p1);
+          int spins = 0;
+#pragma nounroll
+          while (is_sent(rb0) || is_sent(rb1)) {
+            if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, 2u); break; }
+            rb0 = lds_ld(rbef + er); rb1 = lds_ld(rbef + rk * P + p1);
+          }
+          rss_acc += dv[BW] * (va - 2.0 * rb0);
+          if (two) rss_acc += dv[BW + 1] * (vb - 2.0 * rb1);
+        } else {
+          r_0 -= va; r_1 -= vb;
+          if (s == rk - 3) { pick[er] = r_0; if (two) pick[er + 1] = r_1; }
+        }
+      }
+    };
+#ifdef SWC_NO_HELPERS
+    rk_hi = -1;
+#endif
+    if (rk_hi >= 0) {
+      H2r hA = {}, hB = {};
+      int s = (rk_hi >= 3) ? 0 : rk_lo;
+      int s1 = next_w(s);
+      int off1 = hs_b[min(s1, n_steps - 1)];           // offsets are read one step before the loads that use them
+      loadH(hA, hs_b[s]);
+      while (true) {
+        int s2 = next_w(s1);
+        int off2 = hs_b[min(s2, n_steps - 1)];
+        loadH(hB, off1);
+        process(s, hA);
+        if (s1 > rk_hi) break;
+        s = s2; s2 = next_w(s2);
+        off1 = hs_b[min(s2, n_steps - 1)];
+        loadH(hA, off2);
+        process(s1, hB);
+        if (s > rk_hi) break;
+        s1 = s2;
+      }
+    }
   }
+  __syncthreads();
+  TSTAMP0(c, 30);
   // ---------------- sigma^2 (updateSigma, UpdateSigma.h:22-58) ---------------------------------
-  const double th_e = th[eb];
   if (mask & U_SIGMA) {
     // RSS = YY + sum of the threads' shares (RSS(theta_0) - YY and the steps' increments), fixed-order reduction
     // (covariate-adjusted: YY is replaced by sum_i yy_i - 2 o_i's_i + o_i'G_i o_i, block partials of k_curve_z)
@@ -1399,9 +1552,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_fast(Ctx c0) {
   double* s_phi = c.c_Phi + (size_t)slot * K * P * M;
   if (isB) {
     const int jj = b / MD, mt = b - jj * MD;
-    c.theta[(size_t)fd * P + p] = th_e;
-    if (mt == 0) s_nu[jj + (size_t)K * p] = th_e;
-    else s_phi[jj + (size_t)K * (p + (size_t)P * (mt - 1))] = th_e;
+    for (int u = 0; u < (two ? 2 : 1); ++u) {
+      const int pu = p0 + u;
+      const double th_e = th[b * P + pu];
+      c.theta[(size_t)fd * P + pu] = th_e;
+      if (mt == 0) s_nu[jj + (size_t)K * pu] = th_e;
+      else s_phi[jj + (size_t)K * (pu + (size_t)P * (mt - 1))] = th_e;
+    }
   }
   if (MD == 1)
     for (int x = tid; x < K * P * M; x += nthr) {
@@ -1526,16 +1683,17 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     }
     return 0;
   }
-  if (d.P <= 32 && d.A * d.P <= SW_THREADS - 256 && d.BW <= 5) {      // fast path: register-resident sweep
-    const int nthr = 256 + (d.A * d.P + 63) / 64 * 64;
-    const size_t lds = (2 * (size_t)d.A * d.P + 32 + 2 * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + ((size_t)d.A * d.A + 2 * (size_t)d.K * (d.M + 1) + 24) * sizeof(int) + 16;
+  if (d.P <= 32 && d.A * ((d.P + 1) / 2) <= SWC_THREADS - 64 && d.BW <= 5) {      // fast path: the chain in one wave
+    const int nthr = 64 + (d.A * ((d.P + 1) / 2) + 63) / 64 * 64;
+    const size_t lds = (5 * (((size_t)d.A * d.P + 1) & ~(size_t)1) + 32 + (size_t)d.A * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + 2 * ((size_t)d.A + 2) * sizeof(int4) +
+                       ((size_t)d.A * d.A + (size_t)d.A + 8) * sizeof(int) + 16;
     switch (d.BW) {
-      case 0: hipLaunchKernelGGL(k_sweep_fast<0>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
-      case 1: hipLaunchKernelGGL(k_sweep_fast<1>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
-      case 2: hipLaunchKernelGGL(k_sweep_fast<2>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
-      case 3: hipLaunchKernelGGL(k_sweep_fast<3>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
-      case 4: hipLaunchKernelGGL(k_sweep_fast<4>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
-      default: hipLaunchKernelGGL(k_sweep_fast<5>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 0: hipLaunchKernelGGL(k_sweep_chain<0>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 1: hipLaunchKernelGGL(k_sweep_chain<1>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 2: hipLaunchKernelGGL(k_sweep_chain<2>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 3: hipLaunchKernelGGL(k_sweep_chain<3>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      case 4: hipLaunchKernelGGL(k_sweep_chain<4>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
+      default: hipLaunchKernelGGL(k_sweep_chain<5>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
     }
     return 0;
   }

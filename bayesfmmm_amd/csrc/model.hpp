@@ -106,7 +106,7 @@ struct Ctx {
   double* rss_part;             // nblk_curve       partial residual sums of squares
   double* pg_part;              // NWG x NT x 256   pair-Gram partial tiles
   double* H;                    // R x LG           pair-weighted Gram blocks (band-packed)
-  double* H2;                   // R x P x (2BW+2)  the same blocks row-major by p: [G(p,p-BW) .. G(p,p+BW), 0] (k_sweep_fast)
+  double* H2;                   // R x P x (2BW+2)  the same blocks by row p: [G(p,p-BW) .. G(p,p+BW), 0], piece-major (h2_index, kernels_sweep.hip)
   double* tvec;                 // A x P            sum_i w_ai s_i
   double* rvec;                 // A x P            r_a = t_a - sum_b H_ab theta_b at the start of the sweep
   double* hq;                   // A x P            H_aa theta_a
@@ -117,6 +117,7 @@ struct Ctx {
   double* piprep;               // tables of the next iteration's pi / alpha_3 job (scalar_jobs.hpp)
   double* Cmat;                 // A x P x P        covariance of each direction's conditional
   const double* Pmat;           // P x P penalty
+  const int* sweep_tab;         // step tables of k_sweep_chain for the run's (MD, mask): k_sweep_tables (shared by the chains of a batch)
   // ---- covariate adjustment (D > 0): eta_j[:,d] is direction (j, 0, d), xi_jm[:,d] is (j, m+1, d), weight
   //      w = Z_ij * chit_{i,mt} * X_id.  The Phi / nu block sees them as a per-curve offset o_i; they are
   //      sampled by the sequential "direct" steps of kernels_cov.hip.
