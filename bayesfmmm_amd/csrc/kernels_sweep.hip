@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
           if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, 2u); break; }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      asm volatile("" ::: "memory");      // (compiler ordering only: an acquire fence would also wait for this wave's loads in flight)
       double dv[W + 1], va, vb;
       int tries = 0;
 #pragma nounroll

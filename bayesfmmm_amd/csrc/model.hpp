@@ -171,7 +171,10 @@ struct Ctx {
   X_(c_eta) X_(c_xi) X_(c_tau_eta) X_(c_gamma_xi) X_(c_delta_xi) X_(c_A_xi)
 
 template <typename T>
-__host__ __device__ inline T* ptr_shift(T* p, size_t bytes) { return (T*)((uintptr_t)p + bytes); }
+// (pointer arithmetic, not integer arithmetic: a pointer that has been through an integer loses its address space, and every
+//  access through it becomes a FLAT instruction -- 64-bit address registers, and counted on the LDS counter as well, so that
+//  each LDS wait of a kernel also waited for its global loads in flight)
+__host__ __device__ inline T* ptr_shift(T* p, size_t bytes) { return (T*)((char*)p + bytes); }
 
 // the context of chain q of the batch
 __host__ __device__ inline Ctx chain_ctx(const Ctx& c0, unsigned q) {
