@@ -6,17 +6,23 @@
 A "step" is one Gibbs iteration of every chain in flight.  Data: SURVEY.md 8(d) "Config 2" (n_funct = 4096 curves of
 n_i = 100 points, cubic B-splines with 26 internal knots => P = 30, K = 3, M = 6, fp64), synthetic.
 
-N = 1   `value` = the headline of BASELINE.json configs[1]: ONE chain of the full warm-start sweep of BFMMM_MTT_warm_start
-        (Z, pi, alpha_3, Phi, delta, A, gamma, nu, tau, sigma^2, chi + log-likelihood; BFMMM.h:1502-1553, :1670), started at
-        the generating values, inputs and chain resident in HBM.  The same line carries `roofline` (per-kernel HIP-event
-        times of the same sweep, SURVEY 8(d) bytes, measured bytes), `cpu_baseline` (the oracle on one host core) and, as
-        extra keys, `config5` (the 8 multi-try chains of configs[4] on this one GPU) and `other_configs` (configs[2], [3]).
-N > 1   `value` = BASELINE.json configs[4] / SURVEY 8(d) "Config 5": the 8 chains of BFMMM_Nu_Z_multiple_try (n_try = 7;
-        reduced sweep Z, pi, alpha_3, nu, tau, sigma^2, log-likelihood, BFMMM.h:1073-1113) on the config-2 data, dealt
-        round-robin over the N ranks, each rank running its chains as ONE sampler batch; total chain-iterations / time of
-        the slowest rank (strong scaling: 8 chains whatever N).  No collective inside the timed steps -- chains are
-        independent (src/UserFunctions.cpp:302-325); the reference's final selection (all-gather of one score per rank +
-        broadcast of the winning chain, RCCL) is timed separately: `gather_s`, `time_to_best_chain_s` = steps + gather.
+ONE series for every N (`scaling` = "weak"): `value` = the headline of BASELINE.json configs[1] -- the full warm-start sweep of
+BFMMM_MTT_warm_start (Z, pi, alpha_3, Phi, delta, A, gamma, nu, tau, sigma^2, chi + log-likelihood; BFMMM.h:1502-1553, :1670),
+started at the generating values, inputs and chain resident in HBM -- with ONE independent chain per GPU: a chain does not shard
+("replicas only" inside a chain), so N GPUs run N replicas with RNG chain ids 0 .. N - 1 and `value` is the
+whole-node rate, N x steps / (time of the slowest rank).  No collective inside the timed steps.
+
+The same line carries, with the SAME keys at every N, `config5`: BASELINE.json configs[4] / SURVEY 8(d) "Config 5", the 8 chains
+of BFMMM_Nu_Z_multiple_try (n_try = 7; reduced sweep Z, pi, alpha_3, nu, tau, sigma^2, log-likelihood, BFMMM.h:1073-1113) on
+the config-2 data, dealt round-robin over the N ranks, each rank running its chains as ONE sampler batch (strong scaling:
+8 chains whatever N; one GPU already overlaps the 8 chains, so N = 8 can give about 2x over N = 1, not 8x -- DESIGN.md 7), then
+the reference's final selection (all-gather of one score per rank + broadcast of the winning chain, RCCL; `gather_s`,
+`time_to_best_chain_s` = steps + gather).
+
+N = 1 only (rank 0's GPU and host cores): `roofline` (per-kernel HIP-event times of the same sweep; primary figures = the
+band-packed record bytes this build stores and the counter-measured bytes, the SURVEY 8(d) dense-record figure kept beside
+them as `accounting_8d`), `chains_sweep` (1 / 8 / 32 warm-start chains as one batch), `other_configs` (configs[2], [3]) and
+`cpu_baseline` (the oracle on one host core).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -135,7 +141,7 @@ def pmc_summary():
         return None, None
 
 
-KERNELS_OF = {"sweep": ["k_sweep_fast", "k_sweep", "k_sweep_diag"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
+KERNELS_OF = {"sweep": ["k_sweep_chain", "k_sweep_fast", "k_sweep", "k_sweep_diag"], "curve_z": ["k_curve_z"], "curve_chi": ["k_curve_chi"],
               "pair_gram": ["k_pair_gram"], "pg_reduce": ["k_pg_reduce"], "factor": ["k_factor"]}
 
 
@@ -201,8 +207,8 @@ def other_configs(bf, steps=200, warmup=20):
     b_alg = 7 * n * 8 * (P * P + P + 1) + 8 * n * (2 * M + 2 * K) + 8 * n * D
     out["config3"] = dict(workload="covariate-adjusted Mean_CovAdj sweep (19 updates, BFMMM.h:4809-4894), n_funct=4096, D=5, K=3, P=30, M=6",
                           steps=steps, ms_per_sweep=dt * 1e3, iterations_per_s=1.0 / dt, algorithmic_bytes=b_alg,
-                          hbm_frac_8d_accounting=b_alg / dt / 1e9 / HBM_PEAK_GBS,
-                          hbm_frac_banded_records=(7 * n * 8 * (5 * P + 1) + 8 * n * (2 * M + 2 * K) + 8 * n * D) / dt / 1e9 / HBM_PEAK_GBS)
+                          hbm_frac_banded_records=(7 * n * 8 * (5 * P + 1) + 8 * n * (2 * M + 2 * K) + 8 * n * D) / dt / 1e9 / HBM_PEAK_GBS,
+                          accounting_8d_ratio_to_peak=b_alg / dt / 1e9 / HBM_PEAK_GBS)
     smp.close()
     rng = np.random.default_rng(4)
     n, P, K, M = 8192, 50, 4, 8
@@ -225,8 +231,97 @@ def other_configs(bf, steps=200, warmup=20):
     b_alg = 5 * n * P * 8 + 8 * n * (2 * M + 2 * K)
     out["config4"] = dict(workload="BMVMMM warm-start sweep (BFMMM.h:2597-2650), N=8192, dim=50, K=4, M=8", steps=steps,
                           ms_per_sweep=dt * 1e3, iterations_per_s=1.0 / dt, algorithmic_bytes=b_alg,
-                          hbm_frac_8d_accounting=b_alg / dt / 1e9 / HBM_PEAK_GBS)
+                          hbm_frac=b_alg / dt / 1e9 / HBM_PEAK_GBS)      # (G_i = I: the 8(d) figure IS what is stored, y_i only)
     smp.close()
+    return out
+
+
+def config5_record(bf, w, torch, dist, backend, rank, world, local_rank, steps, warmup, barrier):
+    """BASELINE configs[4] with identical keys at every N: the 8 multi-try chains dealt over the ranks, timed between barriers
+    (max over ranks), then the reference's selection (score all-gather + winner broadcast; local at N = 1)."""
+    n, P, K = w["n"], w["P"], w["K"]
+    chain_ids = list(range(rank, N_CHAINS_CONFIG5, world))
+    smp, T = None, warmup + steps
+    if chain_ids:
+        smp, T = run_config5(bf, w, local_rank, chain_ids, steps, warmup)
+    barrier()
+    t0 = time.perf_counter()
+    if smp is not None:
+        smp.run(bf.SWEEP_NU_Z, steps, first_iter=warmup, seed=1, chain=chain_ids[0], phi_chi_zero=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # final selection of BFMMM_Nu_Z_multiple_try (UserFunctions.cpp:302-325)
+    t1 = time.perf_counter()
+    local = None
+    if smp is not None:
+        scores = config5_scores(smp, chain_ids, T)
+        b = int(np.argmax(scores))
+        smp.select_chain(b)
+        local = dict(best_score=scores[b], best_chain=float(chain_ids[b]))
+        for nm in ("nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik", "A", "delta"):
+            local[nm] = smp.get_chain(nm, T)
+    if dist is not None:
+        from bayesfmmm_amd import parallel
+        best = parallel.gather_select_broadcast(local, None)
+    else:
+        best = local
+    barrier()
+    gather_s = time.perf_counter() - t1
+    assert np.isfinite(best["loglik"]).all() and best["Z"].shape == (n, K, T)
+    if smp is not None:
+        smp.close()
+    total = N_CHAINS_CONFIG5 * steps
+    b_band5 = 3 * n * 8 * (4 * P + P + 1) + 8 * n * 2 * K          # band-packed records, per chain-iteration
+    b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K           # SURVEY 8(d) config 5 (dense records), per chain-iteration
+    pm5 = None
+    try:
+        f5 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_nu_z_8_pmc_summary.json")))
+        pm5 = json.load(open(f5[-1])) if f5 else None
+    except Exception:
+        pm5 = None
+    traffic = None
+    if pm5:      # measured bytes of one step of the 8-chain batch on ONE GPU (FETCH_SIZE x 2 + WRITE_SIZE, all kernels)
+        traffic = sum((v.get("hbm_read_bytes_per_launch") or 0.0) + (v.get("hbm_write_bytes_per_launch") or 0.0)
+                      for k, v in pm5.items() if k.startswith("k_") and v.get("calls", 0) >= 50)
+    return dict(workload=f"BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains of the Nu_Z sweep) on the config-2 data, dealt "
+                         f"round-robin over {world} GPU(s), {-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch",
+                scaling="strong", n_gpus=world, chains=N_CHAINS_CONFIG5, chains_per_gpu=-(-N_CHAINS_CONFIG5 // world), steps=steps,
+                value=total / dt, unit="Gibbs iterations/sec (all chains)", ms_per_step=dt / steps * 1e3,
+                gather_s=gather_s, time_to_best_chain_s=dt + gather_s, best_chain=int(best["best_chain"]),
+                best_score=float(best["best_score"]),
+                roofline=dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS * world,
+                              achieved=b_band5 * total / dt / 1e9, frac=b_band5 * total / dt / 1e9 / (HBM_PEAK_GBS * world),
+                              bytes="band-packed records: 3 blocks x n x 8 (5 P + 1) per chain-iteration",
+                              traffic_per_step_one_gpu=traffic,
+                              accounting_8d=dict(bytes_per_chain_iteration=b_alg5, ratio_to_peak=b_alg5 * total / dt / 1e9 / (HBM_PEAK_GBS * world),
+                                                 note="SURVEY 8(d) charges every chain-iteration three passes over DENSE P x P "
+                                                      "records; a batch shares ONE band-packed copy among its chains, so this ratio "
+                                                      "can exceed 1 -- it is bookkeeping, not a bandwidth")))
+
+
+def chains_sweep(bf, w, device, torch, steps=100, warmup=20, counts=(1, 8, 32)):
+    """warm-start chains as ONE batch on this GPU: where each kernel stops being latency-bound"""
+    out = []
+    for nc in counts:
+        cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=w["degree"], tot_mcmc_iters=warmup + steps)
+        s = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=device, n_chains=nc)
+        for q in range(nc):
+            s.select_chain(q)
+            s.set_state(**w["state"])
+        s.run(bf.SWEEP_WARM, warmup, first_iter=0, seed=1, chain=100)
+        s.prepare_run(bf.SWEEP_WARM, steps, first_iter=warmup, seed=1, chain=100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.run(bf.SWEEP_WARM, steps, first_iter=warmup, seed=1, chain=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s.close()
+        out.append(dict(chains=nc, steps_per_chain=steps, value=nc * steps / dt, unit="Gibbs iterations/sec (all chains)",
+                        ms_per_step=dt / steps * 1e3, us_per_chain_iteration=dt / steps / nc * 1e6))
     return out
 
 
@@ -238,7 +333,7 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip config5 / other_configs at N = 1 (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip config5 / chains_sweep / other_configs (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -269,85 +364,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
-        # ---------------- config 5: 8 multi-try chains dealt over the ranks ----------------
-        chain_ids = list(range(rank, N_CHAINS_CONFIG5, world))
-        smp, T = (None, args.warmup + args.steps)
-        if chain_ids:
-            smp, T = run_config5(bf, w, local_rank, chain_ids, args.steps, args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        if smp is not None:
-            smp.run(bf.SWEEP_NU_Z, args.steps, first_iter=args.warmup, seed=1, chain=chain_ids[0], phi_chi_zero=True)
-        barrier()
-        dt = time.perf_counter() - t0
-        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # final selection of BFMMM_Nu_Z_multiple_try (UserFunctions.cpp:302-325): score all-gather + winner broadcast
-        from bayesfmmm_amd import parallel
-        t1 = time.perf_counter()
-        local = None
-        if smp is not None:
-            scores = config5_scores(smp, chain_ids, T)
-            b = int(np.argmax(scores))
-            smp.select_chain(b)
-            local = dict(best_score=scores[b], best_chain=float(chain_ids[b]))
-            for nm in ("nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik", "A", "delta"):
-                local[nm] = smp.get_chain(nm, T)
-        best = parallel.gather_select_broadcast(local, None)
-        barrier()
-        gather_s = time.perf_counter() - t1
-        assert np.isfinite(best["loglik"]).all() and best["Z"].shape == (n, K, T)
-        if rank == 0:
-            total = N_CHAINS_CONFIG5 * args.steps
-            b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K          # SURVEY 8(d) config 5, per chain-iteration
-            out = {
-                "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30", "value": total / dt,
-                "unit": "Gibbs iterations/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains of the Nu_Z sweep), n_funct={n}, "
-                                       f"n_i={w['n_i']}, K={K}, P={P}, fp64, chains dealt round-robin over {world} GPUs "
-                                       f"({-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch)",
-                           "chains": N_CHAINS_CONFIG5, "chains_per_gpu": -(-N_CHAINS_CONFIG5 // world)},
-                "roofline": {"bound": "hbm", "kernel": "iteration (all kernels of a chain-iteration)",
-                             "achieved": b_alg5 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                             "frac": b_alg5 * total / dt / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                             "note": "SURVEY 8(d) config-5 bytes (3 blocks x n x 8 (P^2+P+1) per chain-iteration) x "
-                                     "chain-iterations/s against N x 8 TB/s; per-kernel figures are on the N = 1 line"},
-                "gather_s": gather_s, "time_to_best_chain_s": dt + gather_s,
-                "best_chain": best["best_chain"], "best_score": best["best_score"],
-            }
-            print(json.dumps(out))
-        if smp is not None:
-            smp.close()
-        dist.barrier()
-        dist.destroy_process_group()
-        return
-
-    # ---------------- N = 1: the single-chain headline (BASELINE.json configs[1]) ----------------
+    # ---------------- the headline (BASELINE.json configs[1]): one warm-start chain per GPU ----------------
     T = args.warmup + args.steps
     cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=w["degree"],
                             tot_mcmc_iters=max(T, args.profile_steps))
     smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
     smp.set_state(**w["state"])
-    smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=0)
-    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=0)   # graph capture is set-up
+    smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=rank)
+    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)   # graph capture is set-up
     barrier()
     t0 = time.perf_counter()
-    smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=0)
+    smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)
     barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     dev_ms, _ = smp.timing("total")
     assert np.isfinite(smp.get_chain("loglik", T)).all()
-    value = args.steps / dt
+    value = world * args.steps / dt
 
-    # per-kernel pass: the same sweep, eager launches bracketed by HIP events on the sampler's stream (a replayed graph
+    # per-kernel pass (N = 1): the same sweep, eager launches bracketed by HIP events on the sampler's stream (a replayed graph
     # cannot carry per-launch events; the brackets add about 3 us per launch, so these are upper bounds -- the rocprofv3
     # averages of the same command are committed under profiles/)
     fams = {}
-    if args.profile_steps > 0:
+    if args.profile_steps > 0 and world == 1:
         smp.set_state(**w["state"])
         smp.set_profile(True)
         smp.run(bf.SWEEP_WARM, args.profile_steps, first_iter=0, seed=1, chain=0)
@@ -363,6 +405,7 @@ def main():
     blocks = {"curve_z": 1, "pair_gram": 2, "pg_reduce": 0, "sweep": 1, "curve_chi": 2, "factor": 0, "loglik": 0}
     pm, pm_file = pmc_summary()
     roofline = None
+    it_rate = value / world            # iterations/s of one chain
     if fams:
         # dominant kernel = largest time PER ITERATION among the families that run every iteration
         every = [k for k in fams if blocks[k] > 0 and fams[k]["launches"] >= args.profile_steps]
@@ -370,14 +413,15 @@ def main():
         # Each bracketed launch carries the event pair and the gap of an eager launch (about 3 us); the timed region replays
         # the same kernels as a graph without either.  The families' bracketed times per iteration are therefore brought down
         # by one common per-launch overhead, chosen so that they sum to the measured graph-replay time of an iteration: these
-        # are the durations rocprofv3 reports for the same command (profiles/r02_final_kernel_stats.csv agrees to 0.5 us).
+        # are the durations rocprofv3 reports for the same command (profiles/r03_final_kernel_stats.csv).
         it_ms = dt / args.steps * 1e3
         n_launch = sum(v["launches"] for v in fams.values()) / args.profile_steps
         over = max(0.0, (sum(v["ms_per_iteration"] for v in fams.values()) - it_ms) / max(n_launch, 1.0))
         for v in fams.values():
             v["ms_per_launch_in_graph"] = max(v["ms_per_launch"] - over, 0.0) if v["launches"] else 0.0
         ms = fams[dom]["ms_per_launch_in_graph"]
-        bytes_dom = blocks[dom] * n * 8 * (P * P + P + 1)
+        rec_band, rec_dense = 8 * (5 * P + 1), 8 * (P * P + P + 1)          # bytes of one curve's record: stored / SURVEY 8(d)
+        bytes_dom = blocks[dom] * n * rec_band
         ach = bytes_dom / (ms * 1e-3) / 1e9
         it_bytes = None
         if pm:
@@ -390,10 +434,17 @@ def main():
             bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
             traffic=measured_bytes(pm, dom), traffic_source=pm_file,
             algorithmic_bytes_per_launch=bytes_dom,
-            iteration=dict(algorithmic_bytes=b_alg, achieved=b_alg * value / 1e9, frac=b_alg * value / 1e9 / HBM_PEAK_GBS,
-                           banded_record_bytes=b_band, banded_frac=b_band * value / 1e9 / HBM_PEAK_GBS,
+            bytes="band-packed records this build stores, 8 (5 P + 1) bytes per curve and data-touching block of the kernel",
+            iteration=dict(algorithmic_bytes=b_band, achieved=b_band * it_rate / 1e9, frac=b_band * it_rate / 1e9 / HBM_PEAK_GBS,
                            measured_bytes=it_bytes,
-                           measured_frac=None if it_bytes is None else it_bytes * value / 1e9 / HBM_PEAK_GBS),
+                           measured_achieved=None if it_bytes is None else it_bytes * it_rate / 1e9,
+                           measured_frac=None if it_bytes is None else it_bytes * it_rate / 1e9 / HBM_PEAK_GBS),
+            accounting_8d=dict(kernel_bytes_per_launch=blocks[dom] * n * rec_dense,
+                               kernel_ratio_to_peak=blocks[dom] * n * rec_dense / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               iteration_bytes=b_alg, iteration_ratio_to_peak=b_alg * it_rate / 1e9 / HBM_PEAK_GBS,
+                               note="SURVEY 8(d): dense P x P records, one pass per data-touching block; this build stores "
+                                    "band-packed records (6x fewer bytes) that stay in L2 / Infinity Cache, so this is bookkeeping, "
+                                    "not a bandwidth"),
             per_kernel_ms={k: round(v["ms_per_launch_in_graph"], 6) for k, v in fams.items()},
             per_kernel_ms_event_bracketed={k: round(v["ms_per_launch"], 6) for k, v in fams.items()},
             event_overhead_ms_per_launch=round(over, 6),
@@ -405,70 +456,43 @@ def main():
                       peak_tflops=FP64_MFMA_PEAK_TF,
                       frac=pg_flop / (fams["pair_gram"]["ms_per_launch_in_graph"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
                       note="duration of k_pair_gram in the replayed graph; counter evidence: profiles/*_mfma_pmc.json"),
-            note="`achieved` charges the dominant kernel the SURVEY 8(d) bytes of the update blocks it implements; the "
-                 "sweep is a chain of K*M + K dependent P x P steps bound by step latency, not by bytes: `traffic` "
-                 "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch) and iteration.measured_* are what actually moves")
-    out = {
-        "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30",
-        "value": value, "unit": "Gibbs iterations/sec", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BFMMM_warm_start sweep, n_funct={n}, n_i={w['n_i']}, K={K}, P={P}, M={M}, fp64, one chain",
-                   "chains": 1, "device_ms_per_step": dev_ms / args.steps},
-        "roofline": roofline,
-    }
+            note="the iteration is five dependent kernels, each bound by dependent-step latency at this size (the records, 5 MB, "
+                 "live in L2 / Infinity Cache): `frac` is small by construction; `traffic` (rocprofv3 FETCH_SIZE x 2 + "
+                 "WRITE_SIZE per launch) and iteration.measured_* are what actually moves")
+    if roofline is None:      # N > 1 (the per-kernel figures are on the N = 1 line): the iteration's bytes against N x 8 TB/s
+        roofline = dict(bound="hbm", kernel="iteration (all kernels of a chain-iteration)", unit="GB/s", peak=HBM_PEAK_GBS * world,
+                        achieved=b_band * value / 1e9, frac=b_band * value / 1e9 / (HBM_PEAK_GBS * world), traffic=None,
+                        bytes="band-packed records this build stores, 8 (5 P + 1) bytes per curve and data-touching block",
+                        accounting_8d=dict(iteration_bytes=b_alg, iteration_ratio_to_peak=b_alg * value / 1e9 / (HBM_PEAK_GBS * world)))
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Gibbs iterations/sec (whole node) at n_funct=4096, K=3, P=30",
+            "value": value, "unit": "Gibbs iterations/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BFMMM_warm_start sweep, n_funct={n}, n_i={w['n_i']}, K={K}, P={P}, M={M}, fp64, one "
+                                   f"independent chain per GPU ({world} chain(s): a chain does not shard, replicas only)",
+                       "chains": world, "chains_per_gpu": 1, "device_ms_per_step": dev_ms / args.steps},
+            "roofline": roofline,
+        }
     if not args.no_extras:
-        # config 5 on this one GPU: the N = 1 point of the 8-chain curve the N > 1 runs report
-        c5_steps, c5_warm = max(args.steps, 100), max(args.warmup, 20)
-        chain_ids = list(range(N_CHAINS_CONFIG5))
-        s5, T5 = run_config5(bf, w, local_rank, chain_ids, c5_steps, c5_warm)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s5.run(bf.SWEEP_NU_Z, c5_steps, first_iter=c5_warm, seed=1, chain=0, phi_chi_zero=True)
-        torch.cuda.synchronize()
-        dt5 = time.perf_counter() - t0
-        t1 = time.perf_counter()
-        scores = config5_scores(s5, chain_ids, T5)
-        bsel = int(np.argmax(scores))
-        s5.select_chain(bsel)
-        keep = {nm: s5.get_chain(nm, T5) for nm in ("nu", "Z", "pi", "alpha_3", "tau", "sigma_sq", "loglik", "A", "delta")}
-        sel_s = time.perf_counter() - t1
-        assert keep["Z"].shape == (n, K, T5)
-        s5.close()
-        b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K
-        b_band5 = 3 * n * 8 * (4 * P + P + 1) + 8 * n * 2 * K
-        tot5 = N_CHAINS_CONFIG5 * c5_steps
-        out["config5"] = dict(workload="BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains, Nu_Z sweep) on the config-2 data, "
-                                       "all 8 on this GPU as one sampler batch", chains=N_CHAINS_CONFIG5, steps=c5_steps,
-                              value=tot5 / dt5, unit="Gibbs iterations/sec (all chains)", ms_per_step=dt5 / c5_steps * 1e3,
-                              # SURVEY 8(d) accounting: every chain-iteration is charged three passes over DENSE P x P records;
-                              # the batch keeps ONE band-packed copy of the records for all chains (L2 / Infinity Cache resident),
-                              # so the bytes that can actually move are the banded figure at most -- an accounting ratio, not a
-                              # measured bandwidth (measured bytes of the batch kernels: profiles/r02_nu_z_8_kernel_stats.csv + PMC)
-                              hbm_frac_8d_accounting=b_alg5 * tot5 / dt5 / 1e9 / HBM_PEAK_GBS,
-                              hbm_frac_banded_records=b_band5 * tot5 / dt5 / 1e9 / HBM_PEAK_GBS, gather_s=sel_s,
-                              time_to_best_chain_s=dt5 + sel_s, best_chain=chain_ids[bsel])
-        # 8 warm-start chains (the headline sweep) as one batch on this GPU
-        cfg8 = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=K, n_eigen=M, basis_degree=w["degree"], tot_mcmc_iters=c5_warm + c5_steps)
-        s8 = bf.Sampler(cfg8, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank, n_chains=8)
-        for q in range(8):
-            s8.select_chain(q)
-            s8.set_state(**w["state"])
-        s8.run(bf.SWEEP_WARM, c5_warm, first_iter=0, seed=1, chain=100)
-        s8.prepare_run(bf.SWEEP_WARM, c5_steps, first_iter=c5_warm, seed=1, chain=100)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s8.run(bf.SWEEP_WARM, c5_steps, first_iter=c5_warm, seed=1, chain=100)
-        torch.cuda.synchronize()
-        dt8 = time.perf_counter() - t0
-        s8.close()
-        out["multi_chain"] = dict(chains=8, steps_per_chain=c5_steps, value=8 * c5_steps / dt8,
-                                  unit="Gibbs iterations/sec (all chains)", ms_per_step=dt8 / c5_steps * 1e3,
+        c5 = config5_record(bf, w, torch, dist, backend, rank, world, local_rank, max(args.steps, 100), max(args.warmup, 20), barrier)
+        if rank == 0:
+            out["config5"] = c5
+    if rank == 0 and world == 1 and not args.no_extras:
+        cs = chains_sweep(bf, w, local_rank, torch)
+        out["chains_sweep"] = cs
+        out["multi_chain"] = dict(next(c for c in cs if c["chains"] == 8),
                                   workload="8 independent chains of the warm-start sweep as one sampler batch on this GPU")
         out["other_configs"] = other_configs(bf)
-    if not args.no_cpu_baseline:      # rank 0's host cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0's host cores, N = 1 only
         out["cpu_baseline"] = cpu_baseline(w)
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
