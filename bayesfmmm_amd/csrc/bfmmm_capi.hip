@@ -251,7 +251,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   const int n = cfg->n_funct, K = cfg->K, M = cfg->n_eigen;
   if (n < 1) return fail("'n_funct' must be an integer greater than or equal to 1");
   if (K < 2) return fail("'K' must be an integer greater than or equal to 2");
-  if (K > KMAX) return fail("K larger than 6 is not supported by this build");
+  if (K > KMAX) return fail("K larger than 8 is not supported by this build");
   if (M < 1) return fail("'n_eigen' must be an integer greater than or equal to 1");
   if (cfg->tot_mcmc_iters < 1) return fail("'tot_mcmc_iters' must be positive");
   int P, BW;

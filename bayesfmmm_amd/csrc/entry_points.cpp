@@ -149,7 +149,7 @@ static int validate(const bfmmm_entry_args* a, int entry) {
   if (a->X && (a->D < 1 || a->D > 8)) return efail("the number of covariates (columns of 'X') must be between 1 and 8 in this build");
   if (a->X && a->alpha_eta <= 0) return efail("'alpha_eta' must be positive");
   if (a->X && a->beta_eta <= 0) return efail("'beta_eta' must be positive");
-  if (a->K > 6) return efail("K larger than 6 is not supported by this build");
+  if (a->K > 8) return efail("K larger than 8 is not supported by this build");
   if (a->chain_stride < 1 || a->chain_offset < 0) return efail("invalid chain_offset / chain_stride");
   return 0;
 }

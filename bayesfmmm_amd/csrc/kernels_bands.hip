@@ -8,7 +8,9 @@
 //                      outside [0.5 / N, (N - 0.5) / N])
 //   k_bands_moments    per column mean and standard deviation (N - 1), fixed-order tree
 //   k_bands_maxdev     per draw C_t = max_j |f - mean_j| / sd_j                  (simultaneous bands, PostProcessing.cpp:287-296)
-// A column is limited to 8192 draws (64 KiB of LDS).
+// Columns of up to 8192 draws are sorted in LDS (64 KiB); longer ones (the reference has no limit: arma::quantile sorts any
+// length) by the same network over a padded copy of the column in global memory, k_bands_quantiles_big: the exchanges whose
+// partner is at least LCH elements away run as passes over global memory, the rest of every merge step chunk by chunk in LDS.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -22,7 +24,10 @@ int bfmmm_io_fail(const std::string& m);
 namespace {
 
 constexpr int QT = 256;
-constexpr int TMAX = 8192;
+constexpr int TMAX = 8192;         // draws per column sorted entirely in LDS
+constexpr int TBIG = 1 << 24;      // draws per column, global-memory path
+constexpr int BT = 1024;           // threads of the global-memory path
+constexpr int LCH = 8192;          // elements of its LDS chunk
 
 __global__ __launch_bounds__(QT) void k_bands_fsamp(const double* B, const double* coef, int T, int P, double* f) {
   const int j = blockIdx.x;
@@ -68,6 +73,66 @@ __global__ __launch_bounds__(QT) void k_bands_quantiles(const double* V, int T, 
       const int k = (int)floor(N * p + 0.5);
       const double pk = ((double)k - 0.5) / N, w = (p - pk) * N;
       v = (1.0 - w) * s[k - 1] + w * s[min(k, T - 1)];
+    }
+    out[tid + (size_t)nq * col] = v;
+  }
+}
+
+
+// The same bitonic network for a column that does not fit LDS: W is a scratch copy of the column padded with +inf to NP (a
+// power of two > TMAX), one workgroup per column.  For the exchange distance jj >= LCH the pairs (e, e ^ jj) are exchanged in
+// global memory (agent-scope relaxed accesses: the workgroup re-reads what its other waves wrote, and a wave's vector L1 is not
+// refreshed by other waves' stores); once jj < LCH the remaining exchanges of the merge step stay inside aligned chunks of
+// LCH elements, which are loaded into LDS, finished there and stored back.
+__global__ __launch_bounds__(BT) void k_bands_quantiles_big(const double* V, int T, int NP, double* Wall, const double* probs, int nq, double* out) {
+  extern __shared__ double s[];
+  const int col = blockIdx.x, tid = threadIdx.x;
+  double* W = Wall + (size_t)NP * col;
+  auto ld = [&](int e) { return __hip_atomic_load(W + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st = [&](int e, double v) { __hip_atomic_store(W + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  for (int e = tid; e < NP; e += BT) st(e, (e < T) ? V[(size_t)e + (size_t)T * col] : INFINITY);
+  __syncthreads();
+  for (int k = 2; k <= NP; k <<= 1) {
+    int jj = k >> 1;
+    for (; jj >= LCH; jj >>= 1) {
+      for (int e = tid; e < NP; e += BT) {
+        const int partner = e ^ jj;
+        if (partner > e) {
+          const bool up = (e & k) == 0;
+          const double a = ld(e), b = ld(partner);
+          if ((a > b) == up) { st(e, b); st(partner, a); }
+        }
+      }
+      __syncthreads();
+    }
+    // jj < LCH: the rest of this merge step, chunk by chunk in LDS (the direction of a pair depends on its GLOBAL index)
+    for (int c0 = 0; c0 < NP; c0 += LCH) {
+      for (int e = tid; e < LCH; e += BT) s[e] = ld(c0 + e);
+      for (int j2 = jj; j2 > 0; j2 >>= 1) {
+        __syncthreads();
+        for (int e = tid; e < LCH; e += BT) {
+          const int partner = e ^ j2;
+          if (partner > e) {
+            const bool up = ((c0 + e) & k) == 0;
+            const double a = s[e], b = s[partner];
+            if ((a > b) == up) { s[e] = b; s[partner] = a; }
+          }
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < LCH; e += BT) st(c0 + e, s[e]);
+      __syncthreads();
+    }
+  }
+  if (tid < nq) {
+    const double N = (double)T, p = probs[tid];
+    double v;
+    if (p < 0.5 / N) v = (p < 0.0) ? -INFINITY : ld(0);
+    else if (p > (N - 0.5) / N) v = (p > 1.0) ? INFINITY : ld(T - 1);
+    else {
+      const int k = (int)floor(N * p + 0.5);
+      const double pk = ((double)k - 0.5) / N, w = (p - pk) * N;
+      v = (1.0 - w) * ld(k - 1) + w * ld(min(k, T - 1));
     }
     out[tid + (size_t)nq * col] = v;
   }
@@ -123,18 +188,34 @@ int select_device(int device, const char* who) {
 
 size_t sort_lds_bytes(int T) { int NP = 1; while (NP < T) NP <<= 1; return (size_t)NP * sizeof(double); }
 
+
+// quantiles of the columns of the device table dV (T x ncol): LDS sort, or the global-memory network for long columns
+static int launch_quantiles(Bufs& b, const double* dV, int T, int ncol, const double* dprobs, int nq, double* dout) {
+  if (T <= TMAX) {
+    (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
+    hipLaunchKernelGGL(k_bands_quantiles, dim3(ncol), dim3(QT), sort_lds_bytes(T), 0, dV, T, dprobs, nq, dout);
+    return 0;
+  }
+  int NP = 1;
+  while (NP < T) NP <<= 1;
+  double* dW;
+  if (!b.put(&dW, nullptr, (size_t)NP * ncol)) return 1;
+  (void)hipFuncSetAttribute((const void*)k_bands_quantiles_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LCH * sizeof(double)));
+  hipLaunchKernelGGL(k_bands_quantiles_big, dim3(ncol), dim3(BT), LCH * sizeof(double), 0, dV, T, NP, dW, dprobs, nq, dout);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol, const double* probs, int32_t nq, int32_t device, double* out) {
   if (!V || !probs || !out || T < 1 || ncol < 1 || nq < 1 || nq > QT) return bfmmm_io_fail("bfmmm_post_col_quantiles: bad arguments");
-  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_col_quantiles: at most 8192 draws per column in this build");
+  if (T > TBIG) return bfmmm_io_fail("bfmmm_post_col_quantiles: at most 2^24 draws per column");
   if (select_device(device, "bfmmm_post_col_quantiles")) return 1;
   Bufs b;
   double *dV, *dp, *dout;
   if (!b.put(&dV, V, (size_t)T * ncol) || !b.put(&dp, probs, (size_t)nq) || !b.put(&dout, nullptr, (size_t)nq * ncol))
     return bfmmm_io_fail("bfmmm_post_col_quantiles: device allocation or copy failed");
-  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
-  hipLaunchKernelGGL(k_bands_quantiles, dim3(ncol), dim3(QT), sort_lds_bytes(T), 0, dV, T, dp, nq, dout);
+  if (launch_quantiles(b, dV, T, ncol, dp, nq, dout)) return bfmmm_io_fail("bfmmm_post_col_quantiles: device allocation failed");
   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess ||
       hipMemcpy(out, dout, sizeof(double) * nq * ncol, hipMemcpyDeviceToHost) != hipSuccess)
     return bfmmm_io_fail("bfmmm_post_col_quantiles: kernel launch or copy back failed");
@@ -160,17 +241,16 @@ static int table_bands(Bufs& b, const double* df, int T, int ncol, double alpha,
   if (!b.put(&dp, simultaneous ? p1 : probs, simultaneous ? 1 : 3) || !b.put(&dq, nullptr, (size_t)3 * ncol) ||
       !b.put(&dm, nullptr, (size_t)ncol) || !b.put(&ds, nullptr, (size_t)ncol) || !b.put(&dC, nullptr, (size_t)T))
     return bfmmm_io_fail(std::string(who) + ": device allocation or copy failed");
-  (void)hipFuncSetAttribute((const void*)k_bands_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(TMAX));
   std::vector<double> q((size_t)3 * ncol), m((size_t)ncol), s((size_t)ncol);
   if (!simultaneous) {
-    hipLaunchKernelGGL(k_bands_quantiles, dim3(ncol), dim3(QT), sort_lds_bytes(T), 0, df, T, dp, 3, dq);
+    if (launch_quantiles(b, df, T, ncol, dp, 3, dq)) return bfmmm_io_fail(std::string(who) + ": device allocation failed");
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(q.data(), dq, sizeof(double) * 3 * ncol, hipMemcpyDeviceToHost) != hipSuccess)
       return bfmmm_io_fail(std::string(who) + ": kernel launch or copy back failed");
     for (int j = 0; j < ncol; ++j) { lower[j] = q[(size_t)3 * j]; mid[j] = q[(size_t)3 * j + 1]; upper[j] = q[(size_t)3 * j + 2]; }
   } else {
     hipLaunchKernelGGL(k_bands_moments, dim3(ncol), dim3(QT), 0, 0, df, T, dm, ds);
     hipLaunchKernelGGL(k_bands_maxdev, dim3((T + QT - 1) / QT), dim3(QT), 0, 0, df, T, ncol, dm, ds, dC);
-    hipLaunchKernelGGL(k_bands_quantiles, dim3(1), dim3(QT), sort_lds_bytes(T), 0, dC, T, dp, 1, dq);
+    if (launch_quantiles(b, dC, T, 1, dp, 1, dq)) return bfmmm_io_fail(std::string(who) + ": device allocation failed");
     double qc = 0.0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&qc, dq, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(m.data(), dm, sizeof(double) * ncol, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -186,7 +266,7 @@ static int table_bands(Bufs& b, const double* df, int T, int ncol, double alpha,
 extern "C" int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
                                 int32_t device, double* upper, double* mid, double* lower, double* trace) {
   if (!coef || !B || !upper || !mid || !lower || T < 2 || P < 1 || n_t < 1) return bfmmm_io_fail("bfmmm_post_bands: bad arguments");
-  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_bands: at most 8192 kept draws in this build");
+  if (T > TBIG) return bfmmm_io_fail("bfmmm_post_bands: at most 2^24 kept draws");
   if (select_device(device, "bfmmm_post_bands")) return 1;
   Bufs b;
   double *dc, *dB, *df;
@@ -206,7 +286,7 @@ extern "C" int bfmmm_post_cov_bands(const double* coefL, const double* coefM, in
                                     double* lower, double* trace) {
   if (!coefL || !coefM || !B1 || !B2 || !upper || !mid || !lower || T < 2 || M < 1 || P < 1 || n1 < 1 || n2 < 1)
     return bfmmm_io_fail("bfmmm_post_cov_bands: bad arguments");
-  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_cov_bands: at most 8192 kept draws in this build");
+  if (T > TBIG) return bfmmm_io_fail("bfmmm_post_cov_bands: at most 2^24 kept draws");
   if (select_device(device, "bfmmm_post_cov_bands")) return 1;
   Bufs b;
   double *dl, *dm2, *dB1, *dB2, *dA, *dBm, *dV;
@@ -228,7 +308,7 @@ extern "C" int bfmmm_post_cov_bands(const double* coefL, const double* coefM, in
 extern "C" int bfmmm_post_table_bands(const double* V, int32_t T, int32_t ncol, double alpha, int32_t simultaneous, int32_t device,
                                       double* upper, double* mid, double* lower) {
   if (!V || !upper || !mid || !lower || T < 2 || ncol < 1) return bfmmm_io_fail("bfmmm_post_table_bands: bad arguments");
-  if (T > TMAX) return bfmmm_io_fail("bfmmm_post_table_bands: at most 8192 kept draws in this build");
+  if (T > TBIG) return bfmmm_io_fail("bfmmm_post_table_bands: at most 2^24 kept draws");
   if (select_device(device, "bfmmm_post_table_bands")) return 1;
   Bufs b;
   double* dV;

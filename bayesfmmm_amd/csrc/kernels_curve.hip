@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
   // multivariate model: G_i = I, so G u = u and the GU tile is the U tile (one tile less: a third workgroup per CU)
   const int TW = d.mv ? 1 : 2;
-  const int per_group = (TW * K + 3) * T::STR + MMAX + 32;
+  const int per_group = (TW * K + 3) * T::STR + MMAX + 48;      // (48: the K + K (K + 1) / 2 <= 44 quadratic forms)
   double* gbase = sYp + GPB + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + (TW - 1) * K * T::STR}, tS{gbase + TW * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
   double* sChi = gbase + (TW * K + 3) * T::STR;
@@ -253,16 +253,16 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
     ZT();
     __builtin_amdgcn_wave_barrier();
     // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2  -- one lane each
-    const int ntask = K + K * (K + 1) / 2;
-    if (lp < ntask) {
-      const double* ra = tU.row(lp);
+    const int ntask = K + K * (K + 1) / 2;      // (K = 7, 8: 35, 44 tasks -- more than a 32-lane group has lanes)
+    for (int q = lp; q < ntask; q += LPC) {
+      const double* ra = tU.row(min(q, K - 1));
       const double* rb = tS.row(0);
-      if (lp >= K) {
-        int a = 0, rem = lp - K;
+      if (q >= K) {
+        int a = 0, rem = q - K;
         while (rem >= K - a) { rem -= K - a; ++a; }
         ra = tU.row(a); rb = tG.row(a + rem);
       }
-      sRes[lp] = dotL<LPC>(ra, rb);
+      sRes[q] = dotL<LPC>(ra, rb);
     }
     __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
@@ -580,15 +580,15 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
         for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
       __builtin_amdgcn_wave_barrier();
       const int nzt = K + K * (K + 1) / 2;       // q < K: a_q = u_q's ;  q >= K: pair (k, k2), k <= k2: u_k' G u_k2
-      if (lp < nzt) {
-        const double* ra = tU.row(min(lp, K - 1));
+      for (int q = lp; q < nzt; q += LPC) {
+        const double* ra = tU.row(min(q, K - 1));
         const double* rb = tX.row(2);
-        if (lp >= K) {
-          int a = 0, rem = lp - K;
+        if (q >= K) {
+          int a = 0, rem = q - K;
           while (rem >= K - a) { rem -= K - a; ++a; }
           ra = tU.row(a); rb = tG.row(a + rem);
         }
-        sRes[lp] = dotL<LPC>(ra, rb);
+        sRes[q] = dotL<LPC>(ra, rb);
       }
       __builtin_amdgcn_wave_barrier();
       double q_old = cv.yy, q_new = cv.yy;
@@ -655,7 +655,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
   size_t lds;
   const int TW = c.d.mv ? 1 : 2;
-  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 32 + tileE);
+  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 48 + tileE);
   else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
   if (which == 1 || (do_update & 2)) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch (k_curve_chi, lean k_curve_z)
   lds = (lds + 8) * sizeof(double);

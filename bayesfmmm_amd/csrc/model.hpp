@@ -14,7 +14,7 @@
 
 namespace bfmmm {
 
-constexpr int KMAX = 6;     // clusters supported by the unrolled per-curve code
+constexpr int KMAX = 8;     // clusters supported by the unrolled per-curve code (bfmmm_config.c[8] has room for as many)
 constexpr int PMAX = 64;    // basis functions: one lane per basis function inside a curve group
 constexpr int BWMAX = 5;    // spline degree (band half-width) instantiated
 constexpr int BWWIDE = 31;  // the one wide-band instantiation (user-supplied / tensor-product bases, bfmmm_create_from_basis)

@@ -113,10 +113,10 @@ __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl
 }
 
 // Spare workgroups of k_factor (iteration t): the proposals of iteration t + 1 for 256 / GW curves each (GW lanes per curve:
-// 8 when 2K + 1 <= 8, else 16 -- zprep_lanes).
+// 8 when 2K + 1 <= 8, 16 when 2K + 1 <= 16, else 32 -- zprep_lanes).
 // Z, pi and alpha_3 are final for iteration t by then (k_curve_z and the pi / alpha_3 job ran before k_factor), and the
 // keyed RNG makes the variates a function of (seed, chain, t + 1) alone.  k_curve_z checks the tag before using them.
-__host__ __device__ inline int zprep_lanes(int K) { return (2 * K + 1 <= 8) ? 8 : 16; }
+__host__ __device__ inline int zprep_lanes(int K) { return (2 * K + 1 <= 8) ? 8 : (2 * K + 1 <= 16) ? 16 : 32; }
 
 template <int GW>
 __device__ inline void job_z_prepare_gw(const Ctx& c, int wg) {
@@ -148,7 +148,8 @@ __device__ inline void job_z_prepare_gw(const Ctx& c, int wg) {
 __host__ __device__ inline int zprep_curves_per_wg(int K) { return 256 / zprep_lanes(K); }
 __device__ inline void job_z_prepare(const Ctx& c, int wg) {
   if (zprep_lanes(c.d.K) == 8) job_z_prepare_gw<8>(c, wg);
-  else job_z_prepare_gw<16>(c, wg);
+  else if (zprep_lanes(c.d.K) == 16) job_z_prepare_gw<16>(c, wg);
+  else job_z_prepare_gw<32>(c, wg);
 }
 
 // Spare workgroups of k_factor: the n x M standard normals of THIS iteration's chi update (UpdateChi.h:57-59), which

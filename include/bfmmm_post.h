@@ -107,7 +107,8 @@ int bfmmm_MVBIC(const bfmmm_post_args* a, double* out);
  * bfmmm_post_col_quantiles: quantiles of every column of a T x ncol table (column-major, draw fastest) with Armadillo's
  * arma::quantile rule; out[q + nq * col].  bfmmm_post_bands: the table f[t][j] = B_j' coef_t (coef: T x P, one row per
  * draw; B: n_t x P row-major) and its pointwise (alpha / 2, 0.5, 1 - alpha / 2) or simultaneous bands
- * (src/PostProcessing.cpp:228-238, :284-302); trace (T x n_t, draw fastest) may be NULL.  At most 8192 draws. */
+ * (src/PostProcessing.cpp:228-238, :284-302); trace (T x n_t, draw fastest) may be NULL.  Columns of more than 8192
+ * draws are sorted through global memory (any length up to 2^24). */
 int bfmmm_post_col_quantiles(const double* V, int32_t T, int32_t ncol, const double* probs, int32_t nq, int32_t device, double* out);
 int bfmmm_post_bands(const double* coef, int32_t T, int32_t P, const double* B, int32_t n_t, double alpha, int32_t simultaneous,
                      int32_t device, double* upper, double* mid, double* lower, double* trace);

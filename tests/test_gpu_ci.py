@@ -211,7 +211,9 @@ def test_ci_argument_checks_and_quantile_edges():
     # the quantile primitive: ties, extremes beyond (N - 0.5) / N, a non-power-of-two and a one-element column
     lib = api._lib_entry()
     rng = np.random.default_rng(0)
-    for T in (1, 2, 7, 150, 1000, 4097):
+    # (8192 is the longest column sorted in LDS; 8193, 20000 and 40001 take the global-memory network: two, three and four
+    #  chunks / global exchange distances)
+    for T in (1, 2, 7, 150, 1000, 4097, 8192, 8193, 20000, 40001):
         V = np.asfortranarray(np.round(rng.standard_normal((T, 5)), 1))
         probs = np.array([0.0, 0.004, 0.025, 0.5, 0.75, 0.999, 1.0])
         out = np.zeros((len(probs), 5), order="F")
@@ -219,3 +221,27 @@ def test_ci_argument_checks_and_quantile_edges():
                                             out.ctypes.data_as(api.c_double_p)) == 0
         for c in range(5):
             np.testing.assert_allclose(out[:, c], R.arma_quantile(V[:, c], probs), rtol=1e-15)
+
+
+def test_bands_over_more_than_8192_draws():
+    """the reference has no limit on the number of kept draws (arma::quantile sorts any length): pointwise and simultaneous bands
+    of a 12000-draw table against the numpy oracle"""
+    from bayesfmmm_amd import api
+    lib = api._lib_entry()
+    rng = np.random.default_rng(5)
+    T, ncol = 12000, 7
+    V = np.asfortranarray(rng.standard_normal((T, ncol)) * np.arange(1, ncol + 1) + np.arange(ncol))
+    for simultaneous in (0, 1):
+        up, mid, lo = (np.zeros(ncol) for _ in range(3))
+        assert lib.bfmmm_post_table_bands(V.ctypes.data_as(api.c_double_p), T, ncol, 0.05, simultaneous, 0, up.ctypes.data_as(api.c_double_p),
+                                          mid.ctypes.data_as(api.c_double_p), lo.ctypes.data_as(api.c_double_p)) == 0
+        if simultaneous:
+            m, sd = V.mean(axis=0), V.std(axis=0, ddof=1)
+            qc = R.arma_quantile(np.abs((V - m) / sd).max(axis=1), np.array([0.95]))[0]
+            ref_up, ref_mid, ref_lo = m + qc * sd, m, m - qc * sd
+        else:
+            q = np.stack([R.arma_quantile(V[:, c], np.array([0.025, 0.5, 0.975])) for c in range(ncol)])
+            ref_lo, ref_mid, ref_up = q[:, 0], q[:, 1], q[:, 2]
+        np.testing.assert_allclose(up, ref_up, rtol=1e-12)
+        np.testing.assert_allclose(mid, ref_mid, rtol=1e-12)
+        np.testing.assert_allclose(lo, ref_lo, rtol=1e-12)

@@ -34,7 +34,9 @@ def simulate(n, K, M, degree, n_internal, seed, n_pts=60):
 @pytest.mark.parametrize("K,M,degree,n_internal,n", [
     (2, 1, 1, 3, 33),      # band width 1, a single eigenfunction
     (4, 5, 2, 6, 70),      # band width 2, A*P = 216
-    (6, 2, 3, 8, 90),      # the largest K, P = 12
+    (6, 2, 3, 8, 90),      # K = 6, P = 12
+    (7, 1, 3, 4, 80),      # K = 7: 2 K + 1 = 15 lanes per curve in the Z-proposal job
+    (8, 2, 2, 5, 96),      # the largest K (2 K + 1 = 17: 32 lanes per curve), A * P = 192
     (3, 7, 4, 10, 50),     # band width 4, odd M, P = 15
     (2, 3, 5, 20, 40),     # band width 5, P = 26
     (5, 9, 3, 26, 64),     # A*P = 1500 > 704: the general sweep kernel, P = 30
@@ -75,6 +77,7 @@ def test_warm_trajectory_matches_oracle_across_shapes(K, M, degree, n_internal, 
     (2, 1, 1, 6, 130, 8, True),     # the largest D, band width 1, more than one k_cov_group workgroup
     (4, 2, 5, 10, 37, 1, False),    # band width 5, mean adjustment only
     (3, 5, 4, 20, 33, 4, True),     # band width 4, P = 25, odd M
+    (7, 2, 3, 6, 60, 2, True),      # K = 7 with covariates
 ])
 def test_covariate_adjusted_trajectory_across_shapes(K, M, degree, n_internal, n, D, cov_adj):
     """The eta / Xi block (k_cov_prep, k_cov_w2, k_cov_factor, k_cov_group, k_cov_hyper) and the covariate variants of the
@@ -132,7 +135,7 @@ def test_covariate_adjusted_trajectory_across_shapes(K, M, degree, n_internal, n
 
 
 def test_build_limits_fail_loudly():
-    """The limits of this build that the reference does not have (K <= 6, P <= 64, n_eigen <= 16, degree <= 5, D <= 8) are
+    """The limits of this build that the reference does not have (K <= 8, P <= 64, n_eigen <= 16, degree <= 5, D <= 8) are
     refused at set-up with a message that names the limit -- never truncated, never run on another path."""
     import bayesfmmm_amd as bf
     from bayesfmmm_amd import _lib
@@ -145,8 +148,8 @@ def test_build_limits_fail_loudly():
         cfg = bf.default_config(**{k: v for k, v in args.items() if not k.startswith("_")})
         return bf.Sampler(cfg, sim["y"], sim["t"], ik, sim["boundary_knots"])
 
-    with pytest.raises(_lib.BfmmmError, match="K larger than 6"):
-        make(K=7)
+    with pytest.raises(_lib.BfmmmError, match="K larger than 8"):
+        make(K=9)
     with pytest.raises(_lib.BfmmmError, match="n_eigen larger than 16"):
         make(n_eigen=17)
     with pytest.raises(_lib.BfmmmError, match="basis_degree larger than 5"):
