@@ -1229,10 +1229,14 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
   // ---- ONE round of global loads: the run's step tables, the iteration's scalars, and every thread's rows ----
   const int4* gent = (const int4*)c.sweep_tab;
   const int* ghstp = c.sweep_tab + 8 * (A + 2);
-  // row thread 64 + rk PH + pp owns rows p0 = 2 pp and p0 + 1 of the direction updated at step rk
-  const bool isB = tid >= 64 && tid - 64 < A * PH;
-  const int e2i = min(max(tid - 64, 0), A * PH - 1);
-  const int rk = e2i / PH, p0 = 2 * (e2i - rk * PH);
+  // row thread 64 + rk LRK + pp (pp < PH) owns rows p0 = 2 pp and p0 + 1 of the direction updated at step rk; a rank takes
+  // LRK = 4, 8 or 16 lanes, so that the threads of a rank sit in ONE 16-lane DPP row (the band entries below the diagonal come
+  // from the neighbouring threads' registers, see the row threads' loads)
+  const int lrk_log = (PH <= 4) ? 2 : (PH <= 8) ? 3 : 4, LRK = 1 << lrk_log;
+  const int e2i = max(tid - 64, 0);
+  const int ppr = e2i & (LRK - 1);
+  const bool isB = tid >= 64 && (e2i >> lrk_log) < A && ppr < PH;
+  const int rk = min(e2i >> lrk_log, A - 1), p0 = 2 * min(ppr, PH - 1);
   const bool two = p0 + 1 < P;               // (odd P: the last thread of a rank owns one row)
   const int p1 = two ? p0 + 1 : p0;
   const int b = rank_dir(d, rk, n_phi, n_nu);
@@ -1427,21 +1431,56 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
     int rk_lo = live ? rk : (1 << 20);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rk_lo = min(rk_lo, __shfl_xor(rk_lo, o, 64));
-    const int* hs_b = hstp + b * A;                  // hs_b[s] = byte offset of block (b, a_s) in H2
-    struct H2r { SweepH<BW> a, b; };
+    const int* hs_b = hstp + b * A;                  // hs_b[s] = byte offset of block (b, a_s) in H2 (= twice its offset in H)
+    // The rows of H_{b, a_s} come from the band-packed array H (G(p, p + d) at [d P + p]: half the bytes of the H2 rows; the sweep
+    // is bound by the bytes one compute unit can pull through its L1): a thread loads the UPPER band entries of its two rows, one
+    // 16-byte piece per diagonal, and takes the entries below the diagonal -- G(p, p - d) = G(p - d, p), which the thread owning
+    // row p - d has loaded -- from its neighbours' registers on the DPP path (the threads of a rank share a 16-lane row).
+    struct H2r { v2d u[BW + 1]; };                   // u[d] = (G(p0, p0 + d), G(p0 + 1, p0 + 1 + d))
+    // (every lane loads at every step of its wave: predicating the loads on "the step is one of this lane's" made the kernel
+    //  1.6 us slower -- the compiler then waits for each conditional group on its own)
+    auto is_mine = [&](int s) { return live && (s <= rk - 3 || s == rk); };
     auto loadH = [&](H2r& s, int off) {
 #ifndef SWC_HELPER_NOLOAD
-      const v2d* blk = (const v2d*)((const char*)c.H2 + (uint32_t)off);
+      const char* blk = (const char*)c.H + ((uint32_t)off >> 1);
 #pragma unroll
-      for (int k = 0; k <= BW; ++k) { s.a.h[k] = blk[k * P + p0]; s.b.h[k] = blk[k * P + p1]; }
+      for (int dd = 0; dd <= BW; ++dd) s.u[dd] = *(const v2d*)(blk + (size_t)(dd * P + p0) * 8);
 #endif
+    };
+    // (va, vb) = (H_{b, a_s} delta)[p0], [p0 + 1] with dv[k] = delta[p0 - BW + k]
+    auto band2 = [&](const H2r& hc, const double (&dv)[W + 1], double& va, double& vb) {
+      double a0 = hc.u[0].x * dv[BW], a1 = 0.0, b0 = hc.u[0].y * dv[BW + 1], b1 = 0.0;
+#pragma unroll
+      for (int dd = 1; dd <= BW; ++dd) {
+        // lower entries: row p0 takes G(p0 - dd, p0), row p0 + 1 takes G(p0 + 1 - dd, p0 + 1)
+        double l0, l1;
+        if (dd & 1) {
+          constexpr int dummy = 0; (void)dummy;
+          const int sh0 = (dd + 1) >> 1, sh1 = (dd - 1) >> 1;
+          const double y = hc.u[dd].y, x = hc.u[dd].x;
+          const double g0 = (sh0 == 1) ? dpp_get<0x111>(y) : (sh0 == 2) ? dpp_get<0x112>(y) : dpp_get<0x113>(y);
+          const double g1 = (sh1 == 0) ? x : (sh1 == 1) ? dpp_get<0x111>(x) : dpp_get<0x112>(x);
+          l0 = (ppr >= sh0) ? g0 : 0.0;
+          l1 = (ppr >= sh1) ? g1 : 0.0;
+        } else {
+          const int sh = dd >> 1;
+          const double y = hc.u[dd].y, x = hc.u[dd].x;
+          const double g0 = (sh == 1) ? dpp_get<0x111>(x) : dpp_get<0x112>(x);
+          const double g1 = (sh == 1) ? dpp_get<0x111>(y) : dpp_get<0x112>(y);
+          l0 = (ppr >= sh) ? g0 : 0.0;
+          l1 = (ppr >= sh) ? g1 : 0.0;
+        }
+        a0 += hc.u[dd].x * dv[BW + dd]; a1 += l0 * dv[BW - dd];
+        b0 += hc.u[dd].y * dv[BW + 1 + dd]; b1 += l1 * dv[BW + 1 - dd];
+      }
+      va = a0 + a1; vb = b0 + b1;
     };
     // The steps the WAVE walks (wave-uniform): 0 .. rk_hi - 3 (some lane's lagging update), then rk_lo .. rk_hi (some lane's
     // own term).  Every lane loads the rows of H_{b, a_s} for every step of the wave, one step ahead, so that the two register
     // sets alternate without a copy; a lane uses the result when the step is one of its own: s <= rk - 3 or s == rk.
     auto next_w = [&](int s) { return (s + 1 <= rk_hi - 3 || s + 1 >= rk_lo) ? s + 1 : rk_lo; };
     auto process = [&](int s, const H2r& hc) {
-      const bool mine = live && (s <= rk - 3 || s == rk);
+      const bool mine = is_mine(s);
       const double* dls = dl + s * DLS;
       {
         int spins = 0;
@@ -1462,13 +1501,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
       do {
 #pragma unroll
         for (int k = 0; k <= W; ++k) dv[k] = lds_ld(dls + p0 + k);
-        double a0 = hc.a.h[0].x * dv[0], a1 = hc.a.h[0].y * dv[1], b0 = hc.b.h[0].x * dv[1], b1 = hc.b.h[0].y * dv[2];
-#pragma unroll
-        for (int k = 1; k <= BW; ++k) {
-          a0 += hc.a.h[k].x * dv[2 * k]; a1 += hc.a.h[k].y * dv[2 * k + 1];
-          b0 += hc.b.h[k].x * dv[2 * k + 1]; b1 += hc.b.h[k].y * dv[2 * k + 2];
-        }
-        va = a0 + a1; vb = b0 + b1;
+        band2(hc, dv, va, vb);
         // a delta slot still holding the sentinel makes the sum a NaN: read again (the first element was seen, the rest of
         // the chain's one store instruction follows within cycles)
         bool bad = false;
@@ -1683,8 +1716,9 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     }
     return 0;
   }
-  if (d.P <= 32 && d.A * ((d.P + 1) / 2) <= SWC_THREADS - 64 && d.BW <= 5) {      // fast path: the chain in one wave
-    const int nthr = 64 + (d.A * ((d.P + 1) / 2) + 63) / 64 * 64;
+  const int swc_ph = (d.P + 1) / 2, swc_lrk = swc_ph <= 4 ? 4 : swc_ph <= 8 ? 8 : 16;      // lanes per rank of the row threads
+  if (d.P <= 32 && d.A * swc_lrk <= SWC_THREADS - 64 && d.BW <= 5) {      // fast path: the chain in one wave
+    const int nthr = 64 + (d.A * swc_lrk + 63) / 64 * 64;
     const size_t lds = (5 * (((size_t)d.A * d.P + 1) & ~(size_t)1) + 32 + (size_t)d.A * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + 2 * ((size_t)d.A + 2) * sizeof(int4) +
                        ((size_t)d.A * d.A + (size_t)d.A + 8) * sizeof(int) + 16;
     switch (d.BW) {
