@@ -477,7 +477,9 @@ __device__ inline int step_dir(const Dims& d, int s, int n_phi);
 // route instead (factor_pinv, factor_core.hpp).
 // ---------------------------------------------------------------------------------------------
 template <int PP, int BW>
-__global__ __launch_bounds__(256, (BW <= 5) ? 4 : 1) void k_factor(Ctx c0) {
+// (three workgroups per CU: at four the 128-register cap spilled 62 registers of the factorisation path to scratch -- one chain
+//  64.7 us per iteration against 65.6, 8 Nu_Z chains 103 k iterations/s against 100 k; the spare jobs of a batch still overlap)
+__global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   // one-dimensional grid of chains x jobs with the chain index running FASTEST, so that the long factorisation workgroups
   // of every chain of a batch are dispatched before any of the short spare jobs (workgroups start in index order)
   const int nch_ = c0.nch;
