@@ -284,9 +284,10 @@ def config5_record(bf, w, torch, dist, backend, rank, world, local_rank, steps, 
     except Exception:
         pm5 = None
     traffic = None
-    if pm5:      # measured bytes of one step of the 8-chain batch on ONE GPU (FETCH_SIZE x 2 + WRITE_SIZE, all kernels)
-        traffic = sum((v.get("hbm_read_bytes_per_launch") or 0.0) + (v.get("hbm_write_bytes_per_launch") or 0.0)
-                      for k, v in pm5.items() if k.startswith("k_") and v.get("calls", 0) >= 50)
+    if pm5:      # measured bytes of one step of the 8-chain batch on ONE GPU (FETCH_SIZE x 2 + WRITE_SIZE): every kernel runs once
+        # per half-batch and step, i.e. twice per step of the 8 chains (the profiled run: 120 steps)
+        traffic = sum(2.0 * ((v.get("hbm_read_bytes_per_launch") or 0.0) + (v.get("hbm_write_bytes_per_launch") or 0.0))
+                      for k, v in pm5.items() if k.startswith("k_") and v.get("calls", 0) >= 200)
     return dict(workload=f"BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains of the Nu_Z sweep) on the config-2 data, dealt "
                          f"round-robin over {world} GPU(s), {-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch",
                 scaling="strong", n_gpus=world, chains=N_CHAINS_CONFIG5, chains_per_gpu=-(-N_CHAINS_CONFIG5 // world), steps=steps,

@@ -6,7 +6,7 @@
 #   4. --kernel-trace --stats of the 8-chain batches (warm start and Nu_Z: BASELINE configs[4]) and of configs[2], [3]
 # Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profile.py condenses them into profiles/.
 set -uo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -23,4 +23,8 @@ for spec in warm:8 nu_z:1 nu_z:8 config3:1 config4:1; do
   wl=${spec%%:*}; ch=${spec##*:}
   rocprofv3 --kernel-trace --stats -d "$OUT/${wl}_${ch}" -o run -- python3 "$ROOT/tools/prof_workload.py" --workload "$wl" --chains "$ch" --steps 300 > "$OUT/${wl}_${ch}.json" 2> "$OUT/${wl}_${ch}.err" && echo "$spec done: $(cat "$OUT/${wl}_${ch}.json")"
 done
+# FETCH_SIZE / WRITE_SIZE of the 8-chain Nu_Z batch (BASELINE configs[4] on one GPU): bench.py's config5.roofline.traffic
+unset BFMMM_BATCH_SPLIT
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/nu_z_8_pmc_fetch" -o run -- python3 "$ROOT/tools/prof_workload.py" --workload nu_z --chains 8 --steps 100 > "$OUT/nu_z_8_fetch.log" 2>&1 && echo "nu_z:8 fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/nu_z_8_pmc_write" -o run -- python3 "$ROOT/tools/prof_workload.py" --workload nu_z --chains 8 --steps 100 > "$OUT/nu_z_8_write.log" 2>&1 && echo "nu_z:8 write done"
 find "$OUT" -name "*.db" | head -20

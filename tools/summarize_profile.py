@@ -84,8 +84,24 @@ def main():
         json.dump(mf, open(dst / f"{tag}_mfma_pmc.json", "w"), indent=1, sort_keys=True)
         for k, v in mf.items():
             print("mfma", k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+    # FETCH_SIZE / WRITE_SIZE of the 8-chain Nu_Z batch (per launch of each kernel; a step of the batch = one launch of each
+    # kernel per half-batch, calls_per_step below)
+    nzf, nzw = src / "nu_z_8_pmc_fetch" / "run_results.db", src / "nu_z_8_pmc_write" / "run_results.db"
+    if nzf.exists() and nzw.exists():
+        ksn = kernel_stats(nzf)
+        fz, wz = pmc_per_launch(nzf, "FETCH_SIZE"), pmc_per_launch(nzw, "WRITE_SIZE")
+        sm = {}
+        for k in ksn:
+            if not k.startswith("k_"):
+                continue
+            f_kb, w_kb = fz.get(k), wz.get(k)
+            sm[k] = dict(calls=ksn[k]["calls"], avg_us=ksn[k]["avg_ns"] / 1e3, fetch_size_kb_raw=f_kb, write_size_kb_raw=w_kb,
+                         hbm_read_bytes_per_launch=None if f_kb is None else 2.0 * f_kb * 1024.0,
+                         hbm_write_bytes_per_launch=None if w_kb is None else w_kb * 1024.0)
+        json.dump(sm, open(dst / f"{tag.replace('_final', '')}_nu_z_8_pmc_summary.json", "w"), indent=1, sort_keys=True)
     # the other workloads of the round: per-kernel statistics
-    for sub in sorted(p for p in src.iterdir() if p.is_dir() and (p / "run_results.db").exists() and p.name not in ("trace", "pmc_fetch", "pmc_write", "pmc_mfma")):
+    skip = ("trace", "pmc_fetch", "pmc_write", "pmc_mfma", "nu_z_8_pmc_fetch", "nu_z_8_pmc_write")
+    for sub in sorted(p for p in src.iterdir() if p.is_dir() and (p / "run_results.db").exists() and p.name not in skip):
         ks2 = kernel_stats(sub / "run_results.db")
         tot2 = sum(o["total_ns"] for o in ks2.values())
         with open(dst / f"{tag.replace('_final', '')}_{sub.name}_kernel_stats.csv", "w") as f:
