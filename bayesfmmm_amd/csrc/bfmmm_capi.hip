@@ -888,6 +888,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       const hipError_t ei = hipGraphInstantiate(g, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIPCHK(ei);
+      (void)hipGraphUpload(*g, sb.st);      // (set-up: the first launch of a graph otherwise pays for its upload)
       return 0;
     };
     // a run of nrep repetitions = nrep / GRAPH_UNROLL replays of the unrolled graph + ONE graph holding the remainder
