@@ -390,6 +390,13 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   if (blockIdx.x < 8) return;
   const int blk = blockIdx.x - 8;
   const int do_update = (mode == 2);
+#ifdef BFMMM_TIMELINE
+  unsigned long long ct_[10]; int ci_ = 0;
+#define CT() do { ct_[ci_++] = clock64(); } while (0)
+#else
+#define CT() do { } while (0)
+#endif
+  CT();
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int GPB = 256 / LPC;
   using T = Tile<BW, LPC>;
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     tX.row(2)[lp] = cv.s;
   }
   __syncthreads();
+  CT();
   // covariate adjustment folded into the sums below (see k_curve_z): no per-curve tile of effective rows
   double xv[8];
 #pragma unroll
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     }
     tX.row(0)[lp] = cf;
     __builtin_amdgcn_wave_barrier();
+    CT();
     const double g0 = cv.matvec(tX.row(0), lp);
     tX.row(1)[lp] = cv.s - g0;
     if (!d.mv)
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+    CT();
     // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)
     rss = cv.yy - sRes[nA + Mu] - sRes[nA + Mu + 1];
     if (Mu > 0) {
@@ -551,6 +561,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       c.cfull[(size_t)i * P + lp] = tX.row(0)[lp];
       c.gfull[(size_t)i * P + lp] = cv.s - tX.row(1)[lp];
     }
+    CT();
     if (fuse_z && !zpre && lp == 0) atomicOr(&c.dyn->status, 2u);      // cannot happen in a fused run (see below); reported by bfmmm_run
     if (fuse_z && zpre) {
       // ---- updateZ_PM of iteration it_next for this curve (UpdateMixedMembership.h:131-185), as in k_curve_z:
@@ -626,6 +637,10 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
         }
     }
   }
+  CT();
+#ifdef BFMMM_TIMELINE
+  if (blockIdx.x == 8 && threadIdx.x == 0) for (int x = 0; x + 1 < ci_; ++x) c.dyn->stamps[32 + x] = ct_[x + 1] - ct_[x];
+#endif
   if (lp == 0) sRss[grp] = rss;
   if (fuse_z && lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
   __syncthreads();

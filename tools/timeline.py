@@ -77,6 +77,7 @@ def run(a):
             print(f"  k_sweep_chain: chain loop {(st[25] - st[24]) / 100:.2f} us, pick spins of the chain wave {int(st[26])}; loop starts {(st[24] - st[8]) / 100:.2f} us into the kernel")
             rel = [(st[i] - st[8]) / 100 for i in (28, 24, 25, 30)] + [(st[9] - st[8]) / 100]
             print("  k_sweep_chain stamps (us from kernel start): loads back, LDS set up %.2f | loop start %.2f | chain done %.2f | all rows done %.2f | end %.2f" % tuple(rel))
+        print("  k_curve_chi workgroup 8 phase clocks (load+stage | u_m, c0 | G u_m, dots | Gauss-Seidel, rss | fused Z):", [int(x) for x in st[32:37]])
         pg = st[40:49]
         print("  pair_gram wg0 stamps rel:", [round((x - st[2]) / 100, 2) for x in pg if x > 0])
 
