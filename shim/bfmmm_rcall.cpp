@@ -294,9 +294,11 @@ void set_warm(bfmmm_entry_args& a, SEXP dir, SEXP thinning_num, SEXP beta_N_t, S
   a.progress_every = 100; a.progress_cb = progress_from_R;
 }
 
+// (p1 / p2: the previous-stage results the call was given; their owners are the callers' Owned objects)
 SEXP finish(int rc, bfmmm_result* r, const std::vector<int64_t>* offsets, bfmmm_result* p1 = NULL, bfmmm_result* p2 = NULL) {
-  Owned o1, o2, o3;
-  o1.r = p1; o2.r = p2; o3.r = r;
+  (void)p1; (void)p2;
+  Owned o3;
+  o3.r = r;
   if (rc) lib_error();                                   // (r is NULL on failure)
   return result_to_list(r, offsets);
 }
@@ -381,7 +383,8 @@ SEXP _BayesFMMM_BFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y,
   set_X(a, X, covariance_adj, in);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
   SHIM_END
@@ -403,8 +406,10 @@ SEXP _BayesFMMM_BFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP time,
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
-  bfmmm_result* te = list_to_result(theta_est);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
+  Owned ote; ote.r = list_to_result(theta_est);
+  bfmmm_result* te = ote.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
   SHIM_END
@@ -438,7 +443,8 @@ SEXP _BayesFMMM_BMVMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP Y
   set_X(a, X, covariance_adj, in);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BMVMMM_Theta_est(&a, mt, &r), r, NULL, mt);
   SHIM_END
@@ -458,8 +464,10 @@ SEXP _BayesFMMM_BMVMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP n_ei
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
-  bfmmm_result* te = list_to_result(theta_est);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
+  Owned ote; ote.r = list_to_result(theta_est);
+  bfmmm_result* te = ote.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BMVMMM_warm_start(&a, mt, te, &r), r, NULL, mt, te);
   SHIM_END
@@ -499,7 +507,8 @@ SEXP _BayesFMMM_BHDFMMM_Theta_est(SEXP tot_mcmc_iters, SEXP n_try, SEXP K, SEXP 
   set_X(a, X, covariance_adj, in);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BHDFMMM_Theta_est(&a, mt, &r), r, &y.off, mt);
   SHIM_END
@@ -522,8 +531,10 @@ SEXP _BayesFMMM_BHDFMMM_warm_start(SEXP tot_mcmc_iters, SEXP K, SEXP Y, SEXP tim
   set_warm(a, dir, thinning_num, beta_N_t, N_t, n_temp_trans, r_stored_iters);
   set_hyper(a, HY19, in);
   a.seed = seed_from_R();
-  bfmmm_result* mt = list_to_result(multiple_try);
-  bfmmm_result* te = list_to_result(theta_est);
+  Owned omt; omt.r = list_to_result(multiple_try);       // owned from the moment it exists (a later conversion may throw)
+  bfmmm_result* mt = omt.r;
+  Owned ote; ote.r = list_to_result(theta_est);
+  bfmmm_result* te = ote.r;
   bfmmm_result* r = NULL;
   return finish(bfmmm_BHDFMMM_warm_start(&a, mt, te, &r), r, &y.off, mt, te);
   SHIM_END
