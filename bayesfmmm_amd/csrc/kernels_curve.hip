@@ -387,6 +387,18 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   // Workgroups 1-7 are idle: they keep curve block b at grid index 8 + b, i.e. on the XCD that runs block b of
   // k_curve_z (workgroups go to the XCDs round-robin), so the Z / chi / record lines the two kernels hand each other
   // iteration after iteration stay in that XCD's L2.
+#ifdef BFMMM_TIMELINE
+  // per-workgroup trace (start, XCC / HW id, end) of the curve workgroups and of the scalar-job workgroup, in k_curve_z's array
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    unsigned id, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_ztrace[3 * blockIdx.x] = wall_clock64();
+    g_ztrace[3 * blockIdx.x + 1] = ((unsigned long long)(id & 0xf) << 32) | hw;
+    if (blockIdx.x == 0) c.dyn->stamps[39] = ((c.dyn->stamps[39] << 4) | (id & 0xf)) & 0xFFFFFFFFFULL;      // history of block 0's XCC, one nibble per launch
+  }
+  struct EndTraceC { __device__ ~EndTraceC() { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ztrace[3 * blockIdx.x + 2] = wall_clock64(); } } etc_;
+#endif
   if (blockIdx.x < 8) return;
   const int blk = blockIdx.x - 8;
   const int do_update = (mode == 2);

@@ -1201,6 +1201,9 @@ template <int BW>
 __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   TIMELINE(c, 4);
+#ifdef BFMMM_TIMELINE
+  if (threadIdx.x == 0) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id)); c.dyn->stamps[38] = ((c.dyn->stamps[38] << 4) | (id & 0xf)) & 0xFFFFFFFFFULL; }
+#endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
   const int P = d.P, A = d.A, K = d.K, M = d.M, MD = d.MD;

@@ -78,6 +78,29 @@ def run(a):
             rel = [(st[i] - st[8]) / 100 for i in (28, 24, 25, 30)] + [(st[9] - st[8]) / 100]
             print("  k_sweep_chain stamps (us from kernel start): loads back, LDS set up %.2f | loop start %.2f | chain done %.2f | all rows done %.2f | end %.2f" % tuple(rel))
         print("  k_curve_chi workgroup 8 phase clocks (load+stage | u_m, c0 | G u_m, dots | Gauss-Seidel, rss | fused Z):", [int(x) for x in st[32:37]])
+        try:
+            zt = smp.get_state("ztrace").reshape(-1, 3)[:520]
+            t00 = zt[8:, 0].min()
+            dur = (zt[8:, 2] - zt[8:, 0]) / 100.0
+            end = (zt[8:, 2] - t00) / 100.0
+            xcc = (zt[8:, 1] // 2**32).astype(int)
+            hw = zt[8:, 1].astype(np.int64) % 2**32
+            cu = (hw >> 8) & 0xf
+            se = (hw >> 13) & 0x7 if False else (hw >> 12) & 0xf
+            print("  k_curve_chi curve workgroups: duration us min %.2f median %.2f p90 %.2f max %.2f; end us median %.2f max %.2f" %
+                  (dur.min(), np.median(dur), np.percentile(dur, 90), dur.max(), np.median(end), end.max()))
+            for x in range(8):
+                m = xcc == x
+                if m.any():
+                    print("    XCC %d: %3d workgroups, duration median %.2f max %.2f, start median %.2f" % (x, m.sum(), np.median(dur[m]), dur[m].max(), np.median((zt[8:, 0][m] - t00) / 100.0)))
+            slow = np.argsort(-dur)[:8]
+            print("    slowest:", [(int(b), round(float(dur[b]), 2), int(xcc[b]), hex(int(hw[b]))) for b in slow])
+            raw = smp.get_state("stamps")
+            print("    XCC of block 0, last launches (oldest first): k_curve_chi %s | k_sweep_chain %s" %
+                  (format(int(raw[39]), "09x"), format(int(raw[38]), "09x")))
+            print("    scalar-job workgroup 0: duration %.2f us, XCC %d, hw %s" % ((zt[0, 2] - zt[0, 0]) / 100.0, int(zt[0, 1] // 2**32), hex(int(zt[0, 1]) % 2**32)))
+        except Exception as e:
+            print("  (no ztrace:", e, ")")
         pg = st[40:49]
         print("  pair_gram wg0 stamps rel:", [round((x - st[2]) / 100, 2) for x in pg if x > 0])
 
