@@ -110,9 +110,12 @@ void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_
 // advances the iteration counters at its end), so the curve workgroups take the iteration and the chain slot from the
 // snapshot the sweep left (iter_hyper + 1, slot_hyper + 1), as the fused update in k_curve_chi does; curve block b sits at
 // grid index 8 + b (workgroups 1-7 idle), on the XCD of k_curve_chi's block b.
-template <int BW, int LPC, bool COV, int KT, bool LEAN = false>
+// KEX: K == KT exactly, a compile-time constant (see k_curve_chi's exact instances): 16.6 -> 14.4 us for the 8-chain batch of config 5.
+template <int BW, int LPC, bool COV, int KT, bool LEAN = false, bool KEX = false>
 __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) void k_curve_z(Ctx c0, int do_update) {
-  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
+  Ctx cx = chain_view(c0);           // chain blockIdx.z of the batch
+  if constexpr (KEX) { cx.d.K = KT; cx.d.A = KT * cx.d.MD; }
+  const Ctx& c = cx;
   TIMELINE(c, 0);
   if (LEAN && blockIdx.x < 8) {
     if (blockIdx.x == 0) job_hyper(c);
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
-  const uint32_t it_cur = LEAN ? dyn->iter_hyper + 1u : dyn->iter, slot_cur = LEAN ? dyn->slot_hyper + 1u : dyn->slot;
+  const DynHead dh = dyn_head(dyn);                 // (one batch of loads, not a trip per field: model.hpp)
+  const uint32_t it_cur = LEAN ? dh.iter_hyper + 1u : dh.iter, slot_cur = LEAN ? dh.slot_hyper + 1u : dh.slot;
   // ---- all global loads are requested up front.  Z first: the proposal phase below needs nothing else, and loads
   //      retire in issue order, so it can start while the record, theta and chi are still on their way ----
   double Zold[KMAX];
@@ -171,17 +175,17 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   Curve<BW, LPC> cv;
   cv.load(c.rec + (size_t)min(i, n - 1) * d.LREC, P, d.LG, lp);
   const double chi_l = (MD > 1 && lp < M) ? c.chi[min(i, n - 1) + (size_t)n * min(lp, M - 1)] : 0.0;
-  const double sigma2 = dyn->sigma2, alpha3 = dyn->alpha3, beta = dyn->beta;
+  const double sigma2 = dh.sigma2, alpha3 = dh.alpha3, beta = dh.beta;
   // ---- proposal phase (UpdateMixedMembership.h:131-150): everything of the update that does not depend on the data
   //      (z_proposal.hpp).  Normally it was prepared during the previous iteration's k_factor; otherwise (first
   //      iteration of a run, tempered sweeps, changed state) it is evaluated here, while the loads are in flight ----
   ZProposal zp;
   if (valid && do_update) {
-    const bool pre = dyn->zprep_valid && dyn->zprep_iter == it_cur && dyn->zprep_tt == dyn->tt_step &&
-                     dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed && D == 0;
+    const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == it_cur) & (dh.zprep_tt == dh.tt_step) &
+                     (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed) & (D == 0);
     if (pre) z_proposal_load(c, i, zp);
     else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
-    else z_proposal<LPC>(c, make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
+    else z_proposal<LPC>(c, make_key(c.seed, c.chain, dh.iter, dh.tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
   }
   // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
 #pragma unroll
@@ -367,10 +371,20 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
 // ------------------------------------------------------------------------------------------------
 // SMALL: K <= 4 and M <= 8 -- the per-cluster and per-eigenfunction loops are unrolled to those bounds instead of KMAX = 6 and
 // MMAX = 16 (the Gauss-Seidel recursion and the residual update are MMAX^2 guarded terms otherwise): 18.7 -> 17.4 us at config 2
-template <int BW, int LPC, bool COV, bool SMALL>
+// KX, MX > 0: an EXACT-shape instance -- K and M are compile-time constants (BFMMM_CHI_EXACT below lists the pairs built).  The
+// kernel is bound by the latency of its dependent LDS reads, two waves to a SIMD; with run-time K and M every "k < K" / "m < M"
+// guard inside the unrolled loops is a uniform branch that ends a batch of LDS reads (each batch then costs its own wait), and the
+// packed-triangle indices of the Gauss-Seidel recursion are computed addresses.  With the two constants the loops unroll into
+// straight-line code whose reads are issued together: 16.0 -> 12.7 us at config 2 (K 3, M 6); K alone or M alone gives 1.3 - 1.5 us.
+template <int BW, int LPC, bool COV, bool SMALL, int KX = 0, int MX = 0>
 __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
-  constexpr int KT = SMALL ? 4 : KMAX, MT = SMALL ? 8 : MMAX;
-  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
+  static_assert((KX > 0) == (MX > 0) && KX <= KMAX && MX <= MMAX, "exact instances fix both K and M");
+  constexpr int KT = KX ? KX : (SMALL ? 4 : KMAX), MT = MX ? MX : (SMALL ? 8 : MMAX);
+  Ctx cx = chain_view(c0);           // chain blockIdx.z of the batch
+  if constexpr (KX > 0) {            // (the launcher checked K == KX, M == MX; every use below, helpers included, sees constants)
+    cx.d.K = KX; cx.d.M = MX; cx.d.MD = (cx.d.MD > 1) ? MX + 1 : 1; cx.d.A = KX * cx.d.MD;
+  }
+  const Ctx& c = cx;
   TIMELINE(c, 5);
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
   if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
@@ -432,68 +446,87 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   double* sChi = gbase + (TW * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
   double* sZn = sChi + M + 1;
   double* sRes = sZn + M + 1;
-  copy_to_lds<4>(sTh, c.theta, nth, threadIdx.x, 256);
-  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   const int i = blk * GPB + grp;
   const bool valid = i < n;
+  const int ic = min(i, n - 1);
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
-  const double sigma2 = dyn->sigma2, beta = dyn->beta;
-  Curve<BW, LPC> cv;
-  if (valid) {
-    cv.load(c.rec + (size_t)i * d.LREC, P, d.LG, lp);
-    tU.zero_pads(TW * RT + 3, lp);
-    if (lp <= M) sChi[lp] = (MD > 1 && lp < M) ? c.chi[i + (size_t)n * min(lp, M - 1)] : 0.0;
-    tX.row(2)[lp] = cv.s;
-  }
-  __syncthreads();
-  CT();
-  // covariate adjustment folded into the sums below (see k_curve_z): no per-curve tile of effective rows
-  double xv[8];
+  // ---- ALL global loads of the workgroup are requested up front, into registers, before the first of them is waited for (as in
+  //      k_curve_z), and WITHOUT branches (clamped addresses, values masked afterwards): a load behind a uniform branch makes the
+  //      compiler wait for everything outstanding (vmcnt(0)) at the first use behind the join.  The small operands first and the
+  //      record -- nine tenths of the bytes -- last: loads retire in issue order, and u_m / c0 below need only the small ones. ----
+  const DynHead dh = dyn_head(dyn);                 // (one batch of loads, not a trip per field: model.hpp)
+  double thv[4];                                     // first 1024 entries of theta (the rest, if any, follows below)
 #pragma unroll
-  for (int dd = 0; dd < 8; ++dd) xv[dd] = (valid && dd < D) ? c.X[i + (size_t)n * dd] : 0.0;
+  for (int u = 0; u < 4; ++u) thv[u] = c.theta[min((int)threadIdx.x + 256 * u, nth - 1)];
+  double chi_l = c.chi[ic + (size_t)n * min(lp, M - 1)];
+  if (!(MD > 1 && lp < M)) chi_l = 0.0;
+  double Zi[KMAX];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) { Zi[k] = c.Z[ic + (size_t)n * min(k, K - 1)]; if (k >= K) Zi[k] = 0.0; }
+  double xv[8];                                      // covariates of the curve (adjustment folded into the sums below, see k_curve_z)
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) xv[dd] = (dd < D) ? c.X[ic + (size_t)n * dd] : 0.0;
+  Curve<BW, LPC> cv;
+  cv.load(c.rec + (size_t)ic * d.LREC, P, d.LG, lp);
+  double zn_pre = c.chi_norm[ic + (size_t)n * min(lp, M - 1)];       // (used only if its tag in Dyn matches)
+  ZProposal zp;
+  if (fuse_z) z_proposal_load(c, ic, zp);            // likewise
+  const double sigma2 = dh.sigma2, beta = dh.beta;
+  // ---- now the staged data: theta to LDS, chi to the curve's tile ----
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
+  if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
+  if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
+  if (valid) {
+    tU.zero_pads(TW * RT + 3, lp);
+    if (lp <= M) sChi[lp] = chi_l;
+  }
+  // (not __syncthreads(): its fence waits for every outstanding load -- the record included.  Only the LDS stores above are published.)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  CT();
   double rss = 0.0;
   double logz_mine = 0.0;
   if (valid) {
-    double Zi[KMAX];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) Zi[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
-    // fused Z update: the proposal prepared by this iteration's k_factor is requested now, used at the end
-    ZProposal zp;
-    const uint32_t it_next = dyn->iter_hyper + 1u;
+    // fused Z update: the proposal prepared by this iteration's k_factor (requested above) is used at the end
+    const uint32_t it_next = dh.iter_hyper + 1u;
     bool zpre = false;
     if (fuse_z) {
-      zpre = dyn->zprep_valid && dyn->zprep_iter == it_next && dyn->zprep_tt == dyn->tt_step &&
-             dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed;
-      if (zpre) z_proposal_load(c, i, zp);
+      zpre = (dh.zprep_valid != 0u) & (dh.zprep_iter == it_next) & (dh.zprep_tt == dh.tt_step) &
+             (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
     }
     // u_m = sum_k Z_k phi_km ;  c0 = sum_k Z_k nu_k + sum_m chi_m u_m
     // row r = (k, mt) of the parameters as this curve sees it: theta_r + sum_d x_d thetaX_{r,d}
+    // (no branch on k < K: the row index is clamped and Z_k = 0 there, so the LDS reads of a row are all in flight together)
+    const int lpc = min(lp, P - 1);
     auto zrow = [&](int mt) {
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < KT; ++k)
-        if (k < K) {
-          const int r = k * (M + 1) + mt;
-          double e = sTh[(size_t)r * P + lp];
+        {
+          const int r = min(k, K - 1) * (M + 1) + mt;
+          double e = sTh[r * P + lpc];
           if (D > 0) {
 #pragma unroll
             for (int dd = 0; dd < 8; ++dd)
-              if (dd < D) e += xv[dd] * sThX[((size_t)r * D + dd) * P + lp];
+              if (dd < D) e += xv[dd] * sThX[(r * D + dd) * P + lpc];
           }
           v += Zi[k] * e;
         }
       return v;
     };
-    double cf = act ? zrow(0) : 0.0;
+    double cf = zrow(0);
+    if (!act) cf = 0.0;
     if (MD > 1) {
       for (int m = 0; m < M; ++m) {
-        const double um = act ? zrow(m + 1) : 0.0;
+        double um = zrow(m + 1);
+        if (!act) um = 0.0;
         if (m < Mu) tU.row(m)[lp] = um;
         cf += sChi[m] * um;
       }
     }
     tX.row(0)[lp] = cf;
+    tX.row(2)[lp] = cv.s;                            // (first use of the record)
     __builtin_amdgcn_wave_barrier();
     CT();
     const double g0 = cv.matvec(tX.row(0), lp);
@@ -520,11 +553,11 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     }
     if (Mu > 0) {
       // the normals were drawn by spare workgroups of this iteration's k_factor (job_chi_normals); in place otherwise
-      const bool pre = dyn->znorm_valid && dyn->znorm_iter == dyn->iter_hyper && dyn->znorm_tt == dyn->tt_step &&
-                       dyn->zprep_chain == c.chain && dyn->zprep_seed == c.seed;
+      const bool pre = (dh.znorm_valid != 0u) & (dh.znorm_iter == dh.iter_hyper) & (dh.znorm_tt == dh.tt_step) &
+                       (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
       if (lp < M) {
-        if (pre) sZn[lp] = c.chi_norm[i + (size_t)n * lp];
-        else sZn[lp] = rnorm(make_key(c.seed, c.chain, dyn->iter_hyper, dyn->tt_step), UPD_CHI, (uint32_t)(i * M + lp));
+        if (pre) sZn[lp] = zn_pre;
+        else sZn[lp] = rnorm(make_key(c.seed, c.chain, dh.iter_hyper, dh.tt_step), UPD_CHI, (uint32_t)(i * M + lp));
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -534,7 +567,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     if (Mu > 0) {
       // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
       double dl[MT];
-      double* cslot = c.c_chi + (size_t)dyn->slot_hyper * n * M;
+      double* cslot = c.c_chi + (size_t)dh.slot_hyper * n * M;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         dl[m] = 0.0;
@@ -638,7 +671,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       for (int k = 0; k < KT; ++k)
         if (k < K && Zi[k] <= 0) acceptance = 1;                        // UpdateMixedMembership.h:170-174
       const bool took_new = zp.log_uu < acceptance;
-      double* zslot = c.c_Z + (size_t)(dyn->slot_hyper + 1u) * n * K;
+      double* zslot = c.c_Z + (size_t)(dh.slot_hyper + 1u) * n * K;
 #pragma unroll
       for (int k = 0; k < KT; ++k)
         if (k < K && lp == k) {
@@ -652,6 +685,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   CT();
 #ifdef BFMMM_TIMELINE
   if (blockIdx.x == 8 && threadIdx.x == 0) for (int x = 0; x + 1 < ci_; ++x) c.dyn->stamps[32 + x] = ct_[x + 1] - ct_[x];
+  if (blockIdx.x == 10 && threadIdx.x == 0) { const int sl_[4] = {27, 29, 31, 37}; for (int x = 0; x + 1 < ci_ && x < 4; ++x) c.dyn->stamps[sl_[x]] = ct_[x + 1] - ct_[x]; }
 #endif
   if (lp == 0) sRss[grp] = rss;
   if (fuse_z && lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
@@ -670,6 +704,60 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
 }
 
 // ---- host launchers -------------------------------------------------------------------------
+// The (K, M) pairs k_curve_chi is also built for exactly, for the cubic-spline functional model (BW 3; with covariates only at
+// P <= 32) and the multivariate model (BW 0).  Any other shape runs the general instances.
+#define BFMMM_CHI_EXACT(X)                                                                                     \
+  X(2, 1) X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8)                                               \
+  X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(3, 5) X(3, 6) X(3, 7) X(3, 8)                                               \
+  X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(4, 5) X(4, 6) X(4, 7) X(4, 8)
+template <int BW, int L, bool CV>
+constexpr bool chi_exact_built() { return (BW == 3 && (!CV || L == 32)) || (BW == 0 && !CV); }
+
+template <int BW, int L, bool CV>
+static bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode) {
+  if constexpr (chi_exact_built<BW, L, CV>()) {
+#define X(k, m)                                                                                                \
+    if (c.d.K == k && c.d.M == m) {                                                                            \
+      hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true, k, m>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, mode);   \
+      return true;                                                                                             \
+    }
+    BFMMM_CHI_EXACT(X)
+#undef X
+  }
+  return false;
+}
+
+// k_curve_z with K exact (2, 3, 4), same models; covariates run the general instances
+template <int BW, int L, bool CV>
+static bool launch_z_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int do_update) {
+  if constexpr (chi_exact_built<BW, L, false>() && !CV) {
+    const bool lean = (do_update & 2) != 0;
+#define X(k)                                                                                                   \
+    if (c.d.K == k) {                                                                                          \
+      if (lean) hipLaunchKernelGGL((k_curve_z<BW, L, false, k, true, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
+      else hipLaunchKernelGGL((k_curve_z<BW, L, false, k, false, true>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);          \
+      return true;                                                                                             \
+    }
+    X(2) X(3) X(4)
+#undef X
+  }
+  return false;
+}
+
+template <int BW, int L, bool CV>
+static void prepare_chi_exact() {
+  if constexpr (chi_exact_built<BW, L, false>() && !CV) {
+#define X(k) set_max_lds((const void*)k_curve_z<BW, L, false, k, true, true>); set_max_lds((const void*)k_curve_z<BW, L, false, k, false, true>);
+    X(2) X(3) X(4)
+#undef X
+  }
+  if constexpr (chi_exact_built<BW, L, CV>()) {
+#define X(k, m) set_max_lds((const void*)k_curve_chi<BW, L, CV, true, k, m>);
+    BFMMM_CHI_EXACT(X)
+#undef X
+  }
+}
+
 template <int BW>
 static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t st) {
   const int LPC = (c.d.P <= 32) ? 32 : 64;
@@ -689,9 +777,11 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const bool cov = D > 0;
 #define LAUNCH_CURVE(L, CV)                                                                                   \
   do {                                                                                                        \
-    if (which == 0) { if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
+    if (which == 0) { if (launch_z_exact<BW, L, CV>(c, nblk, lds, st, do_update)) { }                          \
+                      else if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1); }  \
+    else if (launch_chi_exact<BW, L, CV>(c, nblk, lds, st, do_update)) { }                                     \
     else if (K <= 4 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
     else hipLaunchKernelGGL((k_curve_chi<BW, L, CV, false>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
@@ -719,6 +809,7 @@ static void prepare_bw() {
   set_max_lds((const void*)k_curve_chi<BW, 32, true, false>);
   set_max_lds((const void*)k_curve_chi<BW, 64, true, true>);
   set_max_lds((const void*)k_curve_chi<BW, 64, true, false>);
+  prepare_chi_exact<BW, 32, false>(); prepare_chi_exact<BW, 64, false>(); prepare_chi_exact<BW, 32, true>(); prepare_chi_exact<BW, 64, true>();
 }
 
 void prepare_curve_kernels() {

@@ -64,6 +64,34 @@ struct Dyn {
   unsigned long long stamps[64];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
 };
 
+// The scalar head of Dyn, fetched in ONE batch of loads.  A kernel that reads its fields one by one through the pointer -- worse,
+// inside a short-circuit "a && b == c && ..." -- makes a separate trip to L2 for each (0.3 - 0.4 us apiece: the tag test of the
+// prepared Z proposal alone was five trips, 2 us of k_curve_chi's 16).  Same layout as Dyn up to alpha3 (checked below).
+struct DynHead {
+  uint32_t iter, slot, tt_step, status, iter_hyper, slot_hyper;
+  int32_t pend_dir;
+  uint32_t ll_pending, ll_slot, ll_use_part;
+  uint32_t zprep_valid, zprep_iter, zprep_tt, zprep_chain;
+  uint32_t znorm_valid, znorm_iter, znorm_tt;
+  uint32_t piprep_valid, piprep_iter;
+  uint32_t slot_base;
+  unsigned long long zprep_seed;
+  double beta, sigma2, alpha3;
+};
+static_assert(sizeof(DynHead) == 112, "DynHead is seven 16-byte loads");
+static_assert(offsetof(Dyn, zprep_seed) == offsetof(DynHead, zprep_seed) && offsetof(Dyn, alpha3) == offsetof(DynHead, alpha3) &&
+              offsetof(Dyn, slot_base) == offsetof(DynHead, slot_base), "DynHead mirrors the head of Dyn");
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ DynHead dyn_head(const Dyn* dyn) {
+  union U { DynHead h; int4 q[7]; __device__ U() {} } u;
+  const int4* p = reinterpret_cast<const int4*>(dyn);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) u.q[j] = p[j];
+  return u.h;
+}
+#endif
+
 struct Dims {
   int n, K, P, M, D;
   int BW;               // band half-width of G_i (= spline degree; 0 for the multivariate model)

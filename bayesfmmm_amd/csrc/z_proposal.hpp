@@ -172,10 +172,12 @@ __device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp) {
   const int n = c.d.n, K = c.d.K;
   const double* o = c.zprep + i;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    zp.Znew[k] = (k < K) ? o[(size_t)n * k] : 0.0;
-    zp.lo[k] = (k < K) ? o[(size_t)n * (K + k)] : 0.0;
-    zp.ln[k] = (k < K) ? o[(size_t)n * (2 * K + k)] : 0.0;
+  for (int k = 0; k < KMAX; ++k) {          // (clamped address + mask, not a load behind a branch)
+    const int kc = min(k, K - 1);
+    const double a = o[(size_t)n * kc], b = o[(size_t)n * (K + kc)], e = o[(size_t)n * (2 * K + kc)];
+    zp.Znew[k] = (k < K) ? a : 0.0;
+    zp.lo[k] = (k < K) ? b : 0.0;
+    zp.ln[k] = (k < K) ? e : 0.0;
   }
   const double* s = o + (size_t)n * 3 * K;
   zp.pr_old = s[0]; zp.pr_new = s[n]; zp.lpn = s[(size_t)2 * n]; zp.lpo = s[(size_t)3 * n]; zp.log_uu = s[(size_t)4 * n];

@@ -77,9 +77,12 @@ def run(a):
             print(f"  k_sweep_chain: chain loop {(st[25] - st[24]) / 100:.2f} us, pick spins of the chain wave {int(st[26])}; loop starts {(st[24] - st[8]) / 100:.2f} us into the kernel")
             rel = [(st[i] - st[8]) / 100 for i in (28, 24, 25, 30)] + [(st[9] - st[8]) / 100]
             print("  k_sweep_chain stamps (us from kernel start): loads back, LDS set up %.2f | loop start %.2f | chain done %.2f | all rows done %.2f | end %.2f" % tuple(rel))
+        print("  k_curve_chi workgroup 10 (another XCD) first four phase clocks:", [int(st[q]) for q in (27, 29, 31, 37)])
         print("  k_curve_chi workgroup 8 phase clocks (load+stage | u_m, c0 | G u_m, dots | Gauss-Seidel, rss | fused Z):", [int(x) for x in st[32:37]])
         try:
             zt = smp.get_state("ztrace").reshape(-1, 3)[:520]
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                np.save(os.path.join(ROOT, "gpurun_out", "chi_ztrace.npy"), zt)
             t00 = zt[8:, 0].min()
             dur = (zt[8:, 2] - zt[8:, 0]) / 100.0
             end = (zt[8:, 2] - t00) / 100.0
