@@ -102,12 +102,16 @@ __global__ __launch_bounds__(256) void k_cov_prep(Ctx c0, int n_wblocks) {
 constexpr int NPG_MAX = DMAX_COV * (DMAX_COV + 1) / 2;
 constexpr int W2_CH = 128;       // curves per chunk (NB2 = ceil(n / W2_CH))
 
+// DX = D, a compile-time constant: with a run-time D the "v < D" guards of the pair loops are uniform branches around every
+// group of FMAs (44 -> 23 us at config 3, D 5).
+template <int DX>
 __global__ __launch_bounds__(256) void k_cov_w2(Ctx c0) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const Dims& d = c.d;
   const int g = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
-  const int D = d.D, NPG = c.NPG, LG = d.LG;
+  constexpr int D = DX, NPG = DX * (DX + 1) / 2;
+  const int LG = d.LG;
   if (!dir2_updated(c, dir2_of(d, g * D))) return;
   const int i0 = cb * W2_CH, nc = min(d.n - i0, W2_CH);
   double* sW = sm;                       // W2_CH x D weights of the chunk (zero rows beyond its curves)
@@ -126,9 +130,9 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c0) {
   for (int ep = 0; ep < LG; ep += 256) {
     const int e = ep + e0;
     const bool on = e < LG;
-    double acc[NPG_MAX];
+    double acc[NPG];
 #pragma unroll
-    for (int q = 0; q < NPG_MAX; ++q) acc[q] = 0.0;
+    for (int q = 0; q < NPG; ++q) acc[q] = 0.0;
     for (int cb0 = 0; cb0 < per; cb0 += 16) {
       double r[16];
 #pragma unroll
@@ -141,33 +145,29 @@ __global__ __launch_bounds__(256) void k_cov_w2(Ctx c0) {
         // D broadcast LDS reads per curve; the D(D+1)/2 pair weights are formed in registers (one LDS read per FMA
         // bound the first version of this kernel)
         const double* wr = sW + (cl0 + cb0 + t) * D;
-        double w[DMAX_COV];
+        double w[D];
 #pragma unroll
-        for (int v = 0; v < DMAX_COV; ++v) w[v] = (v < D) ? wr[v] : 0.0;
+        for (int v = 0; v < D; ++v) w[v] = wr[v];
 #pragma unroll
-        for (int v = 0; v < DMAX_COV; ++v)
-          if (v < D) {
-            const double wv = w[v] * r[t];
+        for (int v = 0; v < D; ++v) {
+          const double wv = w[v] * r[t];
 #pragma unroll
-            for (int u = 0; u <= v; ++u) acc[v * (v + 1) / 2 + u] += w[u] * wv;
-          }
+          for (int u = 0; u <= v; ++u) acc[v * (v + 1) / 2 + u] += w[u] * wv;
+        }
       }
     }
     if (NH == 2) {
       __syncthreads();
       if (half == 1)
 #pragma unroll
-        for (int q = 0; q < NPG_MAX; ++q)
-          if (q < NPG) sRed[q * 128 + e0] = acc[q];
+        for (int q = 0; q < NPG; ++q) sRed[q * 128 + e0] = acc[q];
       __syncthreads();
       if (half == 0 && on)
 #pragma unroll
-        for (int q = 0; q < NPG_MAX; ++q)
-          if (q < NPG) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q] + sRed[q * 128 + e0];
+        for (int q = 0; q < NPG; ++q) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q] + sRed[q * 128 + e0];
     } else if (on) {
 #pragma unroll
-      for (int q = 0; q < NPG_MAX; ++q)
-        if (q < NPG) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q];
+      for (int q = 0; q < NPG; ++q) c.w2_part[((size_t)(g * NPG + q) * c.NB2 + cb) * LG + e] = acc[q];
     }
   }
 }
@@ -285,9 +285,12 @@ constexpr int GT = 1024;       // threads of k_cov_group
 // done by the first 256 threads.
 typedef double dbl2 __attribute__((ext_vector_type(2)));     // one 16-byte memory instruction
 
-template <int BW, int LPC>
+// DX > 0: D == DX exactly, a compile-time constant (built for the cubic-spline model, BW 3): 14.2 -> 13.4 us per launch at config 3
+template <int BW, int LPC, int DX = 0>
 __global__ __launch_bounds__(GT) void k_cov_group(Ctx c0, int g_prev, int g_next, int par_prev) {
-  const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
+  Ctx cx = chain_view(c0);           // chain blockIdx.z of the batch
+  if constexpr (DX > 0) { cx.d.D = DX; cx.NPG = DX * (DX + 1) / 2; }
+  const Ctx& c = cx;
   constexpr int GPB = GT / LPC;           // lane groups
   constexpr int CPB = GPB * COV_CPG;      // curves per workgroup
   constexpr int LR = 256 / LPC;           // lanes per row of C in the draw (row = tid / LR, tid < 256)
@@ -751,9 +754,21 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
 }
 
 // ---- host launchers -------------------------------------------------------------------------
+#define COV_EACH_D(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+static_assert(DMAX_COV == 8, "COV_EACH_D lists 1 .. DMAX_COV");
 template <int BW>
 static void launch_group_bw(const Ctx& c, int g_prev, int g_next, int par_prev, hipStream_t st) {
   const size_t lds = ((size_t)c.NPG * c.d.LG + 2 + (c.d.P <= 32 ? (size_t)c.d.D * c.d.P * c.d.P + 2 : 0)) * sizeof(double);
+  if constexpr (BW == 3) {           // instances with D exact
+#define X(dx)                                                                                                                    \
+    if (c.d.D == dx) {                                                                                                           \
+      if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32, dx>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);   \
+      else hipLaunchKernelGGL((k_cov_group<BW, 64, dx>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);  \
+      return;                                                                                                                    \
+    }
+    COV_EACH_D(X)
+#undef X
+  }
   if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
   else hipLaunchKernelGGL((k_cov_group<BW, 64>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);
 }
@@ -789,7 +804,11 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
   }
   if (do_eta || do_xi) {
     const size_t lds_w2 = ((size_t)W2_CH * d.D + (size_t)c.NPG * 128) * sizeof(double);
-    hipLaunchKernelGGL(k_cov_w2, dim3(c.A2 / d.D, c.NB2, c.nch), dim3(256), lds_w2, st, c);
+    switch (d.D) {
+#define X(dx) case dx: hipLaunchKernelGGL(k_cov_w2<dx>, dim3(c.A2 / d.D, c.NB2, c.nch), dim3(256), lds_w2, st, c); break;
+      COV_EACH_D(X)
+#undef X
+    }
     const int PP = (d.P <= 32) ? 32 : 64;
     const size_t lds = (2 * (size_t)PP * PP + PP + d.LG + 4 * PP + 2) * sizeof(double);      // + scratch of the pseudo-inverse route
     if (PP == 32) hipLaunchKernelGGL(k_cov_factor<32>, dim3(c.NPAIR, 1, c.nch), dim3(256), lds, st, c);
@@ -811,10 +830,17 @@ template <int BW>
 static void prepare_group_bw() {
   set_max_lds((const void*)k_cov_group<BW, 32>);
   set_max_lds((const void*)k_cov_group<BW, 64>);
+  if constexpr (BW == 3) {
+#define X(dx) set_max_lds((const void*)k_cov_group<BW, 32, dx>); set_max_lds((const void*)k_cov_group<BW, 64, dx>);
+    COV_EACH_D(X)
+#undef X
+  }
 }
 
 void prepare_cov_kernels() {
-  set_max_lds((const void*)k_cov_w2);
+#define X(dx) set_max_lds((const void*)k_cov_w2<dx>);
+  COV_EACH_D(X)
+#undef X
   set_max_lds((const void*)k_cov_hyper);
   set_max_lds((const void*)k_cov_factor<32>);
   set_max_lds((const void*)k_cov_factor<64>);
