@@ -727,15 +727,17 @@ static bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st,
   return false;
 }
 
-// k_curve_z with K exact (2, 3, 4), same models; covariates run the general instances
+// k_curve_z with K exact (2, 3, 4), same models
 template <int BW, int L, bool CV>
 static bool launch_z_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int do_update) {
-  if constexpr (chi_exact_built<BW, L, false>() && !CV) {
-    const bool lean = (do_update & 2) != 0;
+  if constexpr (chi_exact_built<BW, L, CV>()) {
+    const bool lean = (do_update & 2) != 0 && !CV;       // (a lean launch is one without covariates: see LAUNCH_CURVE)
 #define X(k)                                                                                                   \
     if (c.d.K == k) {                                                                                          \
-      if (lean) hipLaunchKernelGGL((k_curve_z<BW, L, false, k, true, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
-      else hipLaunchKernelGGL((k_curve_z<BW, L, false, k, false, true>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);          \
+      if constexpr (!CV) {                                                                                     \
+        if (lean) { hipLaunchKernelGGL((k_curve_z<BW, L, false, k, true, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1); return true; }  \
+      }                                                                                                        \
+      hipLaunchKernelGGL((k_curve_z<BW, L, CV, k, false, true>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);          \
       return true;                                                                                             \
     }
     X(2) X(3) X(4)
@@ -746,8 +748,8 @@ static bool launch_z_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, i
 
 template <int BW, int L, bool CV>
 static void prepare_chi_exact() {
-  if constexpr (chi_exact_built<BW, L, false>() && !CV) {
-#define X(k) set_max_lds((const void*)k_curve_z<BW, L, false, k, true, true>); set_max_lds((const void*)k_curve_z<BW, L, false, k, false, true>);
+  if constexpr (chi_exact_built<BW, L, CV>()) {
+#define X(k) set_max_lds((const void*)k_curve_z<BW, L, CV, k, false, true>); if constexpr (!CV) set_max_lds((const void*)k_curve_z<BW, L, false, k, true, true>);
     X(2) X(3) X(4)
 #undef X
   }
