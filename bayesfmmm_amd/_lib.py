@@ -55,6 +55,7 @@ SYMBOLS = {
     "bfmmm_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int64, c_int64_p]),
     "bfmmm_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "bfmmm_get_timing": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), c_int64_p]),
+    "bfmmm_set_exact_instances": (None, [C.c_int]),
     "bfmmm_last_error": (C.c_char_p, []),
 }
 

@@ -1134,6 +1134,9 @@ extern "C" int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, i
   return fail("bfmmm_debug_get: unknown name '" + s + "'");
 }
 
+namespace bfmmm { int g_exact_instances = 1; }
+extern "C" void bfmmm_set_exact_instances(int enable) { bfmmm::g_exact_instances = enable ? 1 : 0; }
+
 extern "C" int bfmmm_set_profile(bfmmm_handle* h, int enable) {
   if (!h) return fail("bfmmm_set_profile: null handle");
   h->profile = enable ? 1 : 0;

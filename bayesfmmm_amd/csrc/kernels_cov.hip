@@ -761,7 +761,7 @@ static void launch_group_bw(const Ctx& c, int g_prev, int g_next, int par_prev, 
   const size_t lds = ((size_t)c.NPG * c.d.LG + 2 + (c.d.P <= 32 ? (size_t)c.d.D * c.d.P * c.d.P + 2 : 0)) * sizeof(double);
   if constexpr (BW == 3) {           // instances with D exact
 #define X(dx)                                                                                                                    \
-    if (c.d.D == dx) {                                                                                                           \
+    if (g_exact_instances && c.d.D == dx) {                                                                                                           \
       if (c.d.P <= 32) hipLaunchKernelGGL((k_cov_group<BW, 32, dx>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);   \
       else hipLaunchKernelGGL((k_cov_group<BW, 64, dx>), dim3(c.NBS, 1, c.nch), dim3(GT), lds, st, c, g_prev, g_next, par_prev);  \
       return;                                                                                                                    \

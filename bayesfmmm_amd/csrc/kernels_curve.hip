@@ -715,6 +715,7 @@ constexpr bool chi_exact_built() { return (BW == 3 && (!CV || L == 32)) || (BW =
 
 template <int BW, int L, bool CV>
 static bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode) {
+  if (!g_exact_instances) return false;
   if constexpr (chi_exact_built<BW, L, CV>()) {
 #define X(k, m)                                                                                                \
     if (c.d.K == k && c.d.M == m) {                                                                            \
@@ -730,6 +731,7 @@ static bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st,
 // k_curve_z with K exact (2, 3, 4), same models
 template <int BW, int L, bool CV>
 static bool launch_z_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int do_update) {
+  if (!g_exact_instances) return false;
   if constexpr (chi_exact_built<BW, L, CV>()) {
     const bool lean = (do_update & 2) != 0 && !CV;       // (a lean launch is one without covariates: see LAUNCH_CURVE)
 #define X(k)                                                                                                   \

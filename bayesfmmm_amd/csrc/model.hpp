@@ -221,6 +221,8 @@ __host__ __device__ inline Ctx chain_ctx(const Ctx& c0, unsigned q) {
 __device__ inline Ctx chain_view(const Ctx& c0) { return chain_ctx(c0, blockIdx.z); }
 #endif
 
+extern int g_exact_instances;      // bfmmm_set_exact_instances (bfmmm_capi.hip): 0 = the launchers use only the general instances
+
 __host__ __device__ inline int tri_index(int n, int a, int b) {  // a <= b < n  -> index in packed upper triangle
   return a * n - (a * (a - 1)) / 2 + (b - a);
 }

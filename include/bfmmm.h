@@ -184,6 +184,11 @@ int bfmmm_debug_get(bfmmm_handle* h, const char* name, double* out, int64_t capa
 int bfmmm_set_profile(bfmmm_handle* h, int enable);
 int bfmmm_get_timing(bfmmm_handle* h, const char* name, double* ms, int64_t* launches);
 
+/* The per-curve and covariate kernels are also built in exact-shape instances (K, M, D compile-time: DESIGN.md section 5) that
+ * the launchers pick when the model's shape is on the list.  0 makes every later launch (of samplers created afterwards) use the
+ * general instances instead -- the parity tests run both and compare.  Process-wide; default 1. */
+void bfmmm_set_exact_instances(int enable);
+
 const char* bfmmm_last_error(void);
 
 #ifdef __cplusplus
