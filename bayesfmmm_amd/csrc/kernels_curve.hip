@@ -440,12 +440,13 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   const int RT = max(M, K);                          // rows of the U / GU tiles (the fused Z update needs K of them)
   const int nres = max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2);
   const int TW = d.mv ? 1 : 2;                       // multivariate model: G u = u, the GU tile is the U tile
-  const int per_group = (TW * RT + 3) * T::STR + 2 * M + 2 + nres;
+  const int per_group = (TW * RT + 3) * T::STR + 4 * M + 2 + nres;
   double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + (TW - 1) * RT * T::STR}, tX{gbase + TW * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
   double* sChi = gbase + (TW * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
   double* sZn = sChi + M + 1;
-  double* sRes = sZn + M + 1;
+  double* sWq = sZn + M + 1;                         // W_m, then sqrt(W_m): the conditional variances of the chi update
+  double* sRes = sWq + 2 * M;
   const int i = blk * GPB + grp;
   const bool valid = i < n;
   const int ic = min(i, n - 1);
@@ -565,6 +566,15 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)
     rss = cv.yy - sRes[nA + Mu] - sRes[nA + Mu + 1];
     if (Mu > 0) {
+      // W_m = 1 / (1 + A_mm beta / sigma^2) and its square root do not depend on the recursion: lane m forms them for its m, so
+      // the wave pays ONE division and ONE square root sequence (~60 instructions) instead of M of each inside every lane's copy
+      // of the recursion (the same expressions on the same operands: the values are bit-identical)
+      if (lp < M) {
+        const double W0l = sRes[tri_index(M, lp, lp)];
+        const double Wl = 1.0 / (1.0 + ((W0l * beta) / sigma2));
+        sWq[lp] = Wl; sWq[M + lp] = sqrt(Wl);
+      }
+      __builtin_amdgcn_wave_barrier();
       // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
       double dl[MT];
       double* cslot = c.c_chi + (size_t)dh.slot_hyper * n * M;
@@ -579,8 +589,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
           const double W0 = sRes[tri_index(M, m, m)];
           const double chi_old = sChi[m];
           const double w = ((r1 + chi_old * W0) * beta) / sigma2;
-          const double W = 1.0 / (1.0 + ((W0 * beta) / sigma2));
-          const double chi_new = W * w + sqrt(W) * sZn[m];
+          const double chi_new = sWq[m] * w + sWq[M + m] * sZn[m];
           dl[m] = chi_new - chi_old;
           if (lp == m) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; sChi[m] = chi_new; }
         }
@@ -775,7 +784,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   size_t lds;
   const int TW = c.d.mv ? 1 : 2;
   if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 48 + tileE);
-  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 2 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
+  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 4 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
   if (which == 1 || (do_update & 2)) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch (k_curve_chi, lean k_curve_z)
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;
