@@ -722,19 +722,48 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
 template <int BW, int L, bool CV>
 constexpr bool chi_exact_built() { return (BW == 3 && (!CV || L == 32)) || (BW == 0 && !CV); }
 
+// The 120 exact instances of k_curve_chi are compiled in a translation unit of their own (kernels_curve_exact.hip includes this
+// file with BFMMM_CURVE_EXACT_TU defined and gets the kernels plus the two functions below; this file then holds everything else),
+// so that the two halves build side by side.  The diagnostic timeline build keeps one unit: its trace arrays are device globals.
 template <int BW, int L, bool CV>
-static bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode) {
-  if (!g_exact_instances) return false;
-  if constexpr (chi_exact_built<BW, L, CV>()) {
+bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode);      // (built combinations only: chi_exact_built)
+template <int BW, int L, bool CV>
+void prepare_chi_exact_kernels();
+
+#if defined(BFMMM_CURVE_EXACT_TU) || defined(BFMMM_TIMELINE)
+template <int BW, int L, bool CV>
+bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode) {
+  static_assert(chi_exact_built<BW, L, CV>(), "not on the list");
 #define X(k, m)                                                                                                \
-    if (c.d.K == k && c.d.M == m) {                                                                            \
-      hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true, k, m>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, mode);   \
-      return true;                                                                                             \
-    }
-    BFMMM_CHI_EXACT(X)
-#undef X
+  if (c.d.K == k && c.d.M == m) {                                                                              \
+    hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true, k, m>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, mode);     \
+    return true;                                                                                               \
   }
+  BFMMM_CHI_EXACT(X)
+#undef X
   return false;
+}
+template <int BW, int L, bool CV>
+void prepare_chi_exact_kernels() {
+#define X(k, m) set_max_lds((const void*)k_curve_chi<BW, L, CV, true, k, m>);
+  BFMMM_CHI_EXACT(X)
+#undef X
+}
+#define BFMMM_CHI_EXACT_COMBOS(Y) Y(3, 32, false) Y(3, 64, false) Y(3, 32, true) Y(0, 32, false) Y(0, 64, false)
+#define Y(bw, l, cv)                                                                                           \
+  static_assert(chi_exact_built<bw, l, cv>(), "BFMMM_CHI_EXACT_COMBOS lists what chi_exact_built admits");      \
+  template bool launch_chi_exact<bw, l, cv>(const Ctx&, int, size_t, hipStream_t, int);                         \
+  template void prepare_chi_exact_kernels<bw, l, cv>();
+BFMMM_CHI_EXACT_COMBOS(Y)
+#undef Y
+#endif
+
+#ifndef BFMMM_CURVE_EXACT_TU
+template <int BW, int L, bool CV>
+static bool try_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode) {
+  if (!g_exact_instances) return false;
+  if constexpr (chi_exact_built<BW, L, CV>()) return launch_chi_exact<BW, L, CV>(c, nblk, lds, st, mode);
+  else return false;
 }
 
 // k_curve_z with K exact (2, 3, 4), same models
@@ -764,11 +793,7 @@ static void prepare_chi_exact() {
     X(2) X(3) X(4)
 #undef X
   }
-  if constexpr (chi_exact_built<BW, L, CV>()) {
-#define X(k, m) set_max_lds((const void*)k_curve_chi<BW, L, CV, true, k, m>);
-    BFMMM_CHI_EXACT(X)
-#undef X
-  }
+  if constexpr (chi_exact_built<BW, L, CV>()) prepare_chi_exact_kernels<BW, L, CV>();
 }
 
 template <int BW>
@@ -794,7 +819,7 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
                       else if (K <= 4 && (do_update & 2) && !CV && BW <= 5) hipLaunchKernelGGL((k_curve_z<BW, L, false, 4, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else if (K <= 4) hipLaunchKernelGGL((k_curve_z<BW, L, CV, 4>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1);  \
                       else hipLaunchKernelGGL((k_curve_z<BW, L, CV, KMAX>), dim3(nblk, 1, c.nch), dim3(256), lds, st, c, do_update & 1); }  \
-    else if (launch_chi_exact<BW, L, CV>(c, nblk, lds, st, do_update)) { }                                     \
+    else if (try_chi_exact<BW, L, CV>(c, nblk, lds, st, do_update)) { }                                        \
     else if (K <= 4 && M <= 8) hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
     else hipLaunchKernelGGL((k_curve_chi<BW, L, CV, false>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, do_update);      \
   } while (0)
@@ -849,5 +874,6 @@ int curve_blocks(int n, int P) {
   const int GPB = 256 / LPC;
   return (n + GPB - 1) / GPB;
 }
+#endif  // !BFMMM_CURVE_EXACT_TU
 
 }  // namespace bfmmm
