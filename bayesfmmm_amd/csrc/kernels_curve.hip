@@ -221,8 +221,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
         if (D > 0 && k < K && act) {
           const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
 #pragma unroll
-          for (int dd = 0; dd < 8; ++dd)
-            if (dd < D) ucov[k] += xv[dd] * xb[dd * P];
+          for (int dd = 0; dd < 8; ++dd) ucov[k] += xv[dd] * xb[min(dd, D - 1) * P];      // (no branch: x_d = 0 beyond D, the address is clamped)
         }
       }
       if (MD > 1 && act)
@@ -238,8 +237,10 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
                 const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
                 double e0 = 0.0, e1 = 0.0;
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd)
-                  if (dd < D) { e0 += xv[dd] * xb[(r0 * D + dd) * P]; e1 += xv[dd] * xb[(r1 * D + dd) * P]; }
+                for (int dd = 0; dd < 8; ++dd) {
+                  const int dc = min(dd, D - 1);
+                  e0 += xv[dd] * xb[(r0 * D + dc) * P]; e1 += xv[dd] * xb[(r1 * D + dc) * P];
+                }
                 ucov[k] += c0 * e0 + c1 * e1;
               }
             }
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
           if (D > 0) {
 #pragma unroll
             for (int dd = 0; dd < 8; ++dd)
-              if (dd < D) e += xv[dd] * sThX[(r * D + dd) * P + lpc];
+              e += xv[dd] * sThX[(r * D + min(dd, D - 1)) * P + lpc];      // (no branch: x_d = 0 beyond D)
           }
           v += Zi[k] * e;
         }
