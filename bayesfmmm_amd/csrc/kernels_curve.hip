@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   ZProposal zp;
   if (valid && do_update) {
     const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == it_cur) & (dh.zprep_tt == dh.tt_step) &
-                     (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed) & (D == 0);
+                     (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
     if (pre) z_proposal_load(c, i, zp);
     else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
     else z_proposal<LPC>(c, make_key(c.seed, c.chain, dh.iter, dh.tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       // ---- updateZ_PM of iteration it_next for this curve (UpdateMixedMembership.h:131-185), as in k_curve_z:
       //      theta (sTh), the record (cv), s (tX row 2) and the new chi (sChi) are on chip; the U / GU tiles are free ----
       // (the data-independent half of the update was prepared by this iteration's k_factor, job_z_prepare: it runs
-      //  under exactly the conditions the host fuses under -- U_Z, no covariates, untempered)
+      //  whenever Z is updated -- a superset of the conditions the host fuses under: U_Z, no covariates, untempered)
       __builtin_amdgcn_wave_barrier();
       double uk[KMAX];
 #pragma unroll

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   if (bx >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
     const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int zcw = zprep_curves_per_wg(d.K);
-    const int nzp = ((c.mask & U_Z) && d.D == 0) ? (d.n + zcw - 1) / zcw : 0;
+    const int nzp = (c.mask & U_Z) ? (d.n + zcw - 1) / zcw : 0;
 #ifdef BFMMM_TIMELINE
     const int sb_ = bx - A;       // one workgroup of each kind of spare job: start / end stamps 56 .. 63
     const int kind_ = sb_ < ndraw ? 0 : sb_ < ndraw + nzp ? 1 : (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) ? 2 : 3;
@@ -1699,7 +1699,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const size_t lds = ((diag ? 0 : 2 * (size_t)PP * PP) + (size_t)c.d.A * PS + (size_t)c.d.A * c.d.P + PP + (size_t)c.d.P * W + 16 + 4 * PP + 2) * sizeof(double);
   const int n_draw = c.d.K * c.d.P * c.d.M + c.d.K * c.d.M + c.d.K + 4 * c.d.K + 1 + 8 * c.d.K;   // + sigma^2's gamma variate, A terms
   const int zcw = zprep_curves_per_wg(c.d.K);       // curves per workgroup of job_z_prepare (z_proposal.hpp)
-  const int n_zprep = ((c.mask & U_Z) && c.d.D == 0) ? (c.d.n + zcw - 1) / zcw : 0;
+  const int n_zprep = (c.mask & U_Z) ? (c.d.n + zcw - 1) / zcw : 0;      // (covariate-adjusted models too: the proposal does not see the data)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
   const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // the last workgroup: next iteration's pi / alpha_3 tables
   const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;
