@@ -403,12 +403,15 @@ def main():
     b_alg = algorithmic_bytes_per_iteration(n, P, M, K)
     b_band = algorithmic_bytes_per_iteration(n, P, M, K, dense=False)
     # SURVEY 8(d) data-touching blocks each kernel family implements (k_curve_chi carries chi + the next iteration's Z)
-    blocks = {"curve_z": 1, "pair_gram": 2, "pg_reduce": 0, "sweep": 1, "curve_chi": 2, "factor": 0, "loglik": 0}
+    # (the sigma^2 block is not charged to k_sweep_chain: that kernel is ONE workgroup working from the 0.45 MB of sufficient
+    #  statistics -- it never reads a record, its residual sums come from k_curve_chi's pass -- and a fraction of the HBM roofline
+    #  on bytes it does not move says nothing; it stays in per_kernel_ms, where it is as long as k_pair_gram)
+    blocks = {"curve_z": 1, "pair_gram": 2, "pg_reduce": 0, "sweep": 0, "curve_chi": 2, "factor": 0, "loglik": 0}
     pm, pm_file = pmc_summary()
     roofline = None
     it_rate = value / world            # iterations/s of one chain
     if fams:
-        # dominant kernel = largest time PER ITERATION among the families that run every iteration
+        # dominant kernel = largest time PER ITERATION among the families that run every iteration AND stream the per-curve records
         every = [k for k in fams if blocks[k] > 0 and fams[k]["launches"] >= args.profile_steps]
         dom = max(every, key=lambda k: fams[k]["ms_per_iteration"])
         # Each bracketed launch carries the event pair and the gap of an eager launch (about 3 us); the timed region replays
