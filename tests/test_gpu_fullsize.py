@@ -128,3 +128,31 @@ def test_config3_covariate_adjusted_properties():
     ll = smp.get_chain("loglik")[t]
     assert abs(ll - ref) < 1e-8 * abs(ref)
     assert 0.005 < s2 < 0.02
+
+
+def test_beyond_the_cache_resident_size_properties():
+    """n_funct = 65536 (16 x BASELINE configs[1]; 80 MB of records): the geometry no benchmark reaches -- 342 k-slices of k_pair_gram
+    and their fixed-order reduction, 8192 curve workgroups per launch, 64-bit offsets of the chain slots -- checked through the same
+    size-independent properties as test_config2_properties: simplex rows, the log-likelihood recomputed from the state on the host,
+    sigma^2 staying at the generating value, bit-reproducibility (BFMMM.h:1502-1553, CalculateLikelihood.h:19-44)."""
+    import bayesfmmm_amd as bf
+    from bench import make_config2
+    S = bf.sampler
+    w = make_config2(n=65536, n_i=24)
+    T = 5
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=3, n_eigen=6, basis_degree=3, tot_mcmc_iters=T)
+    smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"])
+    smp.set_state(**w["state"])
+    smp.run(S.SWEEP_WARM, T, seed=7)
+    Z = smp.get_chain("Z"); nu = smp.get_chain("nu"); Phi = smp.get_chain("Phi"); chi = smp.get_chain("chi")
+    s2 = smp.get_chain("sigma_sq"); ll = smp.get_chain("loglik")
+    assert np.abs(Z.sum(axis=1) - 1).max() < 1e-12 and (Z > 0).all()
+    t = T - 1
+    ref, _ = host_loglik_functional(w, nu[:, :, t], Phi[..., t], chi[:, :, t], Z[:, :, t], s2[t])
+    assert abs(ll[t] - ref) < 1e-8 * abs(ref), (ll[t], ref)
+    assert 0.008 < s2[-1] < 0.0125
+    smp.set_state(**w["state"])
+    smp.run(S.SWEEP_WARM, T, seed=7)
+    np.testing.assert_array_equal(smp.get_chain("nu"), nu)
+    np.testing.assert_array_equal(smp.get_chain("sigma_sq"), s2)
+    smp.close()
