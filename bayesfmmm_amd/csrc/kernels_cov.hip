@@ -604,6 +604,7 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
   double* sPm = sE + K * D * P;     // P x P      penalty
   double* sSk = sPm + P * P;        // D x K*M
   double* sDX = sSk + D * K * M;    // (k*D + dd)*M + m    delta_xi
+  double* sGs = sDX + D * K * M;    // D x K*M             standard gamma variates of the delta_xi step
   if (tid == 0) dyn->pend_dir = -1;
   // ---- commit this iteration's eta / Xi draws (k_cov_group leaves them in thetaN) ----
   for (int e = tid; e < c.A2 * P; e += HT) {
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
       const int dd = e / (K * M), km = e - dd * K * M, k = km / M, m = km - k * M;
       const double* xk = c.thetaX + (size_t)((k * (M + 1) + m + 1) * D + dd) * P;
       const double* gx = c.gamma_xi + (size_t)k * P * D * M + (size_t)P * (dd + (size_t)D * m);
+      const double gsv = c.gstd2[n_tau + e];       // ((dd K + k) M + m: the order of the delta_xi variates)
       double acc = 0.0;
       for (int p0 = 0; p0 < P; p0 += 16) {
         double gq[16], xq[16];
@@ -663,12 +665,15 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
         for (int t = 0; t < 16; ++t) if (p0 + t < P) acc += gq[t] * (xq[t] * xq[t]);
       }
       sSk[e] = acc;
+      sGs[e] = gsv;
     }
     __syncthreads();
     if (tid < K * D) {
       const int dd = tid / K, k = tid - dd * K;
       const double* Sk = sSk + dd * K * M;
       double* DX = sDX + (k * D + dd) * M;
+      const double* gsd = sGs + (dd * K + k) * M;      // (the cell's standard gamma variates, staged with the sums above: read from
+                                                       //  global memory inside the recursion each was a trip of its own)
       for (int i = 0; i < M; ++i) {
         double param2 = 1.0;
         if (i == 0) {
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
             param2 += 0.5 * tt * Sk[k * M + m];
           }
         }
-        const double nv = c.gstd2[n_tau + (dd * K + k) * M + i] * (1.0 / param2);
+        const double nv = gsd[i] * (1.0 / param2);
         DX[i] = nv;
         c.delta_xi[k + (size_t)K * (i + (size_t)M * dd)] = nv;
       }
@@ -692,8 +697,10 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
   }
   // ---- A_xi (UpdateA.h:137-205), cells (j, i, d) ----
   if ((mask & U_A_XI) && xi_on) {
-    if (tid < K * 2 * D) {
-      const int dd = tid % D, ji = tid / D, i = ji % 2, j = ji / 2;
+    // cells (j, i, d): the i = 0 cells on wave 0 and the i = 1 cells on wave 1 -- the two kinds take different branches (different
+    // densities), and side by side in one wave each lane paid for both
+    if ((tid & 63) < K * D && tid < 128) {
+      const int i = tid >> 6, jd = tid & 63, dd = jd % D, j = jd / D;
       const bool first = (i == 0);
       const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
       double* cell = &c.A_xi[j + (size_t)K * (i + 2 * (size_t)dd)];
@@ -822,7 +829,7 @@ void launch_cov_block(const Ctx& c, hipStream_t st) {
     }
   }
   launch_group(c, g_prev, -1, par, st);      // the last group's draws, and the residual sums for the log-likelihood
-  const size_t lds_h = ((size_t)d.K * d.D * d.P + (size_t)d.P * d.P + 2 * (size_t)d.D * d.K * d.M) * sizeof(double);
+  const size_t lds_h = ((size_t)d.K * d.D * d.P + (size_t)d.P * d.P + 3 * (size_t)d.D * d.K * d.M) * sizeof(double);
   hipLaunchKernelGGL(k_cov_hyper, dim3(1, 1, c.nch), dim3(HT), lds_h, st, c);
 }
 
