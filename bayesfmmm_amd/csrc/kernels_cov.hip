@@ -628,8 +628,10 @@ __global__ __launch_bounds__(HT) void k_cov_hyper(Ctx c0) {
       sE[e] = c.thetaX[(size_t)((j * (M + 1)) * D + i) * P + p];
     }
     __syncthreads();
-    const int grp = tid >> 5, l = tid & 31;
-    for (int pr = grp; pr < K * D; pr += HT / 32) {
+    // (on the UPPER half of the workgroup: the lower waves go straight on to the sums of the delta_xi step, two round trips to
+    //  memory that do not depend on tau_eta)
+    const int grp = (tid >> 5) - HT / 64, l = tid & 31;
+    for (int pr = grp; pr >= 0 && pr < K * D; pr += HT / 64) {
       const double* ev = sE + pr * P;
       double acc = 0.0;
       for (int p = l; p < P; p += 32) {
