@@ -952,6 +952,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->fam_launches[FAM_TOTAL] = n_iters;
   for (int q = 0; q < h->nch; ++q) {
     const uint32_t status = h->status_host[q];
+    if (status & 4u) return fail("bfmmm_run: internal error (a hand-off inside the sweep kernel timed out)");
     if (status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
     if (status & 1u)
       return fail("bfmmm_run: a conditional precision matrix was not positive definite");

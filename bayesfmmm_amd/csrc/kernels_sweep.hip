@@ -1137,6 +1137,7 @@ template <int BW> struct SweepH { v2d h[BW + 1]; };
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long SW_SENT = 0x7FF8DEADBEEF5A5AULL;
 constexpr int SWC_SPIN_LIMIT = 1 << 15;
+constexpr unsigned SWC_STATUS_SPIN = 4u;      // status bit of a hand-off spin that ran out (bfmmm_capi.hip::run_impl reports it by name)
 constexpr int SWC_THREADS = 448;            // chain wave + A ceil(P / 2) <= 384 row threads (two rows each): two waves per SIMD, 256 VGPRs
 
 __device__ inline double lds_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
 #pragma nounroll
         while (is_sent(pk)) {
           if (++spins > SWC_SPIN_LIMIT) {       // (the extra memory operation would shift the counted waits: drain)
-            atomicOr(&dyn->status, 2u);
+            atomicOr(&dyn->status, SWC_STATUS_SPIN);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             break;
           }
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
 #else
           __builtin_amdgcn_s_sleep(1);
 #endif
-          if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, 2u); break; }
+          if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, SWC_STATUS_SPIN); break; }
         }
       }
       asm volatile("" ::: "memory");      // (compiler ordering only: an acquire fence would also wait for this wave's loads in flight)
@@ -1524,6 +1525,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
         }
         if (!__builtin_amdgcn_ballot_w64(mine && bad)) break;
       } while (++tries < SWC_SPIN_LIMIT);
+      if (tries >= SWC_SPIN_LIMIT) atomicOr(&dyn->status, SWC_STATUS_SPIN);
       if (mine) {
         if (s == rk) {
           // RSS(theta + delta e_a) - RSS(theta) = delta'(H_aa delta - 2 r_a), r_a taken before the step
@@ -1531,7 +1533,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
           int spins = 0;
 #pragma nounroll
           while (is_sent(rb0) || is_sent(rb1)) {
-            if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, 2u); break; }
+            if (++spins > SWC_SPIN_LIMIT) { atomicOr(&dyn->status, SWC_STATUS_SPIN); break; }
             rb0 = lds_ld(rbef + er); rb1 = lds_ld(rbef + rk * P + p1);
           }
           rss_acc += dv[BW] * (va - 2.0 * rb0);
@@ -1730,10 +1732,11 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
     return 0;
   }
   const int swc_ph = (d.P + 1) / 2, swc_lrk = swc_ph <= 4 ? 4 : swc_ph <= 8 ? 8 : 16;      // lanes per rank of the row threads
-  if (d.P <= 32 && d.A * swc_lrk <= SWC_THREADS - 64 && d.BW <= 5) {      // fast path: the chain in one wave
+  const size_t swc_lds = (5 * (((size_t)d.A * d.P + 1) & ~(size_t)1) + 32 + (size_t)d.A * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + 2 * ((size_t)d.A + 2) * sizeof(int4) +
+                         ((size_t)d.A * d.A + (size_t)d.A + 8) * sizeof(int) + 16;
+  if (d.P <= 32 && d.A * swc_lrk <= SWC_THREADS - 64 && d.BW <= 5 && swc_lds <= 160 * 1024) {      // fast path: the chain in one wave
     const int nthr = 64 + (d.A * swc_lrk + 63) / 64 * 64;
-    const size_t lds = (5 * (((size_t)d.A * d.P + 1) & ~(size_t)1) + 32 + (size_t)d.A * (32 + 2 * d.BW + 2) + 16) * sizeof(double) + 2 * ((size_t)d.A + 2) * sizeof(int4) +
-                       ((size_t)d.A * d.A + (size_t)d.A + 8) * sizeof(int) + 16;
+    const size_t lds = swc_lds;       // beyond 64 KB at small P and many directions (P = 8, A >= 71): opted in by prepare_sweep_kernels
     switch (d.BW) {
       case 0: hipLaunchKernelGGL(k_sweep_chain<0>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
       case 1: hipLaunchKernelGGL(k_sweep_chain<1>, dim3(1, 1, c.nch), dim3(nthr), lds, st, c); break;
@@ -1766,6 +1769,8 @@ void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st)
 
 void prepare_sweep_kernels() {
   set_max_lds((const void*)k_sweep);
+  set_max_lds((const void*)k_sweep_chain<0>); set_max_lds((const void*)k_sweep_chain<1>); set_max_lds((const void*)k_sweep_chain<2>);
+  set_max_lds((const void*)k_sweep_chain<3>); set_max_lds((const void*)k_sweep_chain<4>); set_max_lds((const void*)k_sweep_chain<5>);
   set_max_lds((const void*)k_pair_gram<false, false>); set_max_lds((const void*)k_pair_gram<true, false>); set_max_lds((const void*)k_pair_gram<true, true>);
   set_max_lds((const void*)k_factor<32, 0>); set_max_lds((const void*)k_factor<64, 0>);
   set_max_lds((const void*)k_factor<32, 1>); set_max_lds((const void*)k_factor<64, 1>);

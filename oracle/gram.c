@@ -324,3 +324,31 @@ void orc_gram_run_warm(const orc_data* d, const orc_gram* g, const orc_hyper* h,
   }
   free(tilde_tau);
 }
+
+/* The Nu_Z sweep of BFMMM_Nu_Z (BFMMM.h:1073-1107 + loglik :1106) in the same sufficient-statistics form: Z, pi, alpha_3, nu,
+ * tau, sigma^2; Phi, chi, gamma, delta, A are carried (with Phi = 0, chi = 0 in the multi-try entry point). */
+static void gcarry(double* base, size_t len, int iter, int T) {
+  if (iter < T - 1) memcpy(base + len * (size_t)(iter + 1), base + len * (size_t)iter, sizeof(double) * len);
+}
+
+void orc_gram_run_nu_z(const orc_data* d, const orc_gram* g, const orc_hyper* h, uint64_t seed, uint32_t chain, int T,
+                       int first_iter, int n_iter, orc_chain* c) {
+  const int n = d->n, K = d->K, P = d->P, M = d->M;
+  const int64_t N = d->off[d->n];
+  for (int i = first_iter; i < first_iter + n_iter && i < T; ++i) {
+    orc_rng r = {seed, chain, (uint32_t)i, 0};
+    gram_updateZ(d, g, &r, 1.0, i, T, h->a_Z_PM, c);
+    orc_updatePi_PM(d, &r, i, T, h->c, h->a_pi_PM, c);
+    orc_updateAlpha3(d, &r, i, T, h->b, h->var_alpha3, c);
+    gram_updateNu(d, g, &r, 1.0, i, T, c);
+    orc_updateTau(d, &r, i, T, h->alpha_nu, h->beta_nu, c);
+    gram_updateSigma(d, g, &r, i, T, h->alpha_0, h->beta_0, c);
+    gcarry(c->chi, (size_t)n * M, i, T);
+    gcarry(c->Phi, (size_t)K * P * M, i, T);
+    gcarry(c->gamma, (size_t)K * P * M, i, T);
+    gcarry(c->delta, (size_t)K * M, i, T);
+    gcarry(c->A, (size_t)K * 2, i, T);
+    const double sigma = c->sigma[i];
+    c->loglik[i] = -(double)N * (0.91893853320467274178 + log(sqrt(sigma))) - rss_of(d, g, c, i) / (2.0 * sigma);
+  }
+}

@@ -184,6 +184,11 @@ struct orc_gram_s* orc_gram_prepare(const orc_data* d);
 void orc_gram_free(struct orc_gram_s* g);
 void orc_gram_run_warm(const orc_data* d, const struct orc_gram_s* g, const orc_hyper* h, uint64_t seed, uint32_t chain, int T,
                        int first_iter, int n_iter, orc_chain* c);
+void orc_gram_run_nu_z(const orc_data* d, const struct orc_gram_s* g, const orc_hyper* h, uint64_t seed, uint32_t chain, int T,
+                       int first_iter, int n_iter, orc_chain* c);
+
+/* updates.c: loops over a basis row restricted to its non-zero window (bit-identical sums; full-size parity tests only) */
+void orc_set_row_window(int on);
 
 void orc_beta_ladder(int N_t, double beta_N_t, double* ladder);
 double orc_calculatePZeta(const orc_data* d, double beta_i, int iter, const orc_chain* c);

@@ -49,23 +49,39 @@ static int singular_route(const orc_rng* r, uint32_t upd, uint32_t idx0, int P, 
   return 1;
 }
 
+/* Optional, for the full-size parity tests only (orc_set_row_window(1); default 0 = the reference's dense row products, which
+ * is what bench.py's cpu_baseline times): every loop over the entries of a basis row B_i(l, .) runs over the row's non-zero
+ * window [W_LO, W_HI) only.  The skipped terms are exact zeros times finite numbers, so every sum is BIT-IDENTICAL to the dense
+ * loop (tests/test_oracle_row_window.py); a cubic B-spline row has 4 non-zeros of 30, a multivariate "row" 1 of 50. */
+static int g_row_window = 0;
+static int W_LO = 0, W_HI = 0;
+void orc_set_row_window(int on) { g_row_window = on; }
+static inline void set_window(const double* b, int P) {
+  W_LO = 0; W_HI = P;
+  if (!g_row_window) return;
+  while (W_LO < P && b[W_LO] == 0) ++W_LO;
+  while (W_HI > W_LO && b[W_HI - 1] == 0) --W_HI;
+}
+#define WIN(b) set_window((b), P)
+#define WIN_P(b, P_) set_window((b), (P_))
+
 static inline double dot_nu(const double* nu_t, int K, int P, int k, const double* b) {
   double s = 0.0;
-  for (int p = 0; p < P; ++p) s += nu_t[k + (size_t)K * p] * b[p];
+  for (int p = W_LO; p < W_HI; ++p) s += nu_t[k + (size_t)K * p] * b[p];
   return s;
 }
 /* arma::dot(Phi.slice(m).row(k), B.row(l)) */
 static inline double dot_phi(const double* phi_t, int K, int P, int k, int m, const double* b) {
   const double* s0 = phi_t + (size_t)K * P * m;
   double s = 0.0;
-  for (int p = 0; p < P; ++p) s += s0[k + (size_t)K * p] * b[p];
+  for (int p = W_LO; p < W_HI; ++p) s += s0[k + (size_t)K * p] * b[p];
   return s;
 }
 /* arma::dot(eta.slice(k) * X.row(i).t(), B.row(l)) */
 static inline double dot_eta(const orc_data* d, const double* eta_t, int k, int i, const double* b) {
   DIMS;
   double s = 0.0;
-  for (int p = 0; p < P; ++p) {
+  for (int p = W_LO; p < W_HI; ++p) {
     double e = 0.0;
     for (int dd = 0; dd < D; ++dd) e += eta_t[p + (size_t)P * (dd + (size_t)D * k)] * XCOV(i, dd);
     s += e * b[p];
@@ -76,7 +92,7 @@ static inline double dot_eta(const orc_data* d, const double* eta_t, int k, int 
 static inline double dot_xi(const orc_data* d, const double* xi_tk, int m, int i, const double* b) {
   DIMS;
   double s = 0.0;
-  for (int p = 0; p < P; ++p) {
+  for (int p = W_LO; p < W_HI; ++p) {
     double e = 0.0;
     for (int dd = 0; dd < D; ++dd) e += xi_tk[p + (size_t)P * (dd + (size_t)D * m)] * XCOV(i, dd);
     s += e * b[p];
@@ -126,6 +142,7 @@ static double lpdf_z(const orc_data* d, const orc_chain* c, int iter, int i, con
   const int ni = NI(i);
   for (int l = 0; l < ni; ++l) {
     const double* b = BROW(i, l);
+    WIN(b);
     double mean = 0.0;
     for (int k = 0; k < K; ++k) {
       mean = mean + Zrow[k] * dot_nu(nu_t, K, P, k, b);
@@ -282,11 +299,12 @@ void orc_updatePhi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
           const double chim = chi_t[i + (size_t)n * m];
           for (int l = 0; l < ni; ++l) {
             const double* b = BROW(i, l);
+            WIN(b);
             double ph = YOBS(i, l) - zij * dot_nu(nu_t, K, P, j, b);
             if (D > 0) ph -= zij * dot_eta(d, SL_ETA(c, iter), j, i, b);
             const double w2 = zij * zij * (chim * chim);
-            for (int q = 0; q < P; ++q)
-              for (int p = 0; p < P; ++p) M_1[p + (size_t)P * q] += w2 * b[p] * b[q];
+            for (int q = W_LO; q < W_HI; ++q)
+              for (int p = W_LO; p < W_HI; ++p) M_1[p + (size_t)P * q] += w2 * b[p] * b[q];
             for (int k = 0; k < K; ++k) {
               const double zik = Z_t[i + (size_t)n * k];
               for (int nn = 0; nn < M; ++nn) {
@@ -307,7 +325,7 @@ void orc_updatePhi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
               }
             }
             const double w = zij * chim * ph;
-            for (int p = 0; p < P; ++p) m_1[p] += w * b[p];
+            for (int p = W_LO; p < W_HI; ++p) m_1[p] += w * b[p];
           }
         }
       }
@@ -462,10 +480,11 @@ void orc_updateNu(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
         const int ni = NI(i);
         for (int l = 0; l < ni; ++l) {
           const double* b = BROW(i, l);
+          WIN(b);
           double ph = YOBS(i, l);
           const double w2 = zij * zij;
-          for (int q = 0; q < P; ++q)
-            for (int p = 0; p < P; ++p) B_1[p + (size_t)P * q] += w2 * b[p] * b[q];
+          for (int q = W_LO; q < W_HI; ++q)
+            for (int p = W_LO; p < W_HI; ++p) B_1[p + (size_t)P * q] += w2 * b[p] * b[q];
           for (int k = 0; k < K; ++k) {
             const double zik = Z_t[i + (size_t)n * k];
             if (zik != 0) {
@@ -479,7 +498,7 @@ void orc_updateNu(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
             }
           }
           const double w = zij * ph;
-          for (int p = 0; p < P; ++p) b_1[p] += w * b[p];
+          for (int p = W_LO; p < W_HI; ++p) b_1[p] += w * b[p];
         }
       }
     }
@@ -541,6 +560,7 @@ void orc_updateTau(const orc_data* d, const orc_rng* r, int iter, int T, double 
 /* fitted mean at observation (i,l): shared by updateSigma / calcLikelihood, which walk
  * k -> n with the Z(i,k) != 0 skip (UpdateSigma.h:39-46, CalculateLikelihood.h:30-39) */
 static double fitted_skipzero(const orc_data* d, const orc_chain* c, int iter, int i, const double* b) {
+  WIN_P(b, d->P);
   DIMS;
   const double* nu_t = SL_NU(c, iter);
   const double* phi_t = SL_PHI(c, iter);
@@ -572,6 +592,7 @@ double orc_yobs(const orc_data* d, int i, int l) { return YOBS(i, l); }
 double orc_row_dot(const orc_data* d, const orc_chain* c, int iter, int i, int l, int k, int mt) {
   DIMS;
   const double* b = BROW(i, l);
+  WIN(b);
   if (mt == 0) return dot_nu(SL_NU(c, iter), K, P, k, b) + (D > 0 ? dot_eta(d, SL_ETA(c, iter), k, i, b) : 0.0);
   return dot_phi(SL_PHI(c, iter), K, P, k, mt - 1, b) + (D > 0 ? dot_xi(d, SL_XI(c, iter, k), mt - 1, i, b) : 0.0);
 }
@@ -619,6 +640,7 @@ void orc_updateChi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
       double w = 0, W = 0;
       for (int l = 0; l < ni; ++l) {
         const double* b = BROW(i, l);
+        WIN(b);
         double ph = 0;
         for (int k2 = 0; k2 < K; ++k2) {
           double t = dot_phi(phi_t, K, P, k2, m, b);
@@ -732,14 +754,15 @@ void orc_updateEta(const orc_data* d, const orc_rng* r, double beta_i, int iter,
           const double xid = XCOV(i, dd);
           for (int l = 0; l < ni; ++l) {
             const double* b = BROW(i, l);
+            WIN(b);
             double ph = YOBS(i, l);
             const double w2 = zij * zij * xid * xid;
-            for (int q = 0; q < P; ++q)
-              for (int p = 0; p < P; ++p) B_1[p + (size_t)P * q] += w2 * b[p] * b[q];
+            for (int q = W_LO; q < W_HI; ++q)
+              for (int p = W_LO; p < W_HI; ++p) B_1[p + (size_t)P * q] += w2 * b[p] * b[q];
             for (int rr = 0; rr < D; ++rr)
               if (rr != dd) {
                 double s = 0.0;
-                for (int p = 0; p < P; ++p) s += eta_t[p + (size_t)P * (rr + (size_t)D * j)] * b[p];
+                for (int p = W_LO; p < W_HI; ++p) s += eta_t[p + (size_t)P * (rr + (size_t)D * j)] * b[p];
                 ph = ph - zij * XCOV(i, rr) * s;
               }
             for (int k = 0; k < K; ++k) {
@@ -753,7 +776,7 @@ void orc_updateEta(const orc_data* d, const orc_rng* r, double beta_i, int iter,
               }
             }
             const double w = zij * xid * ph;
-            for (int p = 0; p < P; ++p) b_1[p] += w * b[p];
+            for (int p = W_LO; p < W_HI; ++p) b_1[p] += w * b[p];
           }
         }
       }
@@ -843,10 +866,11 @@ void orc_updateXi(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
             const double chim = chi_t[i + (size_t)n * m];
             for (int l = 0; l < ni; ++l) {
               const double* b = BROW(i, l);
+              WIN(b);
               double ph = YOBS(i, l);
               const double w2 = zij * zij * xid * xid * (chim * chim);
-              for (int q = 0; q < P; ++q)
-                for (int p = 0; p < P; ++p) M_1[p + (size_t)P * q] += w2 * b[p] * b[q];
+              for (int q = W_LO; q < W_HI; ++q)
+                for (int p = W_LO; p < W_HI; ++p) M_1[p + (size_t)P * q] += w2 * b[p] * b[q];
               for (int k = 0; k < K; ++k) {
                 const double zik = Z_t[i + (size_t)n * k];
                 ph = ph - (zik * (dot_nu(nu_t, K, P, k, b) + dot_eta(d, eta_t, k, i, b)));
@@ -855,10 +879,10 @@ void orc_updateXi(const orc_data* d, const orc_rng* r, double beta_i, int iter, 
                              (dot_phi(phi_t, K, P, k, nn, b) + dot_xi(d, SL_XI(c, iter, k), nn, i, b)));
               }
               double own = 0.0;
-              for (int p = 0; p < P; ++p) own += xi_j[p + (size_t)P * (dd + (size_t)D * m)] * b[p];
+              for (int p = W_LO; p < W_HI; ++p) own += xi_j[p + (size_t)P * (dd + (size_t)D * m)] * b[p];
               ph = ph + (zij * chim * xid * own);
               const double w = zij * chim * xid * ph;
-              for (int p = 0; p < P; ++p) m_1[p] += w * b[p];
+              for (int p = W_LO; p < W_HI; ++p) m_1[p] += w * b[p];
             }
           }
         }

@@ -221,6 +221,11 @@ class Chain:
                 arr[..., 0] = v
 
 
+def set_row_window(on):
+    """oracle/updates.c: loops over a basis row restricted to its non-zero window (bit-identical; full-size parity tests only)"""
+    lib().orc_set_row_window(int(bool(on)))
+
+
 def run_sweeps(model, hyper, chain, sweep, n_iter=None, seed=1, chain_id=0, covariance_adj=False, first_iter=0):
     n_iter = chain.T if n_iter is None else n_iter
     lib().orc_run_sweeps(C.byref(model.data), C.byref(hyper), seed, chain_id, sweep, int(covariance_adj),
@@ -230,24 +235,43 @@ def run_sweeps(model, hyper, chain, sweep, n_iter=None, seed=1, chain_id=0, cova
 SWEEP_NU_Z, SWEEP_THETA, SWEEP_WARM = 0, 1, 2
 
 
-def run_warm_gram(model, hyper, chain, n_iter=None, seed=1, chain_id=0, first_iter=0):
-    """The warm-start sweep in sufficient-statistics form on the CPU (oracle/gram.c); returns the seconds spent in the
-    sweeps (the one-off G_i, s_i, yy_i pass is not included)."""
+def run_warm_gram(model, hyper, chain, n_iter=None, seed=1, chain_id=0, first_iter=0, sweep=SWEEP_WARM, prepared=None):
+    """The warm-start sweep (or, sweep=SWEEP_NU_Z, the Nu_Z sweep) in sufficient-statistics form on the CPU (oracle/gram.c);
+    returns the seconds spent in the sweeps (the one-off G_i, s_i, yy_i pass is not included).  `prepared`: a handle from
+    gram_prepare(model) to share that pass between calls (the caller frees it with gram_free)."""
     import time
     n_iter = chain.T if n_iter is None else n_iter
     L = lib()
+    _gram_sigs(L)
+    g = L.orc_gram_prepare(C.addressof(model.data)) if prepared is None else prepared
+    fn = L.orc_gram_run_warm if sweep == SWEEP_WARM else L.orc_gram_run_nu_z
+    t0 = time.perf_counter()
+    fn(C.addressof(model.data), g, C.addressof(hyper), seed, chain_id, chain.T, first_iter, n_iter, C.addressof(chain.c))
+    dt = time.perf_counter() - t0
+    if prepared is None:
+        L.orc_gram_free(g)
+    return dt
+
+
+def _gram_sigs(L):
     L.orc_gram_prepare.restype = C.c_void_p
     L.orc_gram_prepare.argtypes = [C.c_void_p]
     L.orc_gram_free.argtypes = [C.c_void_p]
-    L.orc_gram_run_warm.restype = None
-    L.orc_gram_run_warm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    g = L.orc_gram_prepare(C.addressof(model.data))
-    t0 = time.perf_counter()
-    L.orc_gram_run_warm(C.addressof(model.data), g, C.addressof(hyper), seed, chain_id, chain.T, first_iter, n_iter,
-                        C.addressof(chain.c))
-    dt = time.perf_counter() - t0
+    for fn in (L.orc_gram_run_warm, L.orc_gram_run_nu_z):
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+
+def gram_prepare(model):
+    L = lib()
+    _gram_sigs(L)
+    return L.orc_gram_prepare(C.addressof(model.data))
+
+
+def gram_free(g):
+    L = lib()
+    _gram_sigs(L)
     L.orc_gram_free(g)
-    return dt
 
 
 def run_warm_tt(model, hyper, chain, N_t, n_temp_trans, beta_N_t, n_iter=None, seed=1, chain_id=0, first_iter=0,

@@ -40,6 +40,7 @@ def simulate(n, K, M, degree, n_internal, seed, n_pts=60):
     (3, 7, 4, 10, 50),     # band width 4, odd M, P = 15
     (2, 3, 5, 20, 40),     # band width 5, P = 26
     (5, 9, 3, 26, 64),     # A*P = 1500 > 704: the general sweep kernel, P = 30
+    (8, 8, 3, 4, 64),      # P = 8, A = 72: the one-wave sweep kernel with more than 64 KB of dynamic LDS (opt-in attribute)
 ])
 def test_warm_trajectory_matches_oracle_across_shapes(K, M, degree, n_internal, n):
     import bayesfmmm_amd as bf

@@ -24,3 +24,26 @@ def test_gram_form_reproduces_the_reference_structure_sweep():
         a, b = getattr(ch_gram, nm), getattr(ch_ref, nm)
         err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
         assert err < 1e-7, (nm, err)
+
+
+def test_gram_form_reproduces_the_reference_structure_nu_z_sweep():
+    """the Nu_Z sweep (BFMMM.h:1073-1107) in Gram form, with Phi = 0 and chi = 0 as the multi-try entry point runs it and with a
+    generic Phi / chi carried through"""
+    for zero in (True, False):
+        sim = simulate_functional(n=19, M=2, sigma_sq=0.01, seed=6, ragged=True)
+        T = 4
+        model, ch_ref = truth_chain(sim, T)
+        _, ch_gram = truth_chain(sim, T)
+        for ch in (ch_ref, ch_gram):
+            r2 = np.random.default_rng(10)
+            ch.nu[:, :, 0] = sim["nu"] + 0.3 * r2.standard_normal(ch.nu.shape[:2])
+            if zero:
+                ch.chi[:] = 0.0
+                ch.Phi[:] = 0.0
+        h = O.make_hyper(sim["K"])
+        O.run_sweeps(model, h, ch_ref, O.SWEEP_NU_Z, seed=4, chain_id=3)
+        O.run_warm_gram(model, h, ch_gram, seed=4, chain_id=3, sweep=O.SWEEP_NU_Z)
+        for nm in ["nu", "Phi", "chi", "Z", "pi", "alpha3", "delta", "A", "gamma", "tau", "sigma", "loglik"]:
+            a, b = getattr(ch_gram, nm), getattr(ch_ref, nm)
+            err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+            assert err < 1e-7, (zero, nm, err)
