@@ -1335,7 +1335,11 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
   if (chainw && n_steps > 0) {
     // (the compiler waits for ge0 / ge1 here; everything issued above is older and already on its way)
     // the issue order of the steady state: C(st), H(st), C(st + 1), H(st + 1)
+    // (s_nop 13 / 14 and 11 / 12 below are MARKERS for tools/isa_check.py, which verifies in the shipped code object that no
+    //  instruction touches a prefetch destination between its load and the counted wait: tests/test_isa_sweep_chain.py)
+    asm volatile("s_nop 13");
     issueC(c0s, ge0.y); issueH(h0s, ge0.x); issueC(c1s, ge1.y); issueH(h1s, ge1.x);
+    asm volatile("s_nop 14");
   }
   __syncthreads();
 #ifdef BFMMM_TIMELINE
@@ -1346,6 +1350,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
     // ================= the chain wave =================
     // mat-vec role of lane l: rows 2 pp, 2 pp + 1 (pp = l >> 2), columns q = 8 g .. 8 g + 7 (g = l & 3)
     // band role of lane l   : row pb = 2 pp + (l & 1), rank half h = (l >> 1) & 1
+    asm volatile("s_nop 11");
     int4 e0 = ge0, e1 = ge1, e2 = ge2;
     // rank 0 is complete: its rhs; the h = 0 lanes then hold rank 1, the h = 1 lanes rank 2
     {
@@ -1356,7 +1361,9 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
     double lz0 = lzs[e0.z + pb], th0 = th[e0.z + pb];
     double hq1 = hqs[e1.z + pb];                    // H_aa theta_a of the direction of step st + 1
     asm volatile("" ::: "memory");
-    auto step = [&](int st, SwcC& cs, SweepH<BW>& hs) {
+    // (LAST: the odd last step behind the pair loop issues no further prefetch -- nothing follows it)
+    auto step = [&](auto last_tag, int st, SwcC& cs, SweepH<BW>& hs) {
+      constexpr bool LAST = decltype(last_tag)::value;
       // ---- mat-vec operands first: rhs was written at the end of the previous step
       const v2d* rv = (const v2d*)(rhs + 8 * g);
       v2d x[4];
@@ -1380,7 +1387,7 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
       v2d s0 = cs.v[0] * x[0].x, s1 = cs.v[1] * x[0].y;
 #pragma unroll
       for (int u = 1; u < 4; ++u) { s0 += cs.v[2 * u] * x[u].x; s1 += cs.v[2 * u + 1] * x[u].y; }
-      issueC(cs, e2.y);
+      if constexpr (!LAST) issueC(cs, e2.y);
       const v2d ss = s0 + s1;
       // sum over the four column groups of the quad (every lane of the quad ends with the same two sums), then this lane's row
       double a_x = ss.x, a_y = ss.y;
@@ -1412,11 +1419,11 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
         }
         r = pk;
       }
-      swc_wait_h<NC + NH + NC, BW>(hs);
+      swc_wait_h<(LAST ? 0 : NC) + NH + NC, BW>(hs);       // younger loads in flight: C(st + 2) (not issued by the last step), H(st + 1), C(st + 1)
       double v0 = hs.h[0].x * dv[0], v1 = hs.h[0].y * dv[1];
 #pragma unroll
       for (int k = 1; k <= BW; ++k) { v0 += hs.h[k].x * dv[2 * k]; v1 += hs.h[k].y * dv[2 * k + 1]; }      // last .y is the zero pad
-      issueH(hs, e2.x);
+      if constexpr (!LAST) issueH(hs, e2.x);
       r -= (v0 + v1);
       if (wr && st + 1 < n_steps) { rhs[pb] = f * (r + hq1); rbef[(st + 1) * P + pb] = r; }
       asm volatile("" ::: "memory");
@@ -1426,13 +1433,19 @@ __global__ __launch_bounds__(SWC_THREADS) void k_sweep_chain(Ctx c0) {
       if (h == 0) r = rsw;
       e0 = e1; e1 = e2; e2 = e3; lz0 = lz1; th0 = th1; hq1 = hq2;
     };
-    for (int st = 0; st < n_steps; st += 2) {
-      step(st, c0s, h0s);
-      if (st + 1 < n_steps) step(st + 1, c1s, h1s);
+    // (pairs of steps in the loop and an odd last step behind it -- not `if (st + 1 < n_steps)` inside the loop: the control-flow
+    //  graph then has no path "first half, skipped second half, first half again", which never runs but which a static check of
+    //  the counted waits would have to assume: tools/isa_check.py)
+    int st = 0;
+    for (; st + 1 < n_steps; st += 2) {
+      step(std::false_type{}, st, c0s, h0s);
+      step(std::false_type{}, st + 1, c1s, h1s);
     }
+    if (st < n_steps) step(std::true_type{}, st, c0s, h0s);
     // drain the prefetches of the (clamped) tail before their registers are reused
     swc_wait_c<0>(c0s); swc_wait_c<0>(c1s);
     swc_wait_h<0, BW>(h0s); swc_wait_h<0, BW>(h1s);
+    asm volatile("s_nop 12");
 #ifdef BFMMM_TIMELINE
     if (tid == 2) { dyn->stamps[25] = wall_clock64(); dyn->stamps[26] = n_spin; }
 #endif

@@ -200,7 +200,8 @@ def other_configs(bf, steps=200, warmup=20):
     mask = S.SWEEP_WARM | S.COV_MEAN | S.COV_XI
     def timed(smp_, mask_):
         """the same `steps` sweeps three times over (same iterations, same seed: the chain slots are simply rewritten); the
-        fastest is reported and all three are kept -- one run in five of these side records came out 15 % slow on the box"""
+        MEDIAN is reported as ms_per_sweep and all three are kept in ms_per_sweep_runs (the first is the first call after
+        prepare_run, what a user who calls once pays)"""
         smp_.run(mask_, warmup, seed=2)
         smp_.prepare_run(mask_, steps, first_iter=warmup, seed=2)
         runs = []
@@ -208,7 +209,7 @@ def other_configs(bf, steps=200, warmup=20):
             t0 = time.perf_counter()
             smp_.run(mask_, steps, first_iter=warmup, seed=2)
             runs.append((time.perf_counter() - t0) / steps)
-        return min(runs), [r * 1e3 for r in runs]
+        return sorted(runs)[1], [r * 1e3 for r in runs]
 
     dt, runs3 = timed(smp, mask)
     n, P, M, K, D = w["n"], w["P"], w["M"], w["K"], w["D"]
@@ -279,7 +280,9 @@ def config5_record(bf, w, torch, dist, backend, rank, world, local_rank, steps, 
     if smp is not None:
         smp.close()
     total = N_CHAINS_CONFIG5 * steps
-    b_band5 = 3 * n * 8 * (4 * P + P + 1) + 8 * n * 2 * K          # band-packed records, per chain-iteration
+    b_band5 = 3 * n * 8 * (4 * P + P + 1) + 8 * n * 2 * K          # band-packed records, per chain-iteration (every chain charged its own record passes)
+    cpg = -(-N_CHAINS_CONFIG5 // world)                            # chains of one GPU's batch: they share ONE copy of the records
+    b_shared_step = world * (3 * n * 8 * (4 * P + P + 1)) + N_CHAINS_CONFIG5 * 8 * n * 2 * K      # bytes of one step of all 8 chains: one record pass per batch and block + every chain's Z
     b_alg5 = 3 * n * 8 * (P * P + P + 1) + 8 * n * 2 * K           # SURVEY 8(d) config 5 (dense records), per chain-iteration
     pm5 = None
     try:
@@ -293,15 +296,24 @@ def config5_record(bf, w, torch, dist, backend, rank, world, local_rank, steps, 
         traffic = sum(2.0 * ((v.get("hbm_read_bytes_per_launch") or 0.0) + (v.get("hbm_write_bytes_per_launch") or 0.0))
                       for k, v in pm5.items() if k.startswith("k_") and v.get("calls", 0) >= 200)
     return dict(workload=f"BFMMM_Nu_Z_multiple_try chains (n_try=7: 8 chains of the Nu_Z sweep) on the config-2 data, dealt "
-                         f"round-robin over {world} GPU(s), {-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch",
+                         f"round-robin over {world} GPU(s), {-(-N_CHAINS_CONFIG5 // world)} per GPU as one sampler batch; STRONG scaling of 8 "
+                         "latency-bound chains: one GPU already overlaps its 8 chains, so the expected ceiling at N = 8 (one chain "
+                         "per GPU) is about 8 x the one-chain Nu_Z rate, i.e. roughly 1.2-1.5 x the N = 1 value, not 8 x (DESIGN.md 7)",
                 scaling="strong", n_gpus=world, chains=N_CHAINS_CONFIG5, chains_per_gpu=-(-N_CHAINS_CONFIG5 // world), steps=steps,
                 value=total / dt, unit="Gibbs iterations/sec (all chains)", ms_per_step=dt / steps * 1e3,
                 gather_s=gather_s, time_to_best_chain_s=dt + gather_s, best_chain=int(best["best_chain"]),
                 best_score=float(best["best_score"]),
                 roofline=dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS * world,
-                              achieved=b_band5 * total / dt / 1e9, frac=b_band5 * total / dt / 1e9 / (HBM_PEAK_GBS * world),
-                              bytes="band-packed records: 3 blocks x n x 8 (5 P + 1) per chain-iteration",
+                              achieved=b_shared_step * steps / dt / 1e9, frac=b_shared_step * steps / dt / 1e9 / (HBM_PEAK_GBS * world),
+                              bytes=f"shared-copy algorithmic bytes of one step of the 8 chains: the {cpg} chain(s) of a GPU's batch read ONE "
+                                    "band-packed copy of the records, 3 blocks x n x 8 (5 P + 1) per batch, + 8 n 2K of Z per chain",
+                              algorithmic_bytes_per_step=b_shared_step,
                               traffic_per_step_one_gpu=traffic,
+                              measured_achieved=None if (traffic is None or world != 1) else traffic * steps / dt / 1e9,
+                              measured_frac=None if (traffic is None or world != 1) else traffic * steps / dt / 1e9 / HBM_PEAK_GBS,
+                              per_chain_record_passes=dict(achieved=b_band5 * total / dt / 1e9, ratio_to_peak=b_band5 * total / dt / 1e9 / (HBM_PEAK_GBS * world),
+                                                           note="every chain-iteration charged its own three record passes (the round-3 figure): "
+                                                                "bytes a batch does not move, kept for comparison only"),
                               accounting_8d=dict(bytes_per_chain_iteration=b_alg5, ratio_to_peak=b_alg5 * total / dt / 1e9 / (HBM_PEAK_GBS * world),
                                                  note="SURVEY 8(d) charges every chain-iteration three passes over DENSE P x P "
                                                       "records; a batch shares ONE band-packed copy among its chains, so this ratio "
@@ -416,8 +428,9 @@ def main():
     it_rate = value / world            # iterations/s of one chain
     if fams:
         # dominant kernel = largest time PER ITERATION among the families that run every iteration AND stream the per-curve records
-        every = [k for k in fams if blocks[k] > 0 and fams[k]["launches"] >= args.profile_steps]
-        dom = max(every, key=lambda k: fams[k]["ms_per_iteration"])
+        # (definition FIXED from round 4 on, so that the series stays comparable: `roofline` is k_pair_gram, the longest kernel
+        #  that streams the per-curve records; k_sweep_chain -- as long, but ONE workgroup on 0.45 MB -- is printed beside it)
+        dom = "pair_gram"
         # Each bracketed launch carries the event pair and the gap of an eager launch (about 3 us); the timed region replays
         # the same kernels as a graph without either.  The families' bracketed times per iteration are therefore brought down
         # by one common per-launch overhead, chosen so that they sum to the measured graph-replay time of an iteration: these
@@ -427,7 +440,14 @@ def main():
         over = max(0.0, (sum(v["ms_per_iteration"] for v in fams.values()) - it_ms) / max(n_launch, 1.0))
         for v in fams.values():
             v["ms_per_launch_in_graph"] = max(v["ms_per_launch"] - over, 0.0) if v["launches"] else 0.0
-        ms = fams[dom]["ms_per_launch_in_graph"]
+        ms_live = fams[dom]["ms_per_launch_in_graph"]
+        prof_us = None      # the committed rocprofv3 average of the same command (profiles/r*_final_pmc_summary.json), if it is this build's
+        if pm and "k_pair_gram" in pm and pm["k_pair_gram"].get("calls", 0) >= 100:
+            prof_us = float(pm["k_pair_gram"]["avg_us"])
+        # `frac` follows from the committed profile when it agrees with the live measurement (within 20 %: a profile of an older
+        # build must not stand in for this one); the live figure is always printed beside it
+        use_prof = prof_us is not None and abs(prof_us * 1e-3 - ms_live) <= 0.2 * ms_live
+        ms = prof_us * 1e-3 if use_prof else ms_live
         rec_band, rec_dense = 8 * (5 * P + 1), 8 * (P * P + P + 1)          # bytes of one curve's record: stored / SURVEY 8(d)
         bytes_dom = blocks[dom] * n * rec_band
         ach = bytes_dom / (ms * 1e-3) / 1e9
@@ -440,7 +460,17 @@ def main():
         pg_flop = 2.0 * n * (R_pairs * 4 * P + A_dirs * P)
         roofline = dict(
             bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+            kernel_definition="k_pair_gram: the longest kernel of the iteration that streams the per-curve records (fixed definition)",
+            duration_us=ms * 1e3, duration_source=("rocprofv3 average, profiles/" + pm_file) if use_prof else "HIP events in this run",
+            duration_us_live=ms_live * 1e3, duration_us_profile=prof_us,
+            achieved_live=bytes_dom / (ms_live * 1e-3) / 1e9,
             traffic=measured_bytes(pm, dom), traffic_source=pm_file,
+            traffic_frac=None if measured_bytes(pm, dom) is None else measured_bytes(pm, dom) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            sweep_chain=dict(kernel="k_sweep_chain", note="one workgroup per chain working from the sufficient statistics (no record pass): a latency chain, on no roofline",
+                             duration_us=fams["sweep"]["ms_per_launch_in_graph"] * 1e3,
+                             measured_bytes_per_launch=measured_bytes(pm, "sweep"),
+                             achieved=None if measured_bytes(pm, "sweep") is None else measured_bytes(pm, "sweep") / (fams["sweep"]["ms_per_launch_in_graph"] * 1e-3) / 1e9,
+                             frac=None if measured_bytes(pm, "sweep") is None else measured_bytes(pm, "sweep") / (fams["sweep"]["ms_per_launch_in_graph"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
             algorithmic_bytes_per_launch=bytes_dom,
             bytes="band-packed records this build stores, 8 (5 P + 1) bytes per curve and data-touching block of the kernel",
             iteration=dict(algorithmic_bytes=b_band, achieved=b_band * it_rate / 1e9, frac=b_band * it_rate / 1e9 / HBM_PEAK_GBS,
@@ -460,10 +490,10 @@ def main():
                                                   for kn in KERNELS_OF[f_] if kn in pm and pm[kn].get("calls", 0) >= 100},
             per_kernel_ms_per_iteration={k: round(v["ms_per_iteration"], 6) for k, v in fams.items()},
             mfma=dict(kernel="k_pair_gram", flop_per_launch=pg_flop,
-                      achieved_tflops=pg_flop / (fams["pair_gram"]["ms_per_launch_in_graph"] * 1e-3) / 1e12,
+                      achieved_tflops=pg_flop / (ms * 1e-3) / 1e12,
                       peak_tflops=FP64_MFMA_PEAK_TF,
-                      frac=pg_flop / (fams["pair_gram"]["ms_per_launch_in_graph"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
-                      note="duration of k_pair_gram in the replayed graph; counter evidence: profiles/*_mfma_pmc.json"),
+                      frac=pg_flop / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
+                      note="same duration as `duration_us`; counter evidence: profiles/*_mfma_pmc.json"),
             note="the iteration is five dependent kernels, each bound by dependent-step latency at this size (the records, 5 MB, "
                  "live in L2 / Infinity Cache): `frac` is small by construction; `traffic` (rocprofv3 FETCH_SIZE x 2 + "
                  "WRITE_SIZE per launch) and iteration.measured_* are what actually moves")
