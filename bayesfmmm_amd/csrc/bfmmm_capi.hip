@@ -26,6 +26,9 @@ void prepare_curve_kernels();
 void prepare_sweep_kernels();
 void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st);
 void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st);
+bool pgp_geometry(const Dims& d, int nch, int KS, int NKS, PgPack& g);
+size_t pgp_pack_doubles(const PgPack& g);
+void launch_pair_gram_pack(const Ctx& c, const PgPack& g, double* pack, hipStream_t st);
 void launch_factor(const Ctx& c, hipStream_t st);
 int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_sweep_tables(const Ctx& c, hipStream_t st);
@@ -91,10 +94,14 @@ struct bfmmm_handle {
   //   gR / gFR = the remainder of a run after the unrolled graphs, as ONE graph of rem / remF iterations
   struct GraphSet { hipGraphExec_t gN = nullptr, gFN = nullptr, gL = nullptr, gR = nullptr, gFR = nullptr; int rem = 0, remF = 0; };
   static constexpr int MAX_SUB = 4;
+  // packed partial tiles of k_pair_gram_pack, one buffer per sub-batch stream (+ one for the whole batch on one stream)
+  double* pg_pack[MAX_SUB + 1] = {};
+  size_t pg_pack_doubles[MAX_SUB + 1] = {};
   GraphSet gs[MAX_SUB];
   hipStream_t sub_st[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};     // [0] = st
   hipEvent_t sub_ev[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
   int g_nsub = 1;
+  int g_pack_mode = 0;
   uint32_t g_mask = 0; int g_md = -1; uint64_t g_seed = 0; uint32_t g_chain = 0;
   int last_md = -1;
   int64_t tab_key = -1;                // (MD, mask) the step tables of k_sweep_chain were built for
@@ -775,17 +782,24 @@ static Plan make_plan(uint32_t mask, int MD) {
 // trail_z: the iteration ends with the stand-alone Z update of the NEXT iteration, in its lean form (the proposals were prepared
 // by this iteration's k_factor): sweeps without a chi pass cannot fuse the Z update into k_curve_chi, but they can still run
 // it in the order "first Z of the run, then bodies [pair_gram .. chi, next Z]".
+// pk / pack: the (sub-)batch runs its pair-Gram contraction through k_pair_gram_pack (chain batches, long curve sets)
 static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int NKS, int KS, hipStream_t st,
-                             std::vector<hipEvent_t>* evs, bool skip_z = false, bool fuse_z = false, bool trail_z = false) {
+                             std::vector<hipEvent_t>* evs, bool skip_z = false, bool fuse_z = false, bool trail_z = false,
+                             const PgPack* pk = nullptr, double* pack = nullptr, int side = -1) {
   auto mark = [&]() {
     if (evs) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs->push_back(e); }
   };
   mark();
   if (p.z && !skip_z) launch_curve(c, 0, p.z_update, st);
   mark();
-  launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
-  mark();
-  if (p.pg) launch_pg_reduce(c, NKS, st);
+  if (p.pg && pk) {
+    launch_pair_gram_pack(c, *pk, pack, st);      // (contraction + reduction; the pi / alpha_3 job rides in the reduction kernel)
+    mark();
+  } else {
+    launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
+    mark();
+    if (p.pg) launch_pg_reduce(c, NKS, st);
+  }
   mark();
   if (p.factor) launch_factor(c, st);
   mark();
@@ -816,6 +830,26 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   if ((size_t)NKS * c.d.NT * 256 > h->pg_part_doubles) return fail("bfmmm_run: internal workspace too small");
   Plan plan = make_plan(mask, MD);
   if (c.d.D > 0) { plan.z = true; plan.chi = true; plan.use_rss_part = 1; }
+  // pair-Gram through k_pair_gram_pack: batches of four or more chains with at least two row tiles per chain (BFMMM_PG_PACK=0 / 1
+  // switches it off / forces it wherever its limits allow -- both kernels sum in the same order, the results are bit-identical)
+  auto want_pack = [&](int cnt) {
+    const char* e = getenv("BFMMM_PG_PACK");
+    if (e) return atoi(e) != 0;
+    return cnt >= 4 && c.d.RT >= 2;
+  };
+  auto pack_for = [&](int slot, int cnt, PgPack& g, double** buf) -> int {      // 0: packed path ready, 1: not applicable, -1: error
+    *buf = nullptr;
+    if (!plan.pg || !want_pack(cnt) || !pgp_geometry(c.d, cnt, KS, NKS, g)) return 1;
+    const size_t need = pgp_pack_doubles(g);
+    if (h->pg_pack_doubles[slot] < need) {
+      double* nb = nullptr;
+      if (hipMalloc((void**)&nb, need * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 1; }      // (no room: the plain kernel needs no extra buffer)
+      h->allocs.push_back(nb);      // (an outgrown buffer stays until the handle is destroyed: graphs captured earlier may still hold it)
+      h->pg_pack[slot] = nb; h->pg_pack_doubles[slot] = need;
+    }
+    *buf = h->pg_pack[slot];
+    return 0;
+  };
   // without covariates the iteration ends with k_curve_chi: its scalar-job workgroup advances the counters and the
   // log-likelihood is reduced by the next iteration's k_pair_gram job (one kernel boundary less per iteration)
   c.defer_loglik = (c.d.D == 0) ? 1 : 0;
@@ -838,7 +872,9 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     for (int it = 0; it < n_iters; ++it) {
       std::vector<hipEvent_t> evs;
       const bool skip_z = pfuse && it > 0, fuse_z = pfuse && it + 1 < n_iters;
-      launch_iteration(h, c, plan, NKS, KS, h->st, &evs, skip_z, fuse_z);
+      PgPack pkp; double* packp = nullptr;
+      const bool use_p = pack_for(bfmmm_handle::MAX_SUB, h->nch, pkp, &packp) == 0;
+      launch_iteration(h, c, plan, NKS, KS, h->st, &evs, skip_z, fuse_z, false, use_p ? &pkp : nullptr, packp, bfmmm_handle::MAX_SUB);
       HIPCHK(hipStreamSynchronize(h->st));
       const int fams[7] = {FAM_Z, FAM_PG, FAM_REDUCE, FAM_FACTOR, FAM_SWEEP, FAM_CHI, FAM_LOGLIK};
       const bool ran[7] = {plan.z && !skip_z, true, plan.pg, plan.factor, true, true, c.defer_loglik == 0};
@@ -856,14 +892,15 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     const char* env_split = getenv("BFMMM_BATCH_SPLIT");
     int nsub = (h->nch >= 4) ? 2 : 1;
     if (env_split) nsub = std::max(1, std::min({atoi(env_split), (int)bfmmm_handle::MAX_SUB, h->nch / 2}));
-    const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub;
+    const int pack_mode = getenv("BFMMM_PG_PACK") ? 1 + (atoi(getenv("BFMMM_PG_PACK")) != 0) : 0;
+    const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub && h->g_pack_mode == pack_mode;
     if (!reuse) {
       for (auto& g_ : h->gs)
         for (hipGraphExec_t* g : {&g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR})
           if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
-      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_nsub = nsub; h->g_valid = true;
+      h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_nsub = nsub; h->g_pack_mode = pack_mode; h->g_valid = true;
     }
-    struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; int *rem, *remF; };
+    struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; int *rem, *remF; PgPack pk; double* pack; bool use_pack; int slot; };
     Sub subs[bfmmm_handle::MAX_SUB];
     h->sub_st[0] = h->st;
     for (int q = 0, q0 = 0; q < nsub; ++q) {
@@ -873,6 +910,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       bfmmm_handle::GraphSet& g_ = h->gs[q];
       subs[q] = Sub{chain_ctx(c, (unsigned)q0), h->sub_st[q], &g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR, &g_.rem, &g_.remF};
       subs[q].c.nch = cnt;
+      subs[q].use_pack = pack_for(q, cnt, subs[q].pk, &subs[q].pack) == 0;
+      subs[q].slot = q;
       q0 += cnt;
     }
     // graphs are captured on demand: kind 0 = full iterations, 1 = fused bodies (no Z in front, chi + next Z at the end),
@@ -882,7 +921,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       std::lock_guard<std::mutex> lock(g_capture_mutex);
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(sb.st, hipStreamCaptureModeRelaxed));
-      for (int r = 0; r < reps; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, kind != 0, kind == 1, kind == 3);
+      for (int r = 0; r < reps; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, kind != 0, kind == 1, kind == 3, sb.use_pack ? &sb.pk : nullptr, sb.pack, sb.slot);
       const hipError_t ec = hipStreamEndCapture(sb.st, &graph);      // always leaves capture mode, also after a failed launch
       if (ec != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(ec); }
       const hipError_t ei = hipGraphInstantiate(g, graph, nullptr, nullptr, 0);

@@ -111,10 +111,14 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
   const int i0 = ks * KS;
   const int RS = K + MD + 1, ONE = K;
   const int NP = d.NZZ + d.NCC, RP = NP + 1;
-  // LDS: every quantity is stored CURVE-CONTIGUOUS (row f of a table = the KS curves of the slice, stride KSP), and
-  // MFMA k-slot kq of step s is curve kq * KS/4 + s: a lane's operands of two consecutive steps are then adjacent,
-  // so one 16-byte LDS read feeds two MFMAs.
+  // LDS: every quantity is stored per table row (row f of a table = the KS curves of the slice, stride KSP) with curve il of the
+  // slice at POSITION pos(il) = (il & 3) KS/4 + (il >> 2): MFMA k-slot kq of step s reads position kq KS/4 + s, i.e. curve
+  // 4 s + kq -- the four curves of a step are consecutive curves (the CANONICAL summation order, shared with
+  // k_pair_gram_pack, whose chunks are runs of consecutive curves: a chain gives bit-identical H and t through either kernel),
+  // and a lane's operands of two consecutive steps are adjacent, so one 16-byte LDS read feeds two MFMAs.
   const int KSP = KS + 2;                    // even (16-byte alignment of the rows) and 2 mod 8 (row starts spread over banks)
+  const int KQ4 = KS >> 2;
+  auto pos = [&](int il) { return (il & 3) * KQ4 + (il >> 2); };
   const int GG = GROUPS ? G : 1;             // chains staged together (GROUPS: its own instantiation, so that the plain chain loop keeps its registers)
   const int TB = RS + (single ? 0 : RP);     // table rows of a chain
   double* sB = smem;                         // ncol x KSP  record columns
@@ -141,9 +145,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
       const int col = cb + u;
-      if (col < ncw) sW[((col < K) ? col : col + 1) * KSP + il] = live ? v[u] : 0.0;
+      if (col < ncw) sW[((col < K) ? col : col + 1) * KSP + pos(il)] = live ? v[u] : 0.0;
     }
-    if (cb == 0) { sW[ONE * KSP + il] = 1.0; sW[(K + MD) * KSP + il] = 0.0; }
+    if (cb == 0) { sW[ONE * KSP + il] = 1.0; sW[(K + MD) * KSP + il] = 0.0; }      // (constant rows: any order)
   };
   auto loadB = [&](const double* stilq, int base, double (&v)[UB]) {        // s-part workgroups (ncol = CTS * 16)
 #pragma unroll
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       const int q = base + tid + PG_THREADS * u;
       if (q < nB) {
         const int il = q / ncol, cc = q - il * ncol;
-        sB[cc * KSP + il] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
+        sB[cc * KSP + pos(il)] = (i0 + il < n && col0 + cc < colend) ? v[u] : 0.0;
       }
     }
   };
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int il = ilg + (PG_THREADS / 16) * (ub0 + u);
-      if (il < KS) sB[ccg * KSP + il] = (i0 + il < n && colok) ? v[u] : 0.0;
+      if (il < KS) sB[ccg * KSP + pos(il)] = (i0 + il < n && colok) ? v[u] : 0.0;
     }
   };
   // pair slot -> (a, b) table (packed upper triangles of Z x Z and chit x chit), decoded once
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
           if (e < nitem) {
             const int ci = e / KS, il = e - ci * KS;
             const int g = ci / ncw, col = ci - g * ncw;
-            sW[((size_t)g * TB + ((col < K) ? col : col + 1)) * KSP + il] = (i0 + il < n) ? vw[u] : 0.0;
+            sW[((size_t)g * TB + ((col < K) ? col : col + 1)) * KSP + pos(il)] = (i0 + il < n) ? vw[u] : 0.0;
           }
         }
         for (int x = tid; x < gc * KS; x += PG_THREADS) {
@@ -440,6 +444,265 @@ __global__ __launch_bounds__(256) void k_pg_reduce(Ctx c0, int NKS) {
     const int at = t2 / d.CTS, cs = t2 - at * d.CTS;
     const int row = at * 16 + rit, col = cs * 16 + cit;
     if (row < d.A && col < d.P) c.tvec[(size_t)row * d.P + col] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair-Gram for chain BATCHES and LONG curve sets (round 4): row tiles packed across the chains, chunked k-loop
+// ---------------------------------------------------------------------------------------------
+// The batch is ONE contraction  [nch R pair rows] x [n curves] x [LG record columns]  (+ [nch A single rows] x n x P for t_a):
+//  * the 16-row MFMA tiles run over the rows of ALL chains of the (sub-)batch back to back, so only the last tile is padded
+//    (8 x 168 rows = 84 full tiles instead of 8 x 11 with 8 rows of padding each; the s part 8 x 21 = 168 rows = 11 tiles
+//    instead of 16);
+//  * a wave owns ONE packed row tile and ALL column tiles of it (2 NP2 accumulators), so an A operand -- the product of two pair
+//    weights -- is formed once per k-step for 2 NP2 MFMAs and the LDS pipe moves 640 B per MFMA instead of 1.5 KB;
+//  * the workgroup walks its k-slice in CHUNKS of 16 curves (4 k-steps), double-buffered: the next chunk's records and weights
+//    are requested before the MFMAs of this one and stored after them, one barrier per chunk; LDS is ~50 KB and the kernel
+//    holds <= 128 VGPRs, so two workgroups (16 waves) share a CU and one's staging hides behind the other's MFMAs.  The
+//    accumulators persist across the chunks: partial tiles are written once per k-slice whatever its length.
+//  * records are staged as they lie in memory ([curve][column], no transposition): the 16-byte B read of lane (n, kq) holds columns
+//    32 tp + 2 n and 32 tp + 2 n + 1 of curve 4 s + kq and feeds TWO column tiles (the even and the odd columns of a 32-column
+//    pair) -- any assignment of columns to tiles will do, k_pg_reduce_pack knows it.
+// Summation order (canonical, shared with k_pair_gram): slice ks = curves [ks KS, ks KS + KS), one MFMA chain over its k-steps,
+// step s = curves 4 s .. 4 s + 3; A = (Z_j Z_j') (chit_m chit_m') resp. Z_j chit_m; slices combined by k_pg_reduce_pack in
+// k_pg_reduce's order.  A chain's H and t are therefore bit-identical to what k_pair_gram + k_pg_reduce give it alone.
+// Limits (otherwise the launcher keeps k_pair_gram): K <= 4, M <= 8, LG <= 128, P <= 32, no covariates, functional model.
+constexpr int PGP_CH = 16;                     // chunk: 16 curves = 4 k-steps
+constexpr int PGP_RB = 66;                     // row stride of the staged chunk (doubles): 64 record columns + 2 (16-byte aligned rows)
+constexpr int PGP_NWV = 3;                     // most weight values (Z_ik, chi_im) a thread stages per chunk
+
+template <int PGP_WAVES>
+__global__ __launch_bounds__(64 * PGP_WAVES, 4) void k_pair_gram_pack(Ctx c0, PgPack g, double* __restrict__ pack) {
+  constexpr int PGP_THREADS = 64 * PGP_WAVES;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Dims& d = c0.d;
+  const int n = d.n, K = d.K, MD = d.MD, nch = c0.nch;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+  const int ks = blockIdx.y, wg = blockIdx.x;
+  const int nwg_g = g.NRG * g.NCG;
+  if (ks >= g.NKS || wg >= nwg_g + g.NWG_S) return;
+  // A workgroup is (row group, column group): PGP_WAVES packed row tiles (one per wave) x 64 record columns (two 32-column pairs,
+  // four accumulators per wave).  The s part -- single-weight rows against the P columns of s_i -- runs through the SAME code: its
+  // rows multiply Z_j chit_m by 1 x 1 (exact), its 32 columns fill the first pair and the second pair's accumulators are dropped.
+  const bool single = wg >= nwg_g;
+  const int rg = single ? wg - nwg_g : wg / g.NCG, cg = single ? 0 : wg - rg * g.NCG;
+  const int i0 = ks * g.KS;
+  const int nchunk = (min(g.KS, n - i0) + PGP_CH - 1) / PGP_CH;
+  const int SL = g.SLS;                     // raw weight row of a (chain, curve): Z_1 .. Z_K | 1, chi_1 .. chi_M | 0 (| pad)
+  const int RW = single ? d.A : d.R;        // rows per chain
+  const int tile0 = rg * PGP_WAVES;
+  const int ntile = single ? g.TS : g.TG;
+  const int q0 = min((tile0 * 16) / RW, nch - 1);       // the chains this workgroup's rows belong to
+  const int q1 = min(((min(tile0 + PGP_WAVES, ntile)) * 16 - 1) / RW, nch - 1);
+  const int nq = q1 - q0 + 1;
+  constexpr int nbuf_b = 16 * PGP_RB;
+  double* sBb = smem;                                   // 2 x 16 x RB     record chunk, [curve][column]
+  double* sWb = smem + 2 * nbuf_b;                      // 2 x nq x 16 x SL   weights, [chain][curve][slot]
+  const int nbuf_w = nq * 16 * SL;
+  // ---- staging roles ----
+  // records: ONE 16-byte piece per thread: curve il = tid / 32 of the chunk, columns cb0 + 2 pc, + 1 (pc = tid % 32); the s part
+  // starts at column LG, which need not be 16-byte aligned: two 8-byte loads there
+  constexpr int NPB = 512 / PGP_THREADS;          // pieces per thread: piece e = tid + PGP_THREADS u -> curve e / 32, columns 2 (e % 32), + 1
+  const int b_pc = tid & 31;
+  const int cb0 = single ? d.LG : 64 * cg, cend = single ? d.LG + d.P : d.LG;      // (columns beyond the part are zero)
+  const int bc = cb0 + 2 * b_pc;
+  const bool ok0 = bc < cend, ok1 = bc + 1 < cend;
+  const int bc0 = min(bc, d.LREC - 2);
+  v2d vb[NPB];
+  // weights: value e = tid + 512 u of the workgroup's (chain, column, curve) items, curve fastest: chain q0 + e / (16 NV), source
+  // column (e / 16) % NV (Z_1 .. Z_K, chi_1 .. chi_M), curve e % 16 -- sixteen consecutive threads read a 128-byte segment
+  const int NV = K + MD - 1, nval = nq * NV * 16;
+  double wv[PGP_NWV];
+  const double* wsrc[PGP_NWV];
+  int wdst[PGP_NWV];
+#pragma unroll
+  for (int u = 0; u < PGP_NWV; ++u) {
+    const int e = min(tid + PGP_THREADS * u, nval - 1);
+    const int qq = e / (16 * NV), v = (e >> 4) - qq * NV;
+    const size_t offq = (size_t)(q0 + qq) * c0.chain_bytes;
+    wsrc[u] = (v < K) ? ptr_shift(c0.Z, offq) + (size_t)n * v : ptr_shift(c0.chi, offq) + (size_t)n * (v - K);
+    wdst[u] = (qq * 16 + (e & 15)) * SL + ((v < K) ? v : v + 1);
+    wv[u] = 0.0;
+  }
+  const int w_il = tid & 15;
+  auto load_chunk = [&](int t) {
+    const int ib = i0 + t * PGP_CH;
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int b_il = (tid + PGP_THREADS * u) >> 5;
+      const double* src = c0.rec + (size_t)min(ib + b_il, n - 1) * d.LREC + bc0;
+      if (!single) vb[u] = *(const v2d*)src;
+      else { vb[u].x = src[0]; vb[u].y = src[1]; }
+    }
+    const int i = min(ib + w_il, n - 1);
+#pragma unroll
+    for (int u = 0; u < PGP_NWV; ++u)
+      if (PGP_THREADS * u < nval) wv[u] = wsrc[u][i];
+  };
+  auto store_chunk = [&](int t, int buf) {
+    const int ib = i0 + t * PGP_CH;
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int b_il = (tid + PGP_THREADS * u) >> 5;
+      const bool liveb = ib + b_il < n;
+      v2d o2;
+      o2.x = (liveb && ok0) ? vb[u].x : 0.0; o2.y = (liveb && ok1) ? vb[u].y : 0.0;
+      *(v2d*)(sBb + buf * nbuf_b + b_il * PGP_RB + 2 * b_pc) = o2;
+    }
+    const bool live = ib + w_il < n;
+    double* sW = sWb + buf * nbuf_w;
+#pragma unroll
+    for (int u = 0; u < PGP_NWV; ++u)
+      if (tid + PGP_THREADS * u < nval) sW[wdst[u]] = live ? wv[u] : 0.0;
+  };
+  // the constant slots of both weight buffers: chit_0 = 1 at K, the zero slot (rows of the tile padding) at K + MD
+  for (int x = tid; x < 2 * nq * 16; x += PGP_THREADS) {
+    double* w = sWb + (x / (nq * 16)) * nbuf_w + (x % (nq * 16)) * SL;
+    w[K] = 1.0; w[K + MD] = 0.0;
+  }
+  // ---- MFMA role of the wave: packed row tile tile0 + wave, four accumulators (column pair 0 even / odd, pair 1 even / odd) ----
+  double4_t acc[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) acc[x] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // LDS offsets (doubles, within a weight buffer) of the four factors of this lane's row: A = (w[o0] w[o1]) (w[o2] w[o3]);
+  // pair row (j, j', m, m'): Z_j Z_j' chit_m chit_m';  single row (j, m): Z_j chit_m 1 1;  padding rows: the zero slot
+  const int ZERO = K + MD;
+  int o0 = ZERO, o1 = ZERO, o2_ = ZERO, o3 = ZERO;
+  const int tile = tile0 + wave;
+  const bool has_tile = tile < ntile;
+  if (has_tile) {
+    const int grow = tile * 16 + lr;
+    const int q = grow / RW, r = grow - q * RW;
+    if (q < nch) {
+      const int base = (q - q0) * 16 * SL;
+      if (!single) {
+        const int zz = r / d.NCC, cc = r - zz * d.NCC;
+        int a = 0, e = zz;
+        while (e >= K - a) { e -= K - a; ++a; }
+        o0 = base + a; o1 = base + a + e;
+        a = 0; e = cc;
+        while (e >= MD - a) { e -= MD - a; ++a; }
+        o2_ = base + K + a; o3 = base + K + a + e;
+      } else {
+        const int j = r / MD;
+        o0 = base + j; o1 = base + K + (r - j * MD); o2_ = base + K; o3 = base + K;
+      }
+    }
+  }
+  auto mfma_chunk = [&](int buf) {
+    const double* sB = sBb + buf * nbuf_b + 2 * lr;
+    const double* sW = sWb + buf * nbuf_w;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2 += 2) {
+      double a[2];
+      v2d b[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int il = 4 * (s2 + u) + kq;
+        const double* w = sW + il * SL;
+        a[u] = (w[o0] * w[o1]) * (w[o2_] * w[o3]);
+        b[u][0] = *(const v2d*)(sB + il * PGP_RB);
+        b[u][1] = *(const v2d*)(sB + il * PGP_RB + 32);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][0].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][0].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][1].x, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][1].y, acc[3], 0, 0, 0);
+      }
+    }
+  };
+  // ---- the chunk pipeline: the next chunk is requested before the MFMAs of this one and stored behind them ----
+  load_chunk(0);
+  store_chunk(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nchunk; ++t) {
+    if (t + 1 < nchunk) load_chunk(t + 1);
+    mfma_chunk(t & 1);
+    if (t + 1 < nchunk) store_chunk(t + 1, (t + 1) & 1);
+    __syncthreads();
+  }
+  // ---- partial tiles of this k-slice, accumulator layout (k_pg_reduce_pack): pair tile T, column pair tp, parity par at
+  //      index (T NP2 + tp) 2 + par; single tile T, parity par at TG 2 NP2 + 2 T + par ----
+  if (!has_tile) return;
+  double* out0 = pack + (size_t)ks * g.NTP * 256 + lane;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int tp = 2 * cg + (x >> 1);
+    const bool keep = single ? (x < 2) : (tp < g.NP2);
+    if (keep) {
+      const int idx = single ? g.TG * 2 * g.NP2 + tile * 2 + x : (tile * g.NP2 + tp) * 2 + (x & 1);
+      double* out = out0 + (size_t)idx * 256;
+      out[0] = acc[x][0]; out[64] = acc[x][1]; out[128] = acc[x][2]; out[192] = acc[x][3];
+    }
+  }
+}
+
+// pi / alpha_3 (+ the deferred log-likelihood) of every chain of the (sub-)batch: in k_pair_gram this job rides as an extra
+// workgroup; inside k_pair_gram_pack it would cost that kernel its register budget (the job needs 177 VGPRs, the contraction 88),
+// so it is the FIRST nch workgroups of the reduction kernel (12 us each, as long as the reduction itself: dispatched first they
+// run beside it; dispatched last they doubled the kernel: 25 us; on a side stream forked and joined inside the captured graph the
+// two cross-stream edges cost the 8-chain batch 80 us per step).
+// fixed-order sum of the k-slices of the packed partial tiles (the order of k_pg_reduce: four interleaved partial sums over the
+// slices, then (s0 + s1) + (s2 + s3)) and scatter to the chains' H, H2, t
+__global__ __launch_bounds__(256) void k_pg_reduce_pack(Ctx c0, PgPack g, const double* __restrict__ pack) {
+  const Dims& d = c0.d;
+  if ((int)blockIdx.x < c0.nch) {
+    job_pi_alpha(chain_ctx(c0, blockIdx.x));
+    return;
+  }
+  const int bx = blockIdx.x - c0.nch;
+  const int gid4 = bx * 256 + threadIdx.x;
+  const int gid = gid4 >> 2, gl = gid4 & 3;
+  const bool live = gid < g.NTP * 256;
+  const int gc = live ? gid : 0;
+  const int t = gc >> 8, q = gc & 255;
+  const int r = q >> 6, lane = q & 63;
+  const int rit = (lane >> 4) + 4 * r, cit = lane & 15;   // D layout of v_mfma_f64_16x16x4_f64
+  const double* src = pack + (size_t)t * 256 + q;
+  const size_t stride = (size_t)g.NTP * 256;
+  const int NKS = g.NKS;
+  double sg = 0.0;
+  const int nfull = NKS & ~3;
+  for (int k0 = gl; k0 < nfull; k0 += 32) {
+    double v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = src[(size_t)min(k0 + 4 * u, NKS - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (k0 + 4 * u < nfull) sg += v8[u];
+  }
+  {
+    double vt[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) vt[u] = src[(size_t)min(nfull + u, NKS - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (gl == 0 && nfull + u < NKS) sg += vt[u];
+  }
+  const double s01 = sg + __shfl_xor(sg, 1, 4);
+  const double s = s01 + __shfl_xor(s01, 2, 4);
+  if (!live || gl != 0) return;
+  const int NACC = 2 * g.NP2;
+  if (t < g.TG * NACC) {
+    const int tile = t / NACC, x = t - tile * NACC;      // x = 2 tp + par
+    const int grow = tile * 16 + rit;
+    const int qc = grow / d.R, row = grow - qc * d.R;
+    const int col = 32 * (x >> 1) + 2 * cit + (x & 1);
+    if (qc < c0.nch && col < d.LG) {
+      const size_t off = (size_t)qc * c0.chain_bytes;
+      ptr_shift(c0.H, off)[(size_t)row * d.LG + col] = s;
+      const int dd = col / d.P, p0 = col - dd * d.P, W = 2 * d.BW + 2;
+      double* h2 = ptr_shift(c0.H2, off) + (size_t)row * d.P * W;
+      h2[h2_index(d.P, p0, d.BW + dd)] = s;
+      if (dd > 0 && p0 + dd < d.P) h2[h2_index(d.P, p0 + dd, d.BW - dd)] = s;
+    }
+  } else {
+    const int t2 = t - g.TG * NACC;
+    const int tile = t2 >> 1, par = t2 & 1;
+    const int grow = tile * 16 + rit;
+    const int qc = grow / d.A, a = grow - qc * d.A;
+    const int p = 2 * cit + par;
+    if (qc < c0.nch && p < d.P) ptr_shift(c0.tvec, (size_t)qc * c0.chain_bytes)[(size_t)a * d.P + p] = s;
   }
 }
 
@@ -1692,6 +1955,40 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   if (c.nch > 1 && G > 1) hipLaunchKernelGGL((k_pair_gram<true, true>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
   else if (c.nch > 1) hipLaunchKernelGGL((k_pair_gram<true, false>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
   else hipLaunchKernelGGL((k_pair_gram<false, false>), dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
+}
+
+// geometry of k_pair_gram_pack for this (sub-)batch; returns false when the shape is outside its limits (the caller keeps k_pair_gram)
+size_t pgp_lds_bytes(const PgPack& g) {
+  const size_t lg = 2 * (16 * (size_t)PGP_RB + (size_t)g.NQG * 16 * g.SLS), ls = 2 * (16 * (size_t)PGP_RB + (size_t)g.NQS * 16 * g.SLS);
+  return std::max(lg, ls) * sizeof(double);
+}
+bool pgp_geometry(const Dims& d, int nch, int KS, int NKS, PgPack& g) {
+  if (d.mv || d.D > 0 || d.K > 4 || d.MD - 1 > 8 || d.P > 32 || (d.LREC & 1) || (KS & 15)) return false;
+  g.KS = KS; g.NKS = NKS;
+  g.NP2 = (d.LG + 31) / 32;
+  g.TG = (nch * d.R + 15) / 16; g.TS = (nch * d.A + 15) / 16;
+  const char* ew = getenv("BFMMM_PGP_WAVES");
+  g.WPG = (ew && atoi(ew) == 8) ? 8 : (ew && atoi(ew) == 2) ? 2 : 4;
+  const int PGP_WAVES = g.WPG, PGP_THREADS = 64 * g.WPG;
+  g.NRG = (g.TG + PGP_WAVES - 1) / PGP_WAVES; g.NCG = (g.NP2 + 1) / 2; g.NWG_S = (g.TS + PGP_WAVES - 1) / PGP_WAVES;
+  g.SLG = (d.NZZ + d.NCC + 1 + 1) & ~1; g.SLS = (d.K + d.MD + 1 + 1) & ~1;
+  g.NQG = std::min(nch, (PGP_WAVES * 16 + d.R - 2) / d.R + 1); g.NQS = std::min(nch, (PGP_WAVES * 16 + d.A - 2) / d.A + 1);
+  g.NTP = g.TG * 2 * g.NP2 + g.TS * 2;
+  const int NV = d.K + d.MD - 1;
+  if (std::max(g.NQG, g.NQS) * NV * 16 > PGP_NWV * PGP_THREADS) return false;      // weight values a thread stages per chunk
+  return pgp_lds_bytes(g) <= 64 * 1024;
+}
+size_t pgp_pack_doubles(const PgPack& g) { return (size_t)g.NKS * g.NTP * 256; }
+
+void launch_pair_gram_pack(const Ctx& c, const PgPack& g, double* pack, hipStream_t st) {
+  const dim3 grid(g.NRG * g.NCG + g.NWG_S, g.NKS, 1);
+  switch (g.WPG) {
+    case 8: hipLaunchKernelGGL(k_pair_gram_pack<8>, grid, dim3(512), pgp_lds_bytes(g), st, c, g, pack); break;
+    case 2: hipLaunchKernelGGL(k_pair_gram_pack<2>, grid, dim3(128), pgp_lds_bytes(g), st, c, g, pack); break;
+    default: hipLaunchKernelGGL(k_pair_gram_pack<4>, grid, dim3(256), pgp_lds_bytes(g), st, c, g, pack); break;
+  }
+  const int nblk_red = (g.NTP * 256 * 4 + 255) / 256;
+  hipLaunchKernelGGL(k_pg_reduce_pack, dim3(c.nch + nblk_red), dim3(256), PI_ALPHA_LDS_DOUBLES * sizeof(double), st, c, g, pack);
 }
 
 void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st) {

@@ -188,6 +188,19 @@ struct Ctx {
   int nblk_curve;
 };
 
+// geometry of k_pair_gram_pack (kernels_sweep.hip), the pair-Gram kernel of chain batches and long curve sets
+struct PgPack {
+  int KS, NKS;           // curves per k-slice (a multiple of 16), slices
+  int TG, TS;            // packed row tiles: pair rows (nch R), single-weight rows (nch A)
+  int NRG, NCG, NWG_S;   // G workgroups per slice: NRG row groups (WPG pair tiles each) x NCG column groups (2 column pairs
+                         // = 64 record columns each); s workgroups per slice (WPG single tiles each)
+  int SLG, SLS;          // doubles per (chain, curve) of the pair-weight table (NZZ + NCC + 1, even) / the raw table (K + MD + 1, even)
+  int NQG, NQS;          // most chains a G / an s workgroup stages
+  int WPG;               // waves (= packed row tiles) per workgroup
+  int NTP;               // output tiles per slice: TG 2 NP2 + TS 2
+  int NP2;               // 32-column pairs of the G part
+};
+
 // per-chain pointers of Ctx (everything but the shared data rec, ni, Pmat, X)
 #define BFMMM_CHAIN_PTRS(X_)                                                                                         \
   X_(dyn) X_(Z) X_(chi) X_(theta) X_(delta) X_(Aa) X_(gamma) X_(logz_part) X_(rss_part) X_(pg_part) X_(H) X_(H2)       \
