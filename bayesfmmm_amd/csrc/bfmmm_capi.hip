@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -297,7 +298,6 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   h->T = cfg->tot_mcmc_iters;
   h->nch = n_chains;
   HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->evA));
   HIPCHK(hipEventCreate(&h->evB));
   HIPCHK(hipEventCreate(&h->evC));
@@ -818,6 +818,13 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
 static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
                     int phi_chi_zero, double beta, uint32_t tt_step, bool prepare_only = false) {
   if (!h) return fail("bfmmm_run: null handle");
+  // BFMMM_TRACE_RUN=1: host-side time stamps of the phases of a call (diagnostic: where the fixed cost of a short run goes)
+  static const bool trace_run = getenv("BFMMM_TRACE_RUN") && atoi(getenv("BFMMM_TRACE_RUN")) != 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto tmark = [&](const char* what) {
+    if (trace_run && !prepare_only)
+      fprintf(stderr, "[bfmmm_run] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   if (n_iters < 0 || first_iter < h->slot_base || first_iter - h->slot_base + n_iters > h->T)
     return fail("bfmmm_run: iterations exceed the allocated chain");
   HIPCHK(hipSetDevice(h->device));
@@ -828,12 +835,24 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   int NTG, NKS, KS;
   pg_geometry(c.d, NTG, NKS, KS);
   if ((size_t)NKS * c.d.NT * 256 > h->pg_part_doubles) return fail("bfmmm_run: internal workspace too small");
+  // Long curve sets (beyond the cache-resident sizes): k_pair_gram's k-slices are capped by its LDS staging (192 curves), so at
+  // n = 262144 it writes 1366 slabs of partial tiles -- as many bytes as the records themselves.  k_pair_gram_pack walks a slice of
+  // ANY length in 16-curve chunks with persistent accumulators: about 128 slices whatever n, chosen from n alone so that a chain
+  // of a batch and the same chain alone sum in the same order.
+  bool long_set = false;
+  {
+    const char* e = getenv("BFMMM_PG_PACK");
+    PgPack gt;
+    const int KSb = ((c.d.n + 127) / 128 + 15) / 16 * 16, NKSb = (c.d.n + KSb - 1) / KSb;
+    if (c.d.n > 16384 && !(e && atoi(e) == 0) && pgp_geometry(c.d, 1, KSb, NKSb, gt)) { long_set = true; KS = KSb; NKS = NKSb; }
+  }
   Plan plan = make_plan(mask, MD);
   if (c.d.D > 0) { plan.z = true; plan.chi = true; plan.use_rss_part = 1; }
   // pair-Gram through k_pair_gram_pack: batches of four or more chains with at least two row tiles per chain (BFMMM_PG_PACK=0 / 1
   // switches it off / forces it wherever its limits allow -- both kernels sum in the same order, the results are bit-identical)
   auto want_pack = [&](int cnt) {
     const char* e = getenv("BFMMM_PG_PACK");
+    if (long_set) return true;
     if (e) return atoi(e) != 0;
     return cnt >= 4 && c.d.RT >= 2;
   };
@@ -864,6 +883,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     h->state_dirty = false;
     for (int f = 0; f < FAM_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_launches[f] = 0; }
     HIPCHK(hipEventRecord(h->ev0, h->st));
+    tmark("run_begin queued");
   }
   if (h->profile && prepare_only) return 0;
   if (h->profile) {
@@ -965,7 +985,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
         if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gR, sb.st));
       } else {
         launch_curve(sb.c, 0, plan.z_update, sb.st);              // Z of the first iteration
-        for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gFN, sb.st));
+        tmark("first Z queued");
+        for (int q = 0; q < nfull; ++q) { HIPCHK(hipGraphLaunch(*sb.gFN, sb.st)); tmark("graph (full) queued"); }
         if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gFR, sb.st));
         HIPCHK(hipGraphLaunch(*sb.gL, sb.st));
       }
@@ -982,7 +1003,9 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   // the chains' status words: one strided copy queued behind the run
   HIPCHK(hipMemcpy2DAsync(h->status_host, sizeof(uint32_t), &h->c.dyn->status, h->nch > 1 ? h->c.chain_bytes : sizeof(uint32_t), sizeof(uint32_t),
                           (size_t)h->nch, hipMemcpyDeviceToHost, h->st));
+  tmark("all queued");
   HIPCHK(hipStreamSynchronize(h->st));
+  tmark("synchronised");
   if (h->launch_error) { h->launch_error = 0; return fail("bfmmm_run: problem size exceeds the sweep kernel's LDS (5 A P doubles + A^2 ints must fit 160 KB)"); }
   HIPCHK(hipGetLastError());
   float ms = 0;

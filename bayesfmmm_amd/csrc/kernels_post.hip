@@ -35,10 +35,10 @@ namespace {
 constexpr int NJ = 4;            // observations per thread: n_i <= 1024
 constexpr int GMAX = 32;         // draws per tile
 constexpr int BL_MAX = 1536;     // doubles of basis-row windows staged per curve
-constexpr int WMAX = 20;         // K + M + 2 <= 20
+constexpr int WMAX = 26;         // K + M + 2 <= 26: the sampler's K <= 8, n_eigen <= 16
 constexpr int NG = 8;            // draws per thread in the fitted-value phase
 constexpr int KMAXP = 16;         // K <= 16 in the CPO tile tables
-constexpr int NWR = 3;           // prefetch registers: GMAX (K + M + 1) <= 768 items per tile
+constexpr int NWR = 4;           // prefetch registers: GMAX (K + M + 1) <= 1024 items per tile
 
 struct PostDev {
   int n, K, P, M, D, T, first_kept, tchunk;
@@ -240,12 +240,19 @@ __global__ __launch_bounds__(256) void k_post_reduce(PostDev a, int NCH, double*
 // (3) thread (draw, sum q, segment): the sums r'r, U'r, U'U over a quarter of the observations, fixed order; (4) thread
 // (draw): M x M Cholesky, the draw's log-density -> cpo_ll[i][t].  k_post_cpo_reduce then takes the harmonic mean in the
 // reference's stabilised form (:381-386).  No Z_ik == 0 skip here: the reference's loop has none.
-constexpr int CPO_MMAX = 8;
-constexpr int CPO_TILE = 3072;     // doubles of the U tile (draws x (M + 1) x padded observations)
-constexpr int CPO_VT = 1024;       // doubles of the coefficient tile (draws x (M + 1) x P)
-constexpr int CPO_NQ = CPO_MMAX * (CPO_MMAX + 1) / 2 + CPO_MMAX + 1;
+constexpr int CPO_MREG = 8;        // M <= 8: the M x M system of a draw lives in registers (unrolled); 9 <= M <= 16: in LDS
+constexpr int CPO_MMAX = 16;       // the sampler's n_eigen limit
+constexpr int CPO_GMAX = 16;       // most draws of a tile
+constexpr int CPO_LDS_BUDGET = 17000;      // doubles of the per-draw tiles (133 KB of the 160 KB)
 
-__global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
+// per-draw LDS doubles: coefficient tile (M + 1) x CS, U tile (M + 1) x NIP, segment sums NQ x 4, the LDS system of M > 8
+__host__ __device__ inline int cpo_draw_doubles(int M, int CS, int NIP) {
+  const int M1 = M + 1, NQ = M * (M + 1) / 2 + M + 1;
+  return M1 * CS + M1 * NIP + NQ * 4 + ((M > CPO_MREG) ? M * M + M : 0);
+}
+
+// G: draws per tile, chosen on the host for the longest curve (NIPX = its padded length)
+__global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll, int G, int NIPX) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int i = blockIdx.x, tid = threadIdx.x;
   const long long o = a.off[i];
@@ -254,14 +261,13 @@ __global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
   const int M1 = M + 1, NQ = M * (M + 1) / 2 + M + 1;
   const int NIP = (ni + 3) & ~3;                       // observations padded to four segments
   const int CS = P | 1, WS = W | 1;
-  int G = min(min(CPO_TILE / (M1 * max(NIP, 1)), CPO_VT / (M1 * CS)), 16);
-  G = max(G, 1);
   const bool staged = (size_t)ni * WS <= BL_MAX;
   double* sV = sm;                          // G x M1 x CS
-  double* sU = sV + CPO_VT;                 // G x M1 x NIP  (row 0: the residual)
-  double* sP = sU + CPO_TILE;               // G x NQ x 4 segment sums
-  double* sW = sP + 16 * CPO_NQ * 4;        // G x (K + 1): Z_i.(t), sigma^2(t)
-  double* sB = sW + 16 * (KMAXP + 1);       // BL_MAX
+  double* sU = sV + G * M1 * CS;            // G x M1 x NIPX  (row 0: the residual)
+  double* sP = sU + G * M1 * NIPX;          // G x NQ x 4 segment sums
+  double* sA = sP + G * NQ * 4;             // G x (M x M + M): the system of a draw when M > 8
+  double* sW = sA + ((M > CPO_MREG) ? G * (M * M + M) : 0);        // G x (K + 1): Z_i.(t), sigma^2(t)
+  double* sB = sW + CPO_GMAX * (KMAXP + 1); // BL_MAX
   double* sX = sB + BL_MAX;                 // 8
   if (staged)
     for (int e = tid; e < ni * W; e += 256) { const int j = e / W, w = e - j * W; sB[j * WS + w] = a.Bc[(size_t)(o + j) * W + w]; }
@@ -295,10 +301,10 @@ __global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
         for (int mt = 0; mt < M1; ++mt) {
           const double* cg = sV + (g * M1 + mt) * CS + st;
           const double f = staged ? window_dot_lds(sB + j * WS, cg, W) : window_dot(a.Bc + (size_t)(o + j) * W, cg, W);
-          sU[(g * M1 + mt) * NIP + j] = (mt == 0) ? a.y[o + j] - f : f;
+          sU[(g * M1 + mt) * NIPX + j] = (mt == 0) ? a.y[o + j] - f : f;
         }
       } else {
-        for (int mt = 0; mt < M1; ++mt) sU[(g * M1 + mt) * NIP + j] = 0.0;
+        for (int mt = 0; mt < M1; ++mt) sU[(g * M1 + mt) * NIPX + j] = 0.0;
       }
     }
     __syncthreads();
@@ -308,51 +314,78 @@ __global__ __launch_bounds__(256) void k_post_cpo(PostDev a, double* cpo_ll) {
       int ra = 0, rb = 0;
       if (q >= 1 && q <= M) ra = q;
       else if (q > M) { int m1 = 0, rem = q - M - 1; while (rem >= M - m1) { rem -= M - m1; ++m1; } ra = m1 + 1; rb = m1 + 1 + rem; }
-      const double* ua = sU + (g * M1 + ra) * NIP + seg * (NIP >> 2);
-      const double* ub = sU + (g * M1 + rb) * NIP + seg * (NIP >> 2);
+      const double* ua = sU + (g * M1 + ra) * NIPX + seg * (NIP >> 2);
+      const double* ub = sU + (g * M1 + rb) * NIPX + seg * (NIP >> 2);
       double s_ = 0.0;
       for (int j = 0; j < (NIP >> 2); ++j) s_ += ua[j] * ub[j];
-      sP[(g * CPO_NQ + q) * 4 + seg] = s_;
+      sP[(g * NQ + q) * 4 + seg] = s_;
     }
     __syncthreads();
     // (4) the draw's marginal log-density from the M x M system
     if (tid < gn) {
       const int g = tid, t = tb + g;
       const double sig = sW[g * (KMAXP + 1) + K];
-      auto sum4 = [&](int q) { const double* p4 = sP + (g * CPO_NQ + q) * 4; return (p4[0] + p4[1]) + (p4[2] + p4[3]); };
-      double A[CPO_MMAX][CPO_MMAX], b[CPO_MMAX];
+      auto sum4 = [&](int q) { const double* p4 = sP + (g * NQ + q) * 4; return (p4[0] + p4[1]) + (p4[2] + p4[3]); };
       const double rr = sum4(0);
-      int q = M + 1;
-#pragma unroll
-      for (int m1 = 0; m1 < CPO_MMAX; ++m1) {
-        b[m1] = (m1 < M) ? sum4(1 + m1) : 0.0;
-#pragma unroll
-        for (int m2 = 0; m2 < CPO_MMAX; ++m2)
-          if (m2 >= m1) { A[m1][m2] = (m1 < M && m2 < M) ? sum4(q) + ((m1 == m2) ? sig : 0.0) : ((m1 == m2) ? 1.0 : 0.0); if (m1 < M && m2 < M) ++q; }
-      }
-      // Cholesky A = L L' (lower in A[m2][m1], m2 >= m1), forward solve L w = b: log det = 2 sum log L_mm, b' A^-1 b = w'w
       double logdet = 0.0, ww = 0.0;
+      if (M <= CPO_MREG) {
+        double A[CPO_MREG][CPO_MREG], b[CPO_MREG];
+        int q = M + 1;
 #pragma unroll
-      for (int c = 0; c < CPO_MMAX; ++c) {
-        double dg = A[c][c];
+        for (int m1 = 0; m1 < CPO_MREG; ++m1) {
+          b[m1] = (m1 < M) ? sum4(1 + m1) : 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) dg -= A[c][k2] * A[c][k2];
-        const double l = sqrt(dg);
-        A[c][c] = l;
-        double wv = b[c];
+          for (int m2 = 0; m2 < CPO_MREG; ++m2)
+            if (m2 >= m1) { A[m1][m2] = (m1 < M && m2 < M) ? sum4(q) + ((m1 == m2) ? sig : 0.0) : ((m1 == m2) ? 1.0 : 0.0); if (m1 < M && m2 < M) ++q; }
+        }
+        // Cholesky A = L L' (lower in A[m2][m1], m2 >= m1), forward solve L w = b: log det = 2 sum log L_mm, b' A^-1 b = w'w
 #pragma unroll
-        for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) wv -= A[c][k2] * b[k2];
-        wv /= l;
-        b[c] = wv;
-        if (c < M) { logdet += 2.0 * log(l); ww += wv * wv; }
+        for (int c = 0; c < CPO_MREG; ++c) {
+          double dg = A[c][c];
 #pragma unroll
-        for (int r3 = 0; r3 < CPO_MMAX; ++r3)
-          if (r3 > c) {
-            double v = A[c][r3];                 // upper entry (c, r3) holds the symmetric value
+          for (int k2 = 0; k2 < CPO_MREG; ++k2) if (k2 < c) dg -= A[c][k2] * A[c][k2];
+          const double l = sqrt(dg);
+          A[c][c] = l;
+          double wv = b[c];
 #pragma unroll
-            for (int k2 = 0; k2 < CPO_MMAX; ++k2) if (k2 < c) v -= A[r3][k2] * A[c][k2];
-            A[r3][c] = v / l;
+          for (int k2 = 0; k2 < CPO_MREG; ++k2) if (k2 < c) wv -= A[c][k2] * b[k2];
+          wv /= l;
+          b[c] = wv;
+          if (c < M) { logdet += 2.0 * log(l); ww += wv * wv; }
+#pragma unroll
+          for (int r3 = 0; r3 < CPO_MREG; ++r3)
+            if (r3 > c) {
+              double v = A[c][r3];                 // upper entry (c, r3) holds the symmetric value
+#pragma unroll
+              for (int k2 = 0; k2 < CPO_MREG; ++k2) if (k2 < c) v -= A[r3][k2] * A[c][k2];
+              A[r3][c] = v / l;
+            }
+        }
+      } else {
+        // the same elimination, same order of operations, on a system kept in LDS (9 <= M <= 16: 256 doubles do not fit registers)
+        double* A = sA + g * (M * M + M);     // A[r * M + c]
+        double* b = A + M * M;
+        int q = M + 1;
+        for (int m1 = 0; m1 < M; ++m1) {
+          b[m1] = sum4(1 + m1);
+          for (int m2 = m1; m2 < M; ++m2) { A[m1 * M + m2] = sum4(q) + ((m1 == m2) ? sig : 0.0); ++q; }
+        }
+        for (int c = 0; c < M; ++c) {
+          double dg = A[c * M + c];
+          for (int k2 = 0; k2 < c; ++k2) dg -= A[c * M + k2] * A[c * M + k2];
+          const double l = sqrt(dg);
+          A[c * M + c] = l;
+          double wv = b[c];
+          for (int k2 = 0; k2 < c; ++k2) wv -= A[c * M + k2] * b[k2];
+          wv /= l;
+          b[c] = wv;
+          logdet += 2.0 * log(l); ww += wv * wv;
+          for (int r3 = c + 1; r3 < M; ++r3) {
+            double v = A[c * M + r3];
+            for (int k2 = 0; k2 < c; ++k2) v -= A[r3 * M + k2] * A[c * M + k2];
+            A[r3 * M + c] = v / l;
           }
+        }
       }
       const double ld = (double)(ni - M) * log(sig) + logdet;
       const double quad = (rr - ww) / sig;
@@ -442,7 +475,7 @@ static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* lli
   if (n < 1 || K < 1 || P < 1 || M < 0 || T < 1 || first_kept < 0 || first_kept >= T)
     return bfmmm_io_fail("bfmmm_post_pointwise: bad dimensions");
   if ((double)T * K * (M + 1) * P * std::max(D, 1) >= 5.0e8) return bfmmm_io_fail("bfmmm_post_pointwise: too many draws for one call (32-bit offsets into the parameter table): split the draws");
-  if (P > 64 || K + M + 2 > WMAX || D > 8) return bfmmm_io_fail("bfmmm_post_pointwise: P <= 64, K + M <= 18 and D <= 8 in this build");
+  if (P > 64 || K + M + 2 > WMAX || D > 8) return bfmmm_io_fail("bfmmm_post_pointwise: P <= 64, K + M <= 24 and D <= 8 in this build");
   const long long n_obs = in->offsets[n];
   for (int i = 0; i < n; ++i)
     if (in->offsets[i + 1] - in->offsets[i] > 256 * NJ)
@@ -517,19 +550,22 @@ static int post_impl(const bfmmm_post_input* in, int32_t first_kept, double* lli
   if (ok && D > 0) ok = db.put((double**)&a.X, in->X, (size_t)n * D) && db.put((double**)&a.thetaX, thetaX.data(), thetaX.size());
   if (!ok) { (void)hipGetLastError(); return bfmmm_io_fail("bfmmm_post_pointwise: device allocation or copy failed"); }
   if (cpo) {
-    if (M < 1 || M > CPO_MMAX || K > KMAXP) return bfmmm_io_fail("bfmmm_post_cpo: 1 <= M <= 8 and K <= 16 in this build");
-    for (int i = 0; i < n; ++i)
-      if ((M + 1) * ((in->offsets[i + 1] - in->offsets[i] + 3) & ~3LL) > CPO_TILE)
-        return bfmmm_io_fail("bfmmm_post_cpo: (M + 1) x observations of a curve exceed the on-chip tile in this build");
+    if (M < 1 || M > CPO_MMAX || K > KMAXP) return bfmmm_io_fail("bfmmm_post_cpo: 1 <= M <= 16 and K <= 16 in this build");
+    long long ni_max = 1;
+    for (int i = 0; i < n; ++i) ni_max = std::max<long long>(ni_max, in->offsets[i + 1] - in->offsets[i]);
+    const int NIPX = (int)((ni_max + 3) & ~3LL), CSc = P | 1;
+    const int per_draw = cpo_draw_doubles(M, CSc, NIPX);
+    const int Gc = std::min(CPO_GMAX, CPO_LDS_BUDGET / per_draw);
+    if (Gc < 1) return bfmmm_io_fail("bfmmm_post_cpo: (M + 1) x observations of a curve exceed the on-chip tile in this build");
     double *d_cll, *d_cpo;
     if (!db.put(&d_cll, (const double*)nullptr, (size_t)n * T) || !db.put(&d_cpo, (const double*)nullptr, (size_t)n))
       return bfmmm_io_fail("bfmmm_post_cpo: device allocation failed");
-    const size_t lds_c = ((size_t)CPO_VT + CPO_TILE + 16 * CPO_NQ * 4 + 16 * (KMAXP + 1) + BL_MAX + 8) * sizeof(double);
+    const size_t lds_c = ((size_t)Gc * per_draw + CPO_GMAX * (KMAXP + 1) + BL_MAX + 8 + 8) * sizeof(double);
     (void)hipFuncSetAttribute((const void*)k_post_cpo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
     hipEvent_t c0, c1;
     (void)hipEventCreate(&c0); (void)hipEventCreate(&c1);
     (void)hipEventRecord(c0, 0);
-    hipLaunchKernelGGL(k_post_cpo, dim3(n), dim3(256), lds_c, 0, a, d_cll);
+    hipLaunchKernelGGL(k_post_cpo, dim3(n), dim3(256), lds_c, 0, a, d_cll, Gc, NIPX);
     hipLaunchKernelGGL(k_post_cpo_reduce, dim3((n + 255) / 256), dim3(256), 0, 0, a, d_cll, d_cpo);
     (void)hipEventRecord(c1, 0);
     const bool ran_c = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;

@@ -252,3 +252,47 @@ def test_config2_full_size_warm_batch_of_eight_chains_gram_form():
     finally:
         O.gram_free(g)
     batch.close()
+
+
+def test_long_curve_set_through_the_chunked_contraction():
+    """n_funct = 32768 (beyond the cache-resident sizes: bfmmm_capi.hip routes the pair-Gram contraction of n > 16384 through
+    k_pair_gram_pack -- about 128 k-slices of any length walked in 16-curve chunks with persistent accumulators): 3 warm-start
+    sweeps against the sufficient-statistics form of the oracle (BFMMM.h:1502-1553), then a batch of four chains against the same
+    chains run alone, bit for bit (the slices are chosen from n alone)"""
+    import bayesfmmm_amd as bf
+    from bench import make_config2
+    T = 3
+    w = make_config2(n=32768, n_i=24, seed=3)
+    sim = dict(n=w["n"], K=w["K"], M=w["M"], P=w["P"], nu=w["state"]["nu"], Phi=w["state"]["Phi"], chi=w["state"]["chi"])
+    model = O.Model(w["y"], w["B"], w["K"], w["M"])
+    cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=3, tot_mcmc_iters=T)
+    ch = O.Chain(model, T)
+    generic_state(ch, sim, np.random.default_rng(41))
+    smp = make_sampler(bf, cfg, w)
+    push_state(smp, ch)
+    O.run_warm_gram(model, O.make_hyper(3), ch, seed=6)
+    smp.run(bf.sampler.SWEEP_WARM, T, seed=6)
+    for nm in WARM_NAMES:
+        err = rel_err(smp.get_chain(nm), getattr(ch, ORC_FIELD.get(nm, nm)))
+        assert err < 1e-6, (nm, err)
+    solo_nu, solo_chi = smp.get_chain("nu"), smp.get_chain("chi")
+    smp.close()
+    NCH = 4
+    batch = make_sampler(bf, cfg, w, n_chains=NCH)
+    chains = []
+    for q in range(NCH):
+        chq = O.Chain(model, T)
+        generic_state(chq, sim, np.random.default_rng(41 + q))
+        chains.append(chq)
+        batch.select_chain(q)
+        push_state(batch, chq)
+    batch.run(bf.sampler.SWEEP_WARM, T, seed=6, chain=0)
+    batch.select_chain(0)
+    np.testing.assert_array_equal(batch.get_chain("nu"), solo_nu)
+    np.testing.assert_array_equal(batch.get_chain("chi"), solo_chi)
+    O.run_warm_gram(model, O.make_hyper(3), chains[3], seed=6, chain_id=3)
+    batch.select_chain(3)
+    for nm in WARM_NAMES:
+        err = rel_err(batch.get_chain(nm), getattr(chains[3], ORC_FIELD.get(nm, nm)))
+        assert err < 1e-6, (3, nm, err)
+    batch.close()

@@ -224,3 +224,48 @@ def test_mv_odd_dimension_integer_division_quirk():
         np.testing.assert_allclose(ll, O.post_llik(model, ch), rtol=1e-11)
         dic = api.MVDIC(dirn, 1, Y, burnin_prop=0.25)
         assert abs(dic - O.post_dic(model, ch, 0.25)) < 1e-9 * abs(dic)
+
+
+def test_post_pass_takes_what_the_sampler_can_produce(tmp_path):
+    """The post-processing pass at the sampler's own limits (round 4: K + M <= 24 in the pointwise pass, n_eigen <= 16 in the
+    conditional predictive ordinates; 18 and 8 before): (a) FLLik and the per-observation means with K = 4, M = 16 on random draws
+    (in-memory form), (b) ConditionalPredictiveOrdinates over the batches of a warm-start run with n_eigen = 10 -- the M x M system
+    of a draw then lives in LDS (kernels_post.hip, M > 8) -- against the oracle's dense n_i x n_i form
+    (src/PostProcessing.cpp:4892, :6339; CalculateLikelihood.h:344-389)."""
+    from bayesfmmm_amd import api
+    # (a)
+    rng = np.random.default_rng(12)
+    n, K, M, T = 9, 4, 16, 12
+    t = [np.sort(rng.uniform(0, 1000, size=rng.integers(5, 40))) for _ in range(n)]
+    ik, bk = np.array([250.0, 500.0, 750.0]), np.array([0.0, 1000.0])
+    B = [O.bspline_basis(ti, ik, 3, bk) for ti in t]
+    P = B[0].shape[1]
+    ys = [rng.standard_normal(len(ti)) for ti in t]
+    model = O.Model(ys, B, K, M)
+    ch = O.Chain(model, T)
+    ch.nu[:] = rng.standard_normal(ch.nu.shape)
+    ch.Phi[:] = 0.3 * rng.standard_normal(ch.Phi.shape)
+    ch.Z[:] = rng.dirichlet(np.ones(K), size=(n, T)).transpose(0, 2, 1)
+    ch.chi[:] = rng.standard_normal(ch.chi.shape)
+    ch.sigma[:] = rng.uniform(0.5, 1.5, size=T)
+    ll, pdf, fit = api.post_pointwise(ys, B, ch.nu, ch.Phi, ch.Z, ch.chi, ch.sigma, first_kept=2)
+    np.testing.assert_allclose(ll, O.post_llik(model, ch), rtol=1e-10)
+    i = 3
+    fit_ref = np.array([np.mean([O.lib().orc_fitted(O.C.byref(model.data), O.C.byref(ch.c), tt, i, l) for tt in range(2, T)])
+                        for l in range(len(ys[i]))])
+    np.testing.assert_allclose(fit[i], fit_ref, rtol=1e-10, atol=1e-12)
+    # (b)
+    Tw = 120          # (the entry points require tot_mcmc_iters >= 100: UserFunctions.cpp:198-286)
+    sim = simulate_functional(n=12, M=10, sigma_sq=0.01, seed=31, ragged=True)
+    common = (sim["K"], sim["y"], sim["t"], sim["n"], 3, sim["M"], sim["boundary_knots"], sim["internal_knots"])
+    est1 = api.BFMMM_Nu_Z_multiple_try(Tw, 1, *common, seed=1)
+    est2 = api.BFMMM_Theta_est(Tw, 1, *common, est1, seed=2)
+    d = tmp_path / "trace10"
+    d.mkdir()
+    api.BFMMM_warm_start(Tw, *common, est1, est2, seed=3, dir=str(d) + "/", r_stored_iters=40, thinning_num=1)
+    dirn = str(d) + "/"
+    model2, ch2, _ = _oracle_chain(sim, None, dirn, 3, False)
+    assert ch2.chi.shape[1] == 10
+    args = (dirn, 3, 3, sim["boundary_knots"], sim["internal_knots"], sim["t"], sim["y"])
+    cpo = api.ConditionalPredictiveOrdinates(*args, burnin_prop=0.2)
+    np.testing.assert_allclose(cpo, O.post_cpo(model2, ch2, 0.2), rtol=1e-8, atol=1e-8)
