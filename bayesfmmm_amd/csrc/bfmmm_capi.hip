@@ -93,9 +93,18 @@ struct bfmmm_handle {
   //   fused runs (chi kernel of iteration i also runs the Z update of i + 1): gFN = GRAPH_UNROLL bodies [pair_gram .. chi + Z],
   //   gL = the closing iteration without the Z part;
   //   gR / gFR = the remainder of a run after the unrolled graphs, as ONE graph of rem / remF iterations
-  struct GraphSet { hipGraphExec_t gN = nullptr, gFN = nullptr, gL = nullptr, gR = nullptr, gFR = nullptr; int rem = 0, remF = 0; };
+  //   (one per remainder length, kept: a warm-up run of another length between prepare_run and the run does not evict the run's graph)
+  static constexpr int NREM = 10;        // = GRAPH_UNROLL
+  struct GraphSet {
+    hipGraphExec_t gN = nullptr, gFN = nullptr, gL = nullptr;
+    hipGraphExec_t gR[NREM] = {}, gFR[NREM] = {};
+    template <typename F> void each(F f) { f(&gN); f(&gFN); f(&gL); for (int r = 0; r < NREM; ++r) { f(&gR[r]); f(&gFR[r]); } }
+  };
   static constexpr int MAX_SUB = 4;
   // packed partial tiles of k_pair_gram_pack, one buffer per sub-batch stream (+ one for the whole batch on one stream)
+  // snapshot of the chains' work state for the dry launch of freshly captured graphs (bfmmm_prepare_run)
+  char* dry_snap = nullptr;
+  size_t dry_snap_bytes = 0;
   double* pg_pack[MAX_SUB + 1] = {};
   size_t pg_pack_doubles[MAX_SUB + 1] = {};
   GraphSet gs[MAX_SUB];
@@ -140,6 +149,12 @@ static int dalloc(bfmmm_handle* h, T** p, size_t count) {
 // Per-chain buffers come out of one arena per chain: the requests are collected first, then ONE allocation of
 // nch * stride bytes is made and the pointers of chain 0 are handed out; chain q's copy of every buffer sits q * stride
 // bytes further (Ctx::chain_bytes, chain_ctx in model.hpp).
+static std::vector<hipGraphExec_t*> graph_slots(bfmmm_handle::GraphSet& g) {
+  std::vector<hipGraphExec_t*> v;
+  g.each([&](hipGraphExec_t* p) { v.push_back(p); });
+  return v;
+}
+
 struct ArenaReq { void* slot; size_t bytes; };
 template <typename T>
 static void areq(std::vector<ArenaReq>& v, T** p, size_t count) { v.push_back({(void*)p, std::max<size_t>(count, 1) * sizeof(T)}); }
@@ -484,7 +499,7 @@ extern "C" int bfmmm_set_covariates(bfmmm_handle* h, const double* X, int D, int
     HIPCHK(copy_sync(h, cq.A_xi, ones.data(), sizeof(double) * K * 2 * D, hipMemcpyHostToDevice));
   }
   for (auto& g_ : h->gs)
-    for (hipGraphExec_t* g : {&g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR})
+    for (hipGraphExec_t* g : graph_slots(g_))
       if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   h->g_valid = false;
   return 0;
@@ -495,7 +510,7 @@ extern "C" void bfmmm_destroy(bfmmm_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   for (auto& g_ : h->gs)
-    for (hipGraphExec_t g : {g_.gN, g_.gFN, g_.gL, g_.gR, g_.gFR})
+    for (hipGraphExec_t* gp_ : graph_slots(g_)) if (hipGraphExec_t g = *gp_)
       if (g) (void)hipGraphExecDestroy(g);
   for (int q = 1; q < bfmmm_handle::MAX_SUB; ++q) { if (h->sub_st[q]) (void)hipStreamDestroy(h->sub_st[q]); if (h->sub_ev[q]) (void)hipEventDestroy(h->sub_ev[q]); }
   for (void* p : h->allocs) (void)hipFree(p);
@@ -916,11 +931,11 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub && h->g_pack_mode == pack_mode;
     if (!reuse) {
       for (auto& g_ : h->gs)
-        for (hipGraphExec_t* g : {&g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR})
+        for (hipGraphExec_t* g : graph_slots(g_))
           if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
       h->g_mask = mask; h->g_md = MD; h->g_seed = seed; h->g_chain = chain; h->g_nsub = nsub; h->g_pack_mode = pack_mode; h->g_valid = true;
     }
-    struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; int *rem, *remF; PgPack pk; double* pack; bool use_pack; int slot; };
+    struct Sub { Ctx c; hipStream_t st; hipGraphExec_t *gN, *gFN, *gL, *gR, *gFR; PgPack pk; double* pack; bool use_pack; int slot; };
     Sub subs[bfmmm_handle::MAX_SUB];
     h->sub_st[0] = h->st;
     for (int q = 0, q0 = 0; q < nsub; ++q) {
@@ -928,7 +943,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       if (!h->sub_st[q]) HIPCHK(hipStreamCreateWithFlags(&h->sub_st[q], hipStreamNonBlocking));
       if (!h->sub_ev[q]) HIPCHK(hipEventCreateWithFlags(&h->sub_ev[q], hipEventDisableTiming));
       bfmmm_handle::GraphSet& g_ = h->gs[q];
-      subs[q] = Sub{chain_ctx(c, (unsigned)q0), h->sub_st[q], &g_.gN, &g_.gFN, &g_.gL, &g_.gR, &g_.gFR, &g_.rem, &g_.remF};
+      subs[q] = Sub{chain_ctx(c, (unsigned)q0), h->sub_st[q], &g_.gN, &g_.gFN, &g_.gL, g_.gR, g_.gFR};
       subs[q].c.nch = cnt;
       subs[q].use_pack = pack_for(q, cnt, subs[q].pk, &subs[q].pack) == 0;
       subs[q].slot = q;
@@ -936,6 +951,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     }
     // graphs are captured on demand: kind 0 = full iterations, 1 = fused bodies (no Z in front, chi + next Z at the end),
     // 2 = the closing iteration of a fused run (no Z in front, plain chi)
+    std::vector<std::pair<hipGraphExec_t, hipStream_t>> fresh;      // graphs instantiated by this call
     auto ensure = [&](const Sub& sb, hipGraphExec_t* g, int kind, int reps) -> int {
       if (*g) return 0;
       std::lock_guard<std::mutex> lock(g_capture_mutex);
@@ -948,15 +964,14 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       (void)hipGraphDestroy(graph);
       HIPCHK(ei);
       (void)hipGraphUpload(*g, sb.st);      // (set-up: the first launch of a graph otherwise pays for its upload)
+      fresh.push_back({*g, sb.st});
       return 0;
     };
     // a run of nrep repetitions = nrep / GRAPH_UNROLL replays of the unrolled graph + ONE graph holding the remainder
     // (re-captured only when the remainder changes), so that a short run costs two or three graph launches, not one per iteration
-    auto ensure_rem = [&](const Sub& sb, hipGraphExec_t* g, int* have, int kind, int rem) -> int {
+    auto ensure_rem = [&](const Sub& sb, hipGraphExec_t* garr, int kind, int rem) -> int {
       if (rem <= 0) return 0;
-      if (*g && *have != rem) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
-      *have = rem;
-      return ensure(sb, g, kind, rem);
+      return ensure(sb, &garr[rem], kind, rem);
     };
     const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
     // sweeps whose Z update cannot ride in k_curve_chi (no chi pass: the Nu_Z stage) still run it at the END of the previous
@@ -970,24 +985,60 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     for (int s = 0; s < nsub; ++s) {
       const Sub& sb = subs[s];
       if (!bodies) {
-        if ((nfull > 0 && ensure(sb, sb.gN, 0, GRAPH_UNROLL)) || ensure_rem(sb, sb.gR, sb.rem, 0, rem)) return 1;
+        if ((nfull > 0 && ensure(sb, sb.gN, 0, GRAPH_UNROLL)) || ensure_rem(sb, sb.gR, 0, rem)) return 1;
       } else {
-        if ((nfull > 0 && ensure(sb, sb.gFN, body_kind, GRAPH_UNROLL)) || ensure_rem(sb, sb.gFR, sb.remF, body_kind, rem) || ensure(sb, sb.gL, 2, 1)) return 1;
+        if ((nfull > 0 && ensure(sb, sb.gFN, body_kind, GRAPH_UNROLL)) || ensure_rem(sb, sb.gFR, body_kind, rem) || ensure(sb, sb.gL, 2, 1)) return 1;
       }
     }
-    if (prepare_only) return 0;
+    if (prepare_only) {
+      // DRY LAUNCH (set-up): the first launch of an instantiated graph costs the device 13 - 20 us more than every later one,
+      // upload or not (measured: three fresh graphs = +40 us on a 20-iteration run, tools/gpu/trace_run.py).  So every graph this
+      // call instantiated is launched once here, on the real state, between a snapshot and a restore of the chains' work state
+      // (everything of the per-chain arenas but the chain storage; the slots a dry launch writes are the first slots of the
+      // coming run, which rewrites them).  BFMMM_DRY_LAUNCH=0 switches it off.
+      const char* ed = getenv("BFMMM_DRY_LAUNCH");
+      if (!fresh.empty() && !(ed && atoi(ed) == 0)) {
+        const size_t wb1 = (size_t)((char*)h->c.c_nu - (char*)h->c.dyn);
+        const size_t wb2 = (c.d.D > 0 && h->arena_cov) ? (size_t)((char*)h->c.c_eta - (char*)h->c.thetaX) : 0;
+        const size_t need = (size_t)h->nch * (wb1 + wb2);
+        if (h->dry_snap_bytes < need) {
+          char* nb = nullptr;
+          if (hipMalloc((void**)&nb, need) != hipSuccess) { (void)hipGetLastError(); return 0; }      // (no room: the run's first launch pays)
+          h->allocs.push_back(nb);
+          h->dry_snap = nb; h->dry_snap_bytes = need;
+        }
+        const size_t cb1 = h->nch > 1 ? h->c.chain_bytes : wb1, cb2 = h->nch > 1 ? h->c.chain_bytes_cov : wb2;
+        char* snap2 = h->dry_snap + (size_t)h->nch * wb1;
+        for (int q = 0; q < nsub; ++q) HIPCHK(hipStreamSynchronize(subs[q].st));
+        HIPCHK(hipMemcpy2DAsync(h->dry_snap, wb1, h->c.dyn, cb1, wb1, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
+        if (wb2) HIPCHK(hipMemcpy2DAsync(snap2, wb2, h->c.thetaX, cb2, wb2, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
+        const int64_t tkey = ((int64_t)MD << 32) | (mask & (U_PHI | U_NU));
+        if (h->tab_key != tkey) { launch_sweep_tables(c, h->st); h->tab_key = tkey; }
+        for (auto& fg : fresh) {
+          hipLaunchKernelGGL(k_run_begin, dim3(h->nch), dim3(64), 0, h->st, h->c, (uint32_t)first_iter, (uint32_t)h->slot_base, tt_step, beta, 0);
+          HIPCHK(hipStreamSynchronize(h->st));
+          HIPCHK(hipGraphLaunch(fg.first, fg.second));
+          HIPCHK(hipStreamSynchronize(fg.second));
+        }
+        HIPCHK(hipMemcpy2DAsync(h->c.dyn, cb1, h->dry_snap, wb1, wb1, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
+        if (wb2) HIPCHK(hipMemcpy2DAsync(h->c.thetaX, cb2, snap2, wb2, wb2, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        HIPCHK(hipGetLastError());
+      }
+      return 0;
+    }
     HIPCHK(hipEventRecord(h->ev0, h->st));
     for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(subs[q].st, h->evA, 0)); }      // k_run_begin first
     for (int s = 0; s < nsub; ++s) {
       const Sub& sb = subs[s];
       if (!bodies) {
         for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gN, sb.st));
-        if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gR, sb.st));
+        if (rem > 0) HIPCHK(hipGraphLaunch(sb.gR[rem], sb.st));
       } else {
         launch_curve(sb.c, 0, plan.z_update, sb.st);              // Z of the first iteration
         tmark("first Z queued");
         for (int q = 0; q < nfull; ++q) { HIPCHK(hipGraphLaunch(*sb.gFN, sb.st)); tmark("graph (full) queued"); }
-        if (rem > 0) HIPCHK(hipGraphLaunch(*sb.gFR, sb.st));
+        if (rem > 0) HIPCHK(hipGraphLaunch(sb.gFR[rem], sb.st));
         HIPCHK(hipGraphLaunch(*sb.gL, sb.st));
       }
     }

@@ -38,12 +38,22 @@ __device__ inline double readlane_f64(double v, int lane) {     // lane is wave-
 // (always inlined: out of line the LDS pointers degrade to flat addresses and the recursions run 60 % slower)
 template <int PP, int BWT>
 __device__ __forceinline__ bool factor_wave(double* S, double* X, const double* zv, int P, double* Lz_out, int lane) {
+  // (this wave carries the workgroup's chain of 2 P dependent steps while spare-job workgroups -- gamma rejection loops, lgamma
+  //  series -- share its SIMD: it issues ahead of them)
+  __builtin_amdgcn_s_setprio(3);
+  // Root-free form of the recursion (round 4).  With v(i, k) = U(i, k) U(k, k) (the entries before their division by the pivot's
+  // square root) the reverse Cholesky reads  d_k = Prec(k, k) - sum_m v(k, k + m)^2 / d_{k + m},
+  // v(i, k) = Prec(i, k) - sum_m v(i, k + m) v(k, k + m) / d_{k + m}:  no square root on the chain of P dependent pivots, only
+  // 1 / d_k (hardware estimate + two Newton steps = 4 dependent FMAs instead of rsq + 6), and every lane keeps its diagonal
+  // residual d_i up to date incrementally (one FMA on the chain instead of BWT).  The square roots are taken afterwards, for all
+  // rows at once: U(i, i) = sqrt(d_i), U(i, i + t) = v(i, i + t) / sqrt(d_{i + t}).
   double s[BWT + 1], u[BWT + 1];       // s[t] = Prec(i, i + t),  u[t] = U(i, i + t)
+  double v[BWT + 1], w[BWT + 1];       // v[t] = v(i, i + t),  w[t] = v(i, i + t) / d_{i + t}
 #pragma unroll
   for (int t = 0; t <= BWT; ++t) {
     const int j = lane + t;
     s[t] = (lane < P && j < P) ? S[lane + PP * j] : 0.0;
-    u[t] = 0.0;
+    u[t] = 0.0; v[t] = 0.0; w[t] = 0.0;
   }
   double rinv = 0.0;                   // 1 / U(i, i)
   bool bad = false;
@@ -51,29 +61,44 @@ __device__ __forceinline__ bool factor_wave(double* S, double* X, const double* 
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
   const double thr = 1e-12 * dmax;
-  for (int k = P - 1; k >= 0; --k) {
-    double dloc = s[0];
-#pragma unroll
-    for (int t = 1; t <= BWT; ++t) dloc -= u[t] * u[t];
+  double dloc = s[0];                  // d_i so far: Prec(i, i) minus the terms of the columns already eliminated
+  const int Pu = __builtin_amdgcn_readfirstlane(P);      // (a scalar loop counter: the pivot index feeds v_readlane directly)
+  for (int k = Pu - 1; k >= 0; --k) {
     const double dk = readlane_f64(dloc, k);
     if (!(dk > thr)) bad = true;
-    // 1 / sqrt(dk) from the hardware estimate and two Newton steps (the pivot is on the 30-step dependent chain:
-    // a correctly rounded sqrt followed by a division costs three times as many dependent instructions)
-    double rk = __builtin_amdgcn_rsq(dk);
-    rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
-    rk = rk * (1.5 - (0.5 * dk) * (rk * rk));
-    const double ukk = dk * rk;
-    double uk[BWT + 1];
+    // everything that does not need 1 / d_k first: the rows' v(i, k) and which of them (if any) is this lane's
+    double vk[BWT + 1];
 #pragma unroll
-    for (int m = 1; m < BWT; ++m) uk[m] = readlane_f64(u[m], k);      // U(k, k + m)
+    for (int m = 1; m < BWT; ++m) vk[m] = readlane_f64(v[m], k);      // v(k, k + m)
+    double asel = 0.0;
 #pragma unroll
-    for (int t = 1; t <= BWT; ++t) {   // row i = k - t:  U(i, k) = (Prec(i, k) - sum_m U(i, k + m) U(k, k + m)) / U(k, k)
+    for (int t = BWT; t >= 1; --t) {   // row i = k - t:  v(i, k) = Prec(i, k) - sum_m [v(i, k + m) / d_{k + m}] v(k, k + m)
       double acc = s[t];
 #pragma unroll
-      for (int m = 1; m <= BWT - t; ++m) acc -= u[t + m] * uk[m];
-      if (lane == k - t) u[t] = acc * rk;
+      for (int m = 1; m <= BWT - t; ++m) acc -= w[t + m] * vk[m];
+      const bool mine = lane == k - t;
+      v[t] = mine ? acc : v[t];
+      asel = mine ? acc : asel;
     }
-    if (lane == k) { u[0] = ukk; rinv = rk; }
+    // the chain of dependent pivots: d_k -> 1 / d_k (estimate + two Newton steps) -> w = v / d_k -> d_i -= v w -> d_{k - 1}
+    double inv = __builtin_amdgcn_rcp(dk);
+    inv = fma(fma(-dk, inv, 1.0), inv, inv);
+    inv = fma(fma(-dk, inv, 1.0), inv, inv);
+    const double wsel = asel * inv;
+    dloc = fma(-asel, wsel, dloc);      // (asel = 0 on the lanes without a row of this column)
+    __builtin_amdgcn_sched_barrier(0);  // (the selects below are independent of the chain: they fill the wait of the next v_readlane)
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) w[t] = (lane == k - t) ? wsel : w[t];
+  }
+  {
+    // all rows at once: 1 / sqrt(d_i) (estimate + two Newton steps, as before), U(i, i + t) = v(i, i + t) / sqrt(d_{i + t})
+    const double di = (lane < P) ? dloc : 1.0;
+    double rk = __builtin_amdgcn_rsq(di);
+    rk = rk * (1.5 - (0.5 * di) * (rk * rk));
+    rk = rk * (1.5 - (0.5 * di) * (rk * rk));
+    u[0] = di * rk; rinv = rk;
+#pragma unroll
+    for (int t = 1; t <= BWT; ++t) u[t] = v[t] * __shfl_down(rk, t, 64);      // (v is zero where i + t >= P)
   }
   FCT(0);
   // column `lane` of X = U^-1 by back substitution; xw[t] = X(i + t, lane).  Row i of U (its band, 1 / U(i,i)) and
@@ -104,7 +129,7 @@ __device__ __forceinline__ bool factor_wave(double* S, double* X, const double* 
     for (int t = 0; t < BS; ++t) nxt[t] = bc[ip * BS + t];
     double acc = 0.0;
 #pragma unroll
-    for (int t = 1; t <= BWT; ++t) acc += cur[t] * xw[t];
+    for (int t = BWT; t >= 1; --t) acc += cur[t] * xw[t];       // (xw[1], the previous row's result, enters last: one FMA on the chain)
     const double xi = (lane == i) ? cur[0] : ((lane > i) ? -(acc * cur[0]) : 0.0);
     if (lane < PP) X[i * PP + lane] = xi;
     lzacc += xi * cur[BWT + 1];
@@ -114,6 +139,7 @@ __device__ __forceinline__ bool factor_wave(double* S, double* X, const double* 
   }
   FCT(1);
   if (lane < P) Lz_out[lane] = lzacc;
+  __builtin_amdgcn_s_setprio(0);
   return bad;
 }
 

@@ -762,26 +762,35 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   const int P = d.P, MD = d.MD, K = d.K, A = d.A, M = d.M;
   constexpr int W = 2 * BW + 2;     // doubles per row of an H2 block: G(p, p - BW .. p + BW), 0
   const int tid = threadIdx.x;
-  if (bx >= A) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
+  // Two workgroups per direction (round 4; not for the diagonal model, which has no factorisation): workgroup a < A runs the
+  // factorisation of Prec_a -- it needs only H_aa and the prior -- and workgroup A + a forms r_a = t_a - sum_b H_ab theta_b and
+  // H_aa theta_a, which the factorisation does not need: side by side on two CUs instead of one after the other (the r phase
+  // was 2.2 us of the factorisation workgroup's 13).
+  const bool split = !((BW == 0) && d.BWP == 0);
+  const int nF = split ? 2 * A : A;       // first spare job
+  if (bx >= nF) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
     const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int zcw = zprep_curves_per_wg(d.K);
     const int nzp = (c.mask & U_Z) ? (d.n + zcw - 1) / zcw : 0;
 #ifdef BFMMM_TIMELINE
-    const int sb_ = bx - A;       // one workgroup of each kind of spare job: start / end stamps 56 .. 63
+    const int sb_ = bx - nF;       // one workgroup of each kind of spare job: start / end stamps 56 .. 63
     const int kind_ = sb_ < ndraw ? 0 : sb_ < ndraw + nzp ? 1 : (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) ? 2 : 3;
     const bool first_ = (sb_ == 0) || (sb_ == ndraw && nzp > 0) || kind_ == 2 || (kind_ == 3 && sb_ == ndraw + nzp);
     if (first_ && threadIdx.x == 0) c.dyn->stamps[56 + 2 * kind_] = wall_clock64();
 #endif
-    if (bx < A + ndraw) job_hyper_draws(c, (bx - A) * 256);
-    else if (bx < A + ndraw + nzp) job_z_prepare(c, bx - A - ndraw);
+    if (bx < nF + ndraw) job_hyper_draws(c, (bx - nF) * 256);
+    else if (bx < nF + ndraw + nzp) job_z_prepare(c, bx - nF - ndraw);
     else if (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) job_pi_prepare(c);
-    else job_chi_normals(c, bx - A - ndraw - nzp);
+    else job_chi_normals(c, bx - nF - ndraw - nzp);
 #ifdef BFMMM_TIMELINE
     if (first_ && threadIdx.x == 0) c.dyn->stamps[57 + 2 * kind_] = wall_clock64();
 #endif
     return;
   }
-  const int a = bx;
+  const bool role_r = split && bx >= A;      // this workgroup forms r_a, H_aa theta_a (and, without the split, everything)
+  const bool role_f = !role_r;               // this workgroup factorises
+  const bool do_r = role_r || !split;
+  const int a = role_r ? bx - A : bx;
   const int j = a / MD, mt = a - j * MD;
 #ifdef BFMMM_TIMELINE
 #define FST(i) do { if (bx == 1 && threadIdx.x == 0) c.dyn->stamps[48 + (i)] = wall_clock64(); } while (0)
@@ -809,7 +818,9 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   constexpr int MAXI = (BW > 5) ? 1 : 4;          // (b, p) items per thread and pass (wide band: a row is 64 doubles)
   v2d hreg[MAXI][BW + 1];
   double tval[MAXI];
-  {
+  const bool upd_nu0 = (mt == 0) && (c.mask & U_NU), upd_phi0 = (mt > 0) && (c.mask & U_PHI);
+  if (split && role_f && !(upd_nu0 || upd_phi0)) return;      // (a direction that is not sampled needs only its r workgroup)
+  if (do_r) {
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
       const int e = min(tid + 256 * it, AP - 1);
@@ -819,8 +830,14 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
 #pragma unroll
       for (int k = 0; k <= BW; ++k) hreg[it][k] = blk[k * P + p];
     }
+  } else {
+    // factorisation workgroup: row p = tid of H_aa only
+    const v2d* blk = (const v2d*)(c.H2 + (size_t)hrow(d, a, a) * P * W);
+    const int p = min(tid, P - 1);
+#pragma unroll
+    for (int k = 0; k <= BW; ++k) hreg[0][k] = blk[k * P + p];
   }
-  const double tv0 = c.tvec[a * P + min(tid >> 3, P - 1)];      // t_a[p] of the r-reduction's first pass
+  const double tv0 = do_r ? c.tvec[a * P + min(tid >> 3, P - 1)] : 0.0;      // t_a[p] of the r-reduction's first pass
   // prior entries of the band of Prec this thread will build: element (p, p + t), t <= BWP (two per thread at most)
   constexpr int NPRI = (BW > 5) ? ((BWWIDE + 1) * PP + 255) / 256 : 2;
   double pri[NPRI];
@@ -837,8 +854,8 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   const double dlt = (mt > 0 && tid < M) ? c.delta[j + (size_t)K * tid] : 1.0;
   const double f = dyn->beta / dyn->sigma2;
   const double tau_j = dyn->tau[j];
-  for (int x = tid; x < A * PS; x += 256) thp[x] = 0.0;
-  if (upd && tid >= 64 && tid < 64 + P) {     // the direction's normal variates, while the loads are in flight
+  if (do_r) for (int x = tid; x < A * PS; x += 256) thp[x] = 0.0;
+  if (role_f && upd && tid >= 64 && tid < 64 + P) {     // the direction's normal variates, while the loads are in flight
     const RngKey key = make_key(c.seed, c.chain, dyn->iter, dyn->tt_step);
     const uint32_t idx0 = (mt == 0) ? (uint32_t)(j * P) : (uint32_t)((j * M + (mt - 1)) * P);
     zv[tid - 64] = rnorm(key, (mt == 0) ? UPD_NU : UPD_PHI, idx0 + (uint32_t)(tid - 64));
@@ -846,6 +863,16 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   FST(1);
   __syncthreads();
   FST(2);
+  if (!do_r) {
+    // factorisation workgroup of a split launch: the rows of H_aa straight to the precision's work area
+    if (tid < P) {
+#pragma unroll
+      for (int k = 0; k <= BW; ++k) { hb2[tid * W + 2 * k] = hreg[0][k].x; hb2[tid * W + 2 * k + 1] = hreg[0][k].y; }
+    }
+    if (tid < 16) dsc[tid] = dlt;
+    __syncthreads();
+  }
+  if (do_r) {
 #pragma unroll
   for (int it = 0; it < MAXI; ++it) {
     const int e = tid + 256 * it;
@@ -904,7 +931,8 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
     }
   }
   FST(4);
-  if (!upd) return;
+  }      // do_r
+  if (role_r || !upd) return;
   // prior scale: tau_j (nu) or tilde_tau(j, m) = prod_{m' <= m} delta(j, m') (BFMMM.h:1514-1519)
   double tt = 1.0;
   for (int m2 = 0; m2 < mt; ++m2) tt *= dsc[m2];
@@ -2019,7 +2047,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int n_zprep = (c.mask & U_Z) ? (c.d.n + zcw - 1) / zcw : 0;      // (covariate-adjusted models too: the proposal does not see the data)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
   const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // the last workgroup: next iteration's pi / alpha_3 tables
-  const int grid = c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;
+  const int grid = (diag ? 1 : 2) * c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;      // (k_factor: two workgroups per direction)
   if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
   else launch_factor_pp<64>(c, grid, lds, st);
 }

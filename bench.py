@@ -387,13 +387,24 @@ def main():
                             tot_mcmc_iters=max(T, args.profile_steps))
     smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], device=local_rank)
     smp.set_state(**w["state"])
-    smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=rank)
-    smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)   # graph capture is set-up
+    # W warm-up steps, then the set-up of the timed run (bfmmm_prepare_run: graph capture, upload and ONE dry launch of every
+    # freshly instantiated graph between a snapshot and a restore of the chain's state -- the first launch of a graph costs the
+    # device 13 - 20 us more than later ones; measured on one box, us per step of the 20-step form: 63.8 with the dry launch, 65.2
+    # without, 65.6 with the warm-up steps moved behind the set-up: tools/gpu/ab_order.sh)
+    if os.environ.get("BFMMM_BENCH_PREPARE_FIRST"):      # (A/B of the two orders)
+        smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)
+        smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=rank)
+    else:
+        smp.run(bf.SWEEP_WARM, args.warmup, first_iter=0, seed=1, chain=rank)
+        smp.prepare_run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)
     barrier()
     t0 = time.perf_counter()
     smp.run(bf.SWEEP_WARM, args.steps, first_iter=args.warmup, seed=1, chain=rank)
+    t_call = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("BFMMM_BENCH_TRACE"):
+        print(f"[bench] timed region {dt * 1e6:.1f} us: the run call {t_call * 1e6:.1f} us, the closing barrier {(dt - t_call) * 1e6:.1f} us", file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
