@@ -768,6 +768,7 @@ __global__ void k_run_begin(Ctx c0, uint32_t first_iter, uint32_t slot_base, uin
   dyn->ll_pending = 0;
   if (state_dirty) { dyn->zprep_valid = 0; dyn->piprep_valid = 0; }
   dyn->znorm_valid = 0;
+  dyn->pi_done = 0;
 }
 
 // ---- iteration driver -------------------------------------------------------------------------
@@ -807,8 +808,11 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
   mark();
   if (p.z && !skip_z) launch_curve(c, 0, p.z_update, st);
   mark();
-  if (p.pg && pk) {
-    launch_pair_gram_pack(c, *pk, pack, st);      // (contraction + reduction; the pi / alpha_3 job rides in the reduction kernel)
+  const bool packed = p.pg && pk;
+  Ctx cf = c;
+  cf.pi_in_factor = packed ? 1 : 0;      // (the pi / alpha_3 job: an extra workgroup of k_pair_gram, or -- packed path -- of k_factor)
+  if (packed) {
+    launch_pair_gram_pack(c, *pk, pack, st);      // (contraction + reduction)
     mark();
   } else {
     launch_pair_gram(c, p.pg ? 1 : 0, NKS, KS, st);
@@ -816,7 +820,7 @@ static void launch_iteration(bfmmm_handle* h, const Ctx& c, const Plan& p, int N
     if (p.pg) launch_pg_reduce(c, NKS, st);
   }
   mark();
-  if (p.factor) launch_factor(c, st);
+  if (p.factor) launch_factor(cf, st);
   mark();
   if (launch_sweep(c, st)) h->launch_error = 1;
   mark();
@@ -1065,6 +1069,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   h->fam_launches[FAM_TOTAL] = n_iters;
   for (int q = 0; q < h->nch; ++q) {
     const uint32_t status = h->status_host[q];
+    if (status & 8u) return fail("bfmmm_run: internal error (the pi / alpha_3 job of k_factor did not signal)");
     if (status & 4u) return fail("bfmmm_run: internal error (a hand-off inside the sweep kernel timed out)");
     if (status & 2u) return fail("bfmmm_run: internal error (fused Z update without prepared proposals)");
     if (status & 1u)

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   if (valid && do_update) {
     const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == it_cur) & (dh.zprep_tt == dh.tt_step) &
                      (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
-    if (pre) z_proposal_load(c, i, zp);
+    if (pre) z_proposal_load(c, i, zp, alpha3, dyn->pi);
     else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
     else z_proposal<LPC>(c, make_key(c.seed, c.chain, dh.iter, dh.tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
   }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   cv.load(c.rec + (size_t)ic * d.LREC, P, d.LG, lp);
   double zn_pre = c.chi_norm[ic + (size_t)n * min(lp, M - 1)];       // (used only if its tag in Dyn matches)
   ZProposal zp;
-  if (fuse_z) z_proposal_load(c, ic, zp);            // likewise
+  if (fuse_z) z_proposal_load(c, ic, zp, dh.alpha3, dyn->pi);            // likewise
   const double sigma2 = dh.sigma2, beta = dh.beta;
   // ---- now the staged data: theta to LDS, chi to the curve's tile ----
 #pragma unroll

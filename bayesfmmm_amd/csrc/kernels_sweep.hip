@@ -641,18 +641,15 @@ __global__ __launch_bounds__(64 * PGP_WAVES, 4) void k_pair_gram_pack(Ctx c0, Pg
 
 // pi / alpha_3 (+ the deferred log-likelihood) of every chain of the (sub-)batch: in k_pair_gram this job rides as an extra
 // workgroup; inside k_pair_gram_pack it would cost that kernel its register budget (the job needs 177 VGPRs, the contraction 88),
-// so it is the FIRST nch workgroups of the reduction kernel (12 us each, as long as the reduction itself: dispatched first they
-// run beside it; dispatched last they doubled the kernel: 25 us; on a side stream forked and joined inside the captured graph the
-// two cross-stream edges cost the 8-chain batch 80 us per step).
+// so it is a workgroup of the NEXT kernel, k_factor, whose register budget it fits; the spare jobs there that read pi / alpha_3
+// wait for its flag (k_factor: pi_in_factor).  Tried first: as workgroups of the reduction kernel (its 177 VGPRs then set that
+// memory-bound kernel's occupancy: 17.7 us instead of 12 for 8 chains, 59 instead of 40 for 32) and on a side stream forked and
+// joined inside the captured graph (the two cross-stream edges cost the 8-chain batch 80 us per step).
 // fixed-order sum of the k-slices of the packed partial tiles (the order of k_pg_reduce: four interleaved partial sums over the
 // slices, then (s0 + s1) + (s2 + s3)) and scatter to the chains' H, H2, t
 __global__ __launch_bounds__(256) void k_pg_reduce_pack(Ctx c0, PgPack g, const double* __restrict__ pack) {
   const Dims& d = c0.d;
-  if ((int)blockIdx.x < c0.nch) {
-    job_pi_alpha(chain_ctx(c0, blockIdx.x));
-    return;
-  }
-  const int bx = blockIdx.x - c0.nch;
+  const int bx = blockIdx.x;
   const int gid4 = bx * 256 + threadIdx.x;
   const int gid = gid4 >> 2, gl = gid4 & 3;
   const bool live = gid < g.NTP * 256;
@@ -767,7 +764,36 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   // H_aa theta_a, which the factorisation does not need: side by side on two CUs instead of one after the other (the r phase
   // was 2.2 us of the factorisation workgroup's 13).
   const bool split = !((BW == 0) && d.BWP == 0);
-  const int nF = split ? 2 * A : A;       // first spare job
+  const int nF0 = split ? 2 * A : A;       // first spare job
+  if (c.pi_in_factor && bx == nF0) {
+    // The iteration's pi / alpha_3 job (normally an extra workgroup of k_pair_gram; on the packed pair-Gram path of chain
+    // batches it would cost k_pair_gram_pack or its reduction their register budget -- it needs 177 VGPRs, they 88 and 46).  The
+    // one spare job that reads pi / alpha_3 of THIS iteration (job_pi_prepare, one workgroup) waits for it (wait_pi below); the
+    // pi job is dispatched before it (lower workgroup index), so the wait cannot deadlock, and it is bounded anyway.
+    job_pi_alpha(c);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(&c.dyn->pi_done, c.dyn->iter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const int nF = nF0 + (c.pi_in_factor ? 1 : 0);
+  auto wait_pi = [&]() {
+    if (!c.pi_in_factor) return;
+    if (tid == 0) {
+      const uint32_t want = c.dyn->iter + 1u;
+      int spins = 0;
+      // (relaxed polls -- an acquire per poll invalidates the XCD's L2 every time, and four hundred waiting workgroups doing that
+      //  made the kernel four times longer -- and ONE acquire fence once the flag is up)
+      while (__hip_atomic_load(&c.dyn->pi_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(64);
+        if (++spins > (1 << 20)) { atomicOr(&c.dyn->status, 8u); break; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  };
   if (bx >= nF) {       // spare workgroups: the state-independent variates of job_hyper, then next iteration's Z proposals
     const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int zcw = zprep_curves_per_wg(d.K);
@@ -779,8 +805,8 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
     if (first_ && threadIdx.x == 0) c.dyn->stamps[56 + 2 * kind_] = wall_clock64();
 #endif
     if (bx < nF + ndraw) job_hyper_draws(c, (bx - nF) * 256);
-    else if (bx < nF + ndraw + nzp) job_z_prepare(c, bx - nF - ndraw);
-    else if (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) job_pi_prepare(c);
+    else if (bx < nF + ndraw + nzp) job_z_prepare(c, bx - nF - ndraw);      // (does not read pi / alpha_3: z_proposal.hpp)
+    else if (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) { wait_pi(); job_pi_prepare(c); }
     else job_chi_normals(c, bx - nF - ndraw - nzp);
 #ifdef BFMMM_TIMELINE
     if (first_ && threadIdx.x == 0) c.dyn->stamps[57 + 2 * kind_] = wall_clock64();
@@ -2016,7 +2042,7 @@ void launch_pair_gram_pack(const Ctx& c, const PgPack& g, double* pack, hipStrea
     default: hipLaunchKernelGGL(k_pair_gram_pack<4>, grid, dim3(256), pgp_lds_bytes(g), st, c, g, pack); break;
   }
   const int nblk_red = (g.NTP * 256 * 4 + 255) / 256;
-  hipLaunchKernelGGL(k_pg_reduce_pack, dim3(c.nch + nblk_red), dim3(256), PI_ALPHA_LDS_DOUBLES * sizeof(double), st, c, g, pack);
+  hipLaunchKernelGGL(k_pg_reduce_pack, dim3(nblk_red), dim3(256), 0, st, c, g, pack);      // (the pi / alpha_3 job: a workgroup of k_factor, Ctx::pi_in_factor)
 }
 
 void launch_pg_reduce(const Ctx& c, int NKS, hipStream_t st) {
@@ -2047,7 +2073,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int n_zprep = (c.mask & U_Z) ? (c.d.n + zcw - 1) / zcw : 0;      // (covariate-adjusted models too: the proposal does not see the data)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
   const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // the last workgroup: next iteration's pi / alpha_3 tables
-  const int grid = (diag ? 1 : 2) * c.d.A + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;      // (k_factor: two workgroups per direction)
+  const int grid = (diag ? 1 : 2) * c.d.A + (c.pi_in_factor ? 1 : 0) + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;      // (k_factor: two workgroups per direction)
   if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
   else launch_factor_pp<64>(c, grid, lds, st);
 }

@@ -61,6 +61,8 @@ struct Dyn {
   double loglik;
   double pi[KMAX];
   double tau[KMAX];
+  uint32_t pi_done;     // iteration + 1 whose pi / alpha_3 job has finished (the job as a workgroup of k_factor: Ctx::pi_in_factor)
+  uint32_t pad_pi_;
   unsigned long long stamps[64];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
 };
 
@@ -168,6 +170,7 @@ struct Ctx {
   double* step_part;            // 2 x NBS x D x P partial sums of w (s_i - g_i) of the current group of directions (two parities)
   double* thetaN;               // as thetaX: the values drawn in this iteration's eta / Xi steps (committed by k_cov_hyper)
   double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
+  int pi_in_factor;             // the pi / alpha_3 job of the iteration is a workgroup of k_factor (batches on the packed pair-Gram path)
   int defer_loglik;             // the iteration has no k_loglik: bookkeeping in job_hyper, reduction in the next k_pair_gram
   int ll_use_part;              // (deferred) log-likelihood from the per-curve residual partial sums
   int covariance_adj;           // Xi block on (BFMMM.h:4602 vs :4067)

@@ -21,9 +21,12 @@ struct ZProposal {
 };
 constexpr int ZPREP_FIELDS_PER_K = 3, ZPREP_SCALARS = 5;      // layout of Ctx::zprep: field f of curve i at [f * n + i]
 
+// with_prior = false (job_z_prepare): the prior terms pr_old / pr_new are left at zero and pi / alpha_3 are not read -- the
+// consumer forms them from lo / ln when it loads the proposal (z_proposal_load), so that the job does not depend on this
+// iteration's pi / alpha_3 update and can run beside it.
 template <int GW>
 __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl, const double (&Zold)[KMAX],
-                                  double alpha3, const double* pi, ZProposal& out) {
+                                  double alpha3, const double* pi, ZProposal& out, bool with_prior = true) {
   const int K = c.d.K;
   double a_old[KMAX];
 #pragma unroll
@@ -101,8 +104,10 @@ __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl
     if (k < K) {
       const double lo = __shfl(lgz, k, GW), ln = __shfl(lgz, K + k, GW);
       out.lo[k] = lo; out.ln[k] = ln;
-      pr_old += (alpha3 * pi[k] - 1.0) * lo;
-      pr_new += (alpha3 * pi[k] - 1.0) * ln;
+      if (with_prior) {
+        pr_old += (alpha3 * pi[k] - 1.0) * lo;
+        pr_new += (alpha3 * pi[k] - 1.0) * ln;
+      }
       dn += (a_old[k] - 1.0) * ln;       // density of proposing new from old
       dold += (a_new[k] - 1.0) * lo;     // density of proposing old from new
     }
@@ -114,8 +119,9 @@ __device__ inline void z_proposal(const Ctx& c, const RngKey& key, int i, int gl
 
 // Spare workgroups of k_factor (iteration t): the proposals of iteration t + 1 for 256 / GW curves each (GW lanes per curve:
 // 8 when 2K + 1 <= 8, 16 when 2K + 1 <= 16, else 32 -- zprep_lanes).
-// Z, pi and alpha_3 are final for iteration t by then (k_curve_z and the pi / alpha_3 job ran before k_factor), and the
-// keyed RNG makes the variates a function of (seed, chain, t + 1) alone.  k_curve_z checks the tag before using them.
+// Z is final for iteration t by then (k_curve_z ran before k_factor), and the keyed RNG makes the variates a function of
+// (seed, chain, t + 1) alone; the prior terms, which need iteration t's pi / alpha_3, are added by the consumer
+// (z_proposal_load).  k_curve_z checks the tag before using a prepared proposal.
 __host__ __device__ inline int zprep_lanes(int K) { return (2 * K + 1 <= 8) ? 8 : (2 * K + 1 <= 16) ? 16 : 32; }
 
 template <int GW>
@@ -134,7 +140,7 @@ __device__ inline void job_z_prepare_gw(const Ctx& c, int wg) {
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) Zold[k] = (k < K) ? c.Z[i + (size_t)n * k] : 0.0;
   ZProposal zp;
-  z_proposal<GW>(c, key, i, gl, Zold, dyn->alpha3, dyn->pi, zp);
+  z_proposal<GW>(c, key, i, gl, Zold, 0.0, nullptr, zp, false);
   double* o = c.zprep + i;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
@@ -167,8 +173,9 @@ __device__ inline void job_chi_normals(const Ctx& c, int wg) {
   c.chi_norm[i + (size_t)d.n * m] = rnorm(make_key(c.seed, c.chain, dyn->iter, dyn->tt_step), UPD_CHI, (uint32_t)e);
 }
 
-// reads a prepared proposal back (every lane of the curve's group gets all of it)
-__device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp) {
+// reads a prepared proposal back (every lane of the curve's group gets all of it) and adds the prior terms
+// sum_k (alpha_3 pi_k - 1) log Z_k of lpdf_z (UpdateMixedMembership.h:20-50) for the current pi / alpha_3
+__device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp, double alpha3, const double* pi) {
   const int n = c.d.n, K = c.d.K;
   const double* o = c.zprep + i;
 #pragma unroll
@@ -180,7 +187,18 @@ __device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp) {
     zp.ln[k] = (k < K) ? e : 0.0;
   }
   const double* s = o + (size_t)n * 3 * K;
-  zp.pr_old = s[0]; zp.pr_new = s[n]; zp.lpn = s[(size_t)2 * n]; zp.lpo = s[(size_t)3 * n]; zp.log_uu = s[(size_t)4 * n];
+  zp.lpn = s[(size_t)2 * n]; zp.lpo = s[(size_t)3 * n]; zp.log_uu = s[(size_t)4 * n];
+  double piv[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) piv[k] = pi[min(k, K - 1)];
+  double pr_old = 0.0, pr_new = 0.0;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      pr_old += (alpha3 * piv[k] - 1.0) * zp.lo[k];
+      pr_new += (alpha3 * piv[k] - 1.0) * zp.ln[k];
+    }
+  zp.pr_old = pr_old; zp.pr_new = pr_new;
 }
 
 }  // namespace bfmmm
