@@ -867,13 +867,16 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   }
   Plan plan = make_plan(mask, MD);
   if (c.d.D > 0) { plan.z = true; plan.chi = true; plan.use_rss_part = 1; }
-  // pair-Gram through k_pair_gram_pack: batches of four or more chains with at least two row tiles per chain (BFMMM_PG_PACK=0 / 1
-  // switches it off / forces it wherever its limits allow -- both kernels sum in the same order, the results are bit-identical)
+  // pair-Gram through k_pair_gram_pack: batches of four or more chains -- warm-start and Nu_Z sweeps alike (measured, chain-iterations/s
+  // plain / packed: 4 warm chains 35.3 k / 40.4 k, 6: 44.9 / 46.9; 4 Nu_Z chains 65.0 / 68.3, 6: 84.4 / 92.6, 8: 105 / 114; two chains:
+  // no gain) -- and long curve sets (BFMMM_PG_PACK=0 / 1 switches it off / forces it wherever its limits allow: both kernels sum
+  // in the same order, the results are bit-identical)
   auto want_pack = [&](int cnt) {
     const char* e = getenv("BFMMM_PG_PACK");
     if (long_set) return true;
     if (e) return atoi(e) != 0;
-    return cnt >= 4 && c.d.RT >= 2;
+    (void)cnt;
+    return h->nch >= 4;
   };
   auto pack_for = [&](int slot, int cnt, PgPack& g, double** buf) -> int {      // 0: packed path ready, 1: not applicable, -1: error
     *buf = nullptr;
