@@ -35,7 +35,7 @@ int launch_sweep(const Ctx& c, hipStream_t st);
 void launch_sweep_tables(const Ctx& c, hipStream_t st);
 size_t sweep_tab_ints(int A);
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st);
-void launch_loglik_flush(const Ctx& c, hipStream_t st);
+void launch_loglik_flush(const Ctx& c, hipStream_t st, uint32_t* status_out);
 void launch_fill_slots(const Ctx& c, double* chain, const double* cur, size_t len, int s0, int s1, hipStream_t st);
 void launch_cov_block(const Ctx& c, hipStream_t st);
 int cov_step_blocks(int nblk_curve);
@@ -85,7 +85,8 @@ struct bfmmm_handle {
   std::vector<void*> allocs;
   char* arena = nullptr;               // base of the per-chain arena (chain q at arena + q * c.chain_bytes)
   char* arena_cov = nullptr;           // the same for the covariate buffers (c.chain_bytes_cov)
-  uint32_t* status_host = nullptr;     // pinned: the chains' status words after a run (one asynchronous copy, no extra round trip)
+  uint32_t* status_host = nullptr;     // pinned, host-mapped: the chains' status words after a run
+  uint32_t* status_dev = nullptr;      // its device address (written by the run's last kernel)
   size_t pg_part_doubles = 0;
   // graph cache for the last (mask, md, seed, chain)
   // Captured graphs of a run, one set per SUB-BATCH (run_impl splits a chain batch over up to MAX_SUB streams):
@@ -1021,11 +1022,20 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
         if (wb2) HIPCHK(hipMemcpy2DAsync(snap2, wb2, h->c.thetaX, cb2, wb2, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
         const int64_t tkey = ((int64_t)MD << 32) | (mask & (U_PHI | U_NU));
         if (h->tab_key != tkey) { launch_sweep_tables(c, h->st); h->tab_key = tkey; }
-        for (auto& fg : fresh) {
-          hipLaunchKernelGGL(k_run_begin, dim3(h->nch), dim3(64), 0, h->st, h->c, (uint32_t)first_iter, (uint32_t)h->slot_base, tt_step, beta, 0);
-          HIPCHK(hipStreamSynchronize(h->st));
-          HIPCHK(hipGraphLaunch(fg.first, fg.second));
-          HIPCHK(hipStreamSynchronize(fg.second));
+        // (a few milliseconds of it: the device's clocks keep rising over the first ~5 ms of activity after an idle period -- a
+        //  capture is one --, measured as 1240 -> 1219 -> 1212 -> 1205 us of device time for four consecutive 20-iteration runs;
+        //  BFMMM_DRY_LAUNCH_MS sets the duration, default 10: us per step of the 20-step form 64.6 / 63.7 / 63.1 with one launch / 4 ms / 12 ms)
+        const char* ems = getenv("BFMMM_DRY_LAUNCH_MS");
+        const double want_ms = ems ? atof(ems) : 10.0;
+        const auto t_dry = std::chrono::steady_clock::now();
+        for (int round = 0; round < 64; ++round) {
+          for (auto& fg : fresh) {
+            hipLaunchKernelGGL(k_run_begin, dim3(h->nch), dim3(64), 0, h->st, h->c, (uint32_t)first_iter, (uint32_t)h->slot_base, tt_step, beta, 0);
+            HIPCHK(hipStreamSynchronize(h->st));
+            HIPCHK(hipGraphLaunch(fg.first, fg.second));
+            HIPCHK(hipStreamSynchronize(fg.second));
+          }
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dry).count() >= want_ms) break;
         }
         HIPCHK(hipMemcpy2DAsync(h->c.dyn, cb1, h->dry_snap, wb1, wb1, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
         if (wb2) HIPCHK(hipMemcpy2DAsync(h->c.thetaX, cb2, snap2, wb2, wb2, (size_t)h->nch, hipMemcpyDeviceToDevice, h->st));
@@ -1052,15 +1062,21 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->sub_ev[q], subs[q].st)); HIPCHK(hipStreamWaitEvent(h->st, h->sub_ev[q], 0)); }
   }
   if (prepare_only) return 0;
-  if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st);
+  if (!h->status_host) {
+    HIPCHK(hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * (size_t)h->nch, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&h->status_dev, h->status_host, 0) != hipSuccess) { (void)hipGetLastError(); h->status_dev = nullptr; }
+  }
+  // the status words reach the host from the run's last kernel when there is one that can carry them (the deferred
+  // log-likelihood's flush; the fill kernels behind it never touch a status word), by a queued copy otherwise
+  const bool status_by_kernel = c.defer_loglik && n_iters > 0 && h->status_dev != nullptr;
+  if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st, status_by_kernel ? h->status_dev : nullptr);
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c, c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   if (!plan.chi_update) launch_fill_slots(c, c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   HIPCHK(hipEventRecord(h->ev1, h->st));
-  if (!h->status_host) HIPCHK(hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * (size_t)h->nch, hipHostMallocDefault));
-  // the chains' status words: one strided copy queued behind the run
-  HIPCHK(hipMemcpy2DAsync(h->status_host, sizeof(uint32_t), &h->c.dyn->status, h->nch > 1 ? h->c.chain_bytes : sizeof(uint32_t), sizeof(uint32_t),
-                          (size_t)h->nch, hipMemcpyDeviceToHost, h->st));
+  if (!status_by_kernel)      // the chains' status words: one strided copy queued behind the run
+    HIPCHK(hipMemcpy2DAsync(h->status_host, sizeof(uint32_t), &h->c.dyn->status, h->nch > 1 ? h->c.chain_bytes : sizeof(uint32_t), sizeof(uint32_t),
+                            (size_t)h->nch, hipMemcpyDeviceToHost, h->st));
   tmark("all queued");
   HIPCHK(hipStreamSynchronize(h->st));
   tmark("synchronised");

@@ -1978,10 +1978,15 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c0, int use_rss_part, int r_
 }
 
 // reduces a still-pending log-likelihood (launched once at the end of a run)
-__global__ __launch_bounds__(256) void k_loglik_flush(Ctx c0) {
+// status_out (host-mapped pinned memory, one word per chain; may be null): the chain's status word for bfmmm_run -- written
+// from the run's last kernel, it saves the device-to-host copy a run used to queue behind its kernels (about 10 us of a call)
+__global__ __launch_bounds__(256) void k_loglik_flush(Ctx c0, uint32_t* status_out) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   __shared__ double red[256];
   if (c.dyn->ll_pending) deferred_loglik(c, red);
+  if (status_out && threadIdx.x == 0) {
+    __hip_atomic_store(&status_out[blockIdx.z], c.dyn->status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // broadcast the current value of blocks a sweep does not update into chain slots [s0, s1)
@@ -2125,7 +2130,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   return 0;
 }
 
-void launch_loglik_flush(const Ctx& c, hipStream_t st) { hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), 0, st, c); }
+void launch_loglik_flush(const Ctx& c, hipStream_t st, uint32_t* status_out) { hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), 0, st, c, status_out); }
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
   hipLaunchKernelGGL(k_loglik, dim3(1, 1, c.nch), dim3(256), 0, st, c, use_rss_part, r_stored);
