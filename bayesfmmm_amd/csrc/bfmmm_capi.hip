@@ -284,7 +284,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
     if (P < 1) return fail("multivariate model: P must be positive");
   } else if (bs) {
     P = bs->P;
-    BW = (bs->band <= BWMAX) ? std::min(bs->band, std::max(P - 1, 0)) : BWWIDE;     // wide bands share one instantiation (zero padded)
+    BW = (bs->band <= BWMAX) ? std::min(bs->band, std::max(P - 1, 0)) : (bs->band <= BWMID) ? BWMID : BWWIDE;     // wide bands share two instantiations (zero padded)
   } else {
     if (!t || !offsets || !boundary_knots || (cfg->n_internal_knots > 0 && !internal_knots))
       return fail("bfmmm_create: null argument");
@@ -328,6 +328,7 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   d.mv = mv ? 1 : 0;
   d.BWP = mv ? 0 : std::max(BW, 1);   // RW1 penalty is tridiagonal
   if (bs) d.BWP = std::min(std::max(BW, bs->pen_band), (BW > BWMAX) ? BWWIDE : BWMAX);
+  if (bs && BW == BWMID && bs->pen_band > BWMID) { BW = BWWIDE; d.BW = BW; d.LG = (BW + 1) * P; d.LREC = (d.LG + P + 1 + 1) / 2 * 2; d.BWP = std::min(std::max(BW, bs->pen_band), BWWIDE); }
   if (bs && BW <= BWMAX && bs->pen_band > BWMAX) return fail("bfmmm_create_from_basis: a penalty band wider than 5 needs a basis band wider than 5 in this build");
   set_md(d, M + 1);
   for (int k = 0; k < KMAX; ++k) c.h.c[k] = (k < 8) ? cfg->c[k] : 10.0;
@@ -935,7 +936,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     const char* env_split = getenv("BFMMM_BATCH_SPLIT");
     int nsub = (h->nch >= 4) ? 2 : 1;
     if (env_split) nsub = std::max(1, std::min({atoi(env_split), (int)bfmmm_handle::MAX_SUB, h->nch / 2}));
-    const int pack_mode = getenv("BFMMM_PG_PACK") ? 1 + (atoi(getenv("BFMMM_PG_PACK")) != 0) : 0;
+    // (the captured graphs bake in the kernel instances the launchers chose: the cache key carries the switches that choose them)
+    const int pack_mode = (getenv("BFMMM_PG_PACK") ? 1 + (atoi(getenv("BFMMM_PG_PACK")) != 0) : 0) + 4 * (bfmmm::g_exact_instances ? 1 : 0);
     const bool reuse = h->g_valid && h->g_mask == mask && h->g_md == MD && h->g_seed == seed && h->g_chain == chain && h->g_nsub == nsub && h->g_pack_mode == pack_mode;
     if (!reuse) {
       for (auto& g_ : h->gs)

@@ -790,6 +790,7 @@ static void launch_group(const Ctx& c, int g_prev, int g_next, int par_prev, hip
     case 3: launch_group_bw<3>(c, g_prev, g_next, par_prev, st); break;
     case 4: launch_group_bw<4>(c, g_prev, g_next, par_prev, st); break;
     case 5: launch_group_bw<5>(c, g_prev, g_next, par_prev, st); break;
+    case BWMID: launch_group_bw<BWMID>(c, g_prev, g_next, par_prev, st); break;
     default: launch_group_bw<BWWIDE>(c, g_prev, g_next, par_prev, st); break;
   }
 }
@@ -854,7 +855,7 @@ void prepare_cov_kernels() {
   set_max_lds((const void*)k_cov_factor<32>);
   set_max_lds((const void*)k_cov_factor<64>);
   prepare_group_bw<0>(); prepare_group_bw<1>(); prepare_group_bw<2>();
-  prepare_group_bw<3>(); prepare_group_bw<4>(); prepare_group_bw<5>(); prepare_group_bw<BWWIDE>();
+  prepare_group_bw<3>(); prepare_group_bw<4>(); prepare_group_bw<5>(); prepare_group_bw<BWMID>(); prepare_group_bw<BWWIDE>();
 }
 
 // does the covariate block of this model fit the kernels' LDS and staging assumptions? (host check at set-up)
@@ -880,6 +881,7 @@ bool cov_block_fits(const Ctx& c) {
     case 3: return group_fits_bw<3>(c);
     case 4: return group_fits_bw<4>(c);
     case 5: return group_fits_bw<5>(c);
+    case BWMID: return group_fits_bw<BWMID>(c);
     default: return group_fits_bw<BWWIDE>(c);
   }
 }

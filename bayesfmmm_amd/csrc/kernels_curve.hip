@@ -852,7 +852,7 @@ static void prepare_bw() {
 }
 
 void prepare_curve_kernels() {
-  prepare_bw<0>(); prepare_bw<1>(); prepare_bw<2>(); prepare_bw<3>(); prepare_bw<4>(); prepare_bw<5>(); prepare_bw<BWWIDE>();
+  prepare_bw<0>(); prepare_bw<1>(); prepare_bw<2>(); prepare_bw<3>(); prepare_bw<4>(); prepare_bw<5>(); prepare_bw<BWMID>(); prepare_bw<BWWIDE>();
 }
 
 int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st) {
@@ -864,6 +864,7 @@ int launch_curve(const Ctx& c, int which, int do_update, hipStream_t st) {
     case 3: launch_curve_bw<3>(c, which, do_update, st); break;
     case 4: launch_curve_bw<4>(c, which, do_update, st); break;
     case 5: launch_curve_bw<5>(c, which, do_update, st); break;
+    case BWMID: launch_curve_bw<BWMID>(c, which, do_update, st); break;
     case BWWIDE: launch_curve_bw<BWWIDE>(c, which, do_update, st); break;
     default: return 1;
   }

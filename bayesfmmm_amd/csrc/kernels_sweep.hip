@@ -2064,6 +2064,7 @@ static void launch_factor_pp(const Ctx& c, int grid, size_t lds, hipStream_t st)
     case 3: hipLaunchKernelGGL((k_factor<PP, 3>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
     case 4: hipLaunchKernelGGL((k_factor<PP, 4>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
     case 5: hipLaunchKernelGGL((k_factor<PP, 5>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
+    case BWMID: hipLaunchKernelGGL((k_factor<PP, BWMID>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
     default: hipLaunchKernelGGL((k_factor<PP, BWWIDE>), dim3(c.nch * grid), dim3(256), lds, st, c); break;
   }
 }
@@ -2147,6 +2148,7 @@ void prepare_sweep_kernels() {
   set_max_lds((const void*)k_factor<32, 3>); set_max_lds((const void*)k_factor<64, 3>);
   set_max_lds((const void*)k_factor<32, 4>); set_max_lds((const void*)k_factor<64, 4>);
   set_max_lds((const void*)k_factor<32, 5>); set_max_lds((const void*)k_factor<64, 5>);
+  set_max_lds((const void*)k_factor<32, BWMID>); set_max_lds((const void*)k_factor<64, BWMID>);
   set_max_lds((const void*)k_factor<32, BWWIDE>); set_max_lds((const void*)k_factor<64, BWWIDE>);
 }
 

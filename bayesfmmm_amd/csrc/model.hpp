@@ -17,7 +17,9 @@ namespace bfmmm {
 constexpr int KMAX = 8;     // clusters supported by the unrolled per-curve code (bfmmm_config.c[8] has room for as many)
 constexpr int PMAX = 64;    // basis functions: one lane per basis function inside a curve group
 constexpr int BWMAX = 5;    // spline degree (band half-width) instantiated
-constexpr int BWWIDE = 31;  // the one wide-band instantiation (user-supplied / tensor-product bases, bfmmm_create_from_basis)
+constexpr int BWWIDE = 31;  // the widest band instantiation (user-supplied / tensor-product bases, bfmmm_create_from_basis)
+constexpr int BWMID = 15;   // bands 6 .. 15 (round 4: e.g. a 6 x 6 tensor-product basis of quadratic splines has band 14; padded to 31
+                            // its records, pair-Gram columns and per-curve band registers were twice what the band needs)
 
 // update mask bits, in the (fixed) order in which every reference driver applies them
 // (BFMMM.h:1073-1107, 1253-1292, 1502-1553, 3741-3780, 3944-4010, 4809-4894)
