@@ -535,6 +535,22 @@ def main():
         out["chains_sweep"] = cs
         out["multi_chain"] = dict(next(c for c in cs if c["chains"] == 8),
                                   workload="8 independent chains of the warm-start sweep as one sampler batch on this GPU")
+        # the batch's pair-Gram contraction on the matrix cores (k_pair_gram_pack), from the committed counter pass of the same
+        # workload on one stream (tools/profile_round.sh: profiles/r*_warm_8_mfma_pmc.json)
+        try:
+            fm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_warm_8_mfma_pmc.json")))
+            mp = json.load(open(fm[-1]))["k_pair_gram_pack"] if fm else None
+            if mp:
+                R_pairs, A_dirs = (K * (K + 1) // 2) * ((M + 1) * (M + 2) // 2), K * (M + 1)
+                useful = 8 * 2.0 * n * (R_pairs * 4 * P + A_dirs * P)
+                issued = mp["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+                out["multi_chain"]["pair_gram_mfma"] = dict(
+                    kernel="k_pair_gram_pack", source=os.path.basename(fm[-1]), duration_us=mp["avg_us"], useful_flop_per_launch=useful,
+                    achieved_tflops=useful / (mp["avg_us"] * 1e-6) / 1e12, peak_tflops=FP64_MFMA_PEAK_TF,
+                    frac=useful / (mp["avg_us"] * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF, mfma_pipe_busy_frac=mp["mfma_pipe_busy_frac"],
+                    issued_flop_per_launch=issued, tile_padding_frac=1.0 - useful / issued)
+        except Exception:
+            pass
         out["other_configs"] = other_configs(bf)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0's host cores, N = 1 only
         out["cpu_baseline"] = cpu_baseline(w)

@@ -42,7 +42,7 @@ def pmc_per_launch(db, counter):
 
 def main():
     src = Path(sys.argv[1]); tag = sys.argv[2]; dst = Path(sys.argv[3])
-    dst.mkdir(exist_ok=True)
+    dst.mkdir(parents=True, exist_ok=True)
     ks = kernel_stats(src / "trace" / "run_results.db")
     tot = sum(o["total_ns"] for o in ks.values())
     with open(dst / f"{tag}_kernel_stats.csv", "w") as f:
@@ -99,8 +99,36 @@ def main():
                          hbm_read_bytes_per_launch=None if f_kb is None else 2.0 * f_kb * 1024.0,
                          hbm_write_bytes_per_launch=None if w_kb is None else w_kb * 1024.0)
         json.dump(sm, open(dst / f"{tag.replace('_final', '')}_nu_z_8_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    # the same three passes for the 8-chain warm-start batch on one stream
+    wf, ww, wm = (src / f"warm_8_pmc_{x}" / "run_results.db" for x in ("fetch", "write", "mfma"))
+    if wf.exists() and ww.exists():
+        ksn = kernel_stats(wf)
+        fz, wz = pmc_per_launch(wf, "FETCH_SIZE"), pmc_per_launch(ww, "WRITE_SIZE")
+        sm = {}
+        for k in ksn:
+            if not k.startswith("k_"):
+                continue
+            f_kb, w_kb = fz.get(k), wz.get(k)
+            sm[k] = dict(calls=ksn[k]["calls"], avg_us=ksn[k]["avg_ns"] / 1e3, fetch_size_kb_raw=f_kb, write_size_kb_raw=w_kb,
+                         hbm_read_bytes_per_launch=None if f_kb is None else 2.0 * f_kb * 1024.0,
+                         hbm_write_bytes_per_launch=None if w_kb is None else w_kb * 1024.0)
+        json.dump(sm, open(dst / f"{tag.replace('_final', '')}_warm_8_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    if wm.exists():
+        ksn = kernel_stats(wm)
+        names = ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"]
+        per = {nm: pmc_per_launch(wm, nm) for nm in names}
+        mf = {}
+        for k in ksn:
+            if not k.startswith("k_"):
+                continue
+            row = {nm: per[nm].get(k) for nm in names}
+            busy, mbusy = row.get("SQ_BUSY_CYCLES"), row.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            row["mfma_pipe_busy_frac"] = (mbusy / (busy / 32.0 * 1024.0)) if busy and mbusy is not None else None
+            row["avg_us"] = ksn[k]["avg_ns"] / 1e3
+            mf[k] = row
+        json.dump(mf, open(dst / f"{tag.replace('_final', '')}_warm_8_mfma_pmc.json", "w"), indent=1, sort_keys=True)
     # the other workloads of the round: per-kernel statistics
-    skip = ("trace", "pmc_fetch", "pmc_write", "pmc_mfma", "nu_z_8_pmc_fetch", "nu_z_8_pmc_write")
+    skip = ("trace", "pmc_fetch", "pmc_write", "pmc_mfma", "nu_z_8_pmc_fetch", "nu_z_8_pmc_write", "warm_8_pmc_fetch", "warm_8_pmc_write", "warm_8_pmc_mfma")
     for sub in sorted(p for p in src.iterdir() if p.is_dir() and (p / "run_results.db").exists() and p.name not in skip):
         ks2 = kernel_stats(sub / "run_results.db")
         tot2 = sum(o["total_ns"] for o in ks2.values())
