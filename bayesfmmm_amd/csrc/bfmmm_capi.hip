@@ -359,11 +359,13 @@ static int create_impl(const bfmmm_config* cfg, int device, const double* y, con
   pg_geometry(d, NTG, NKS, KS);
   h->pg_part_doubles = (size_t)NKS * d.NT * 256;
   areq(ar, &c.logz_part, (size_t)c.nblk_curve * K); areq(ar, &c.rss_part, c.nblk_curve);
-  areq(ar, &c.pg_part, h->pg_part_doubles); areq(ar, &c.H, (size_t)d.R * d.LG); areq(ar, &c.H2, (size_t)d.R * P * (2 * d.BW + 2));
+  // (+ 2 doubles on H and Cmat: for odd P the last row thread of k_sweep_chain reads a 16-byte pair that starts at the last
+  //  element -- the second half is masked, but the read must stay inside the request, whatever the arena's rounding)
+  areq(ar, &c.pg_part, h->pg_part_doubles); areq(ar, &c.H, (size_t)d.R * d.LG + 2); areq(ar, &c.H2, (size_t)d.R * P * (2 * d.BW + 2));
   areq(ar, &c.tvec, (size_t)d.A * P); areq(ar, &c.rvec, (size_t)d.A * P); areq(ar, &c.hq, (size_t)d.A * P);
   areq(ar, &c.gstd, (size_t)K * P * M + (size_t)K * M + 13 * K + 8); areq(ar, &c.zprep, (size_t)(3 * K + 5) * n);
   areq(ar, &c.chi_norm, (size_t)n * M); areq(ar, &c.piprep, 9 * KMAX + 16); areq(ar, &c.Lz, (size_t)d.A * P);
-  areq(ar, &c.Cmat, (size_t)d.A * P * P);
+  areq(ar, &c.Cmat, (size_t)d.A * P * P + 2);
   {
     const size_t T = (size_t)h->T;
     areq(ar, &c.c_nu, T * K * P); areq(ar, &c.c_chi, T * n * M); areq(ar, &c.c_Z, T * n * K); areq(ar, &c.c_pi, T * K);

@@ -149,8 +149,13 @@ int bfmmm_init_state(bfmmm_handle* h, int stage, uint64_t seed, uint32_t chain);
 int bfmmm_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
               int phi_chi_zero, double beta);
 
-/* Set-up half of bfmmm_run: captures and instantiates the HIP graphs a run with the same arguments replays and launches
- * nothing (a caller that times bfmmm_run, or needs its first call to return quickly, pays the capture here). */
+/* Set-up half of bfmmm_run: captures and instantiates the HIP graphs a run with the same arguments replays (a caller that
+ * times bfmmm_run, or needs its first call to return quickly, pays the capture here).  Every graph this call instantiates is
+ * also launched a few times ("dry launch", about 10 ms; BFMMM_DRY_LAUNCH=0 / BFMMM_DRY_LAUNCH_MS=x) between a snapshot and a
+ * restore of the chains' work state: the first launch of a graph costs the device 13 - 20 us more than later ones, and the
+ * clocks of a device that idled through the capture take milliseconds to come up.  The state a later bfmmm_run starts from is
+ * bit-identical with and without the call (tests/test_gpu_prepare.py); the chain SLOTS first_iter .. first_iter + 10 hold
+ * scratch values until that run rewrites them. */
 int bfmmm_prepare_run(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters, uint64_t seed, uint32_t chain,
                       int phi_chi_zero);
 
