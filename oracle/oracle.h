@@ -67,6 +67,8 @@ double orc_dtruncnorm_log(double x, double mu, double sd, double lo, double hi);
 double orc_pnorm(double x);
 /* test hooks */
 void   orc_rgamma_hook(int arm, uint32_t upd, const double* inject, double* rec_shape_scale, int cap);
+double orc_rnorm_ms(const orc_rng* r, uint32_t upd, uint32_t idx, double mean, double sd);      /* mean + sd * N(0, 1), hookable */
+void   orc_rnorm_hook(int arm, uint32_t upd, const double* inject, double* rec_mean_sd, int cap);
 void   orc_test_fill(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t upd, int kind,
                      double p1, double p2, int count, double* out);
 

@@ -100,6 +100,21 @@ double orc_rnorm(const orc_rng* r, uint32_t upd, uint32_t idx) {
   return orc_qnorm(u0);
 }
 
+/* R::rnorm(mean, sd) as the update functions draw it (mean + sd * standard normal), with a test hook of the same kind as
+ * orc_rgamma_hook below (tests/test_oracle_pit_data_blocks.py): while armed for update id `upd`, a draw records the (mean, sd)
+ * the restatement asked for and returns the injected value -- the reference package's own saved draw -- instead. */
+static struct { int armed; uint32_t upd; const double* inject; double* rec; int cap; } g_norm_hook;
+void orc_rnorm_hook(int arm, uint32_t upd, const double* inject, double* rec_mean_sd, int cap) {
+  g_norm_hook.armed = arm; g_norm_hook.upd = upd; g_norm_hook.inject = inject; g_norm_hook.rec = rec_mean_sd; g_norm_hook.cap = cap;
+}
+double orc_rnorm_ms(const orc_rng* r, uint32_t upd, uint32_t idx, double mean, double sd) {
+  if (g_norm_hook.armed && upd == g_norm_hook.upd && (int)idx < g_norm_hook.cap) {
+    g_norm_hook.rec[2 * idx] = mean; g_norm_hook.rec[2 * idx + 1] = sd;
+    return g_norm_hook.inject[idx];
+  }
+  return mean + sd * orc_rnorm(r, upd, idx);
+}
+
 #define ORC_MAX_ATTEMPTS 256u
 #define ORC_BOOST_ATTEMPT 0xFFFFu
 

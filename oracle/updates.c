@@ -667,7 +667,7 @@ void orc_updateChi(const orc_data* d, const orc_rng* r, double beta_i, int iter,
       w = (w * beta_i) / sigma;
       W = 1 + ((W * beta_i) / sigma);
       W = 1 / W;
-      chi_t[i + (size_t)n * m] = W * w + sqrt(W) * orc_rnorm(r, UPD_CHI, (uint32_t)(i * M + m));
+      chi_t[i + (size_t)n * m] = orc_rnorm_ms(r, UPD_CHI, (uint32_t)(i * M + m), W * w, sqrt(W));      /* R::rnorm(W * w, sqrt(W)), :58 */
     }
   }
   if (iter < (T - 1)) memcpy(SL_CHI(c, iter + 1), chi_t, sizeof(double) * (size_t)n * M);
