@@ -61,6 +61,7 @@ static int fail(const std::string& msg) { g_err = msg; return 1; }
   do {                                                                                              \
     hipError_t e_ = (x);                                                                            \
     if (e_ != hipSuccess) {                                                                         \
+      (void)hipGetLastError(); /* (not sticky: a caller that retries with a smaller batch starts clean) */ \
       char buf_[512];                                                                               \
       snprintf(buf_, sizeof buf_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); \
       return fail(buf_);                                                                            \

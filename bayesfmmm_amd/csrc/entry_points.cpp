@@ -245,7 +245,11 @@ static void run_device(const bfmmm_entry_args* a, const bfmmm_config& cfg, uint3
       if (nb > 1 && strstr(bfmmm_last_error(), "memory")) { cap = (size_t)(nb + 1) / 2; continue; }      // smaller batches
       return fail_device(nullptr);
     }
-    if (attach_cov(h, a) || bfmmm_set_chain_id_stride(h, id_stride)) return fail_device(h);
+    if (attach_cov(h, a)) {      // (the covariate arena scales with the batch too: an out-of-memory here halves the batch as well)
+      if (nb > 1 && strstr(bfmmm_last_error(), "memory")) { bfmmm_destroy(h); cap = (size_t)(nb + 1) / 2; continue; }
+      return fail_device(h);
+    }
+    if (bfmmm_set_chain_id_stride(h, id_stride)) return fail_device(h);
     for (int q = 0; q < nb; ++q)
       if (bfmmm_select_chain(h, q) || setup(h, r.chains[base + q], ctx)) return fail_device(h);
     if (bfmmm_run(h, mask, 0, T, a->seed, (uint32_t)r.chains[base], phi_chi_zero, 1.0)) return fail_device(h);

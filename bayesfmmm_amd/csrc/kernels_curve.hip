@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   cv.load(c.rec + (size_t)min(i, n - 1) * d.LREC, P, d.LG, lp);
   const double chi_l = (MD > 1 && lp < M) ? c.chi[min(i, n - 1) + (size_t)n * min(lp, M - 1)] : 0.0;
   const double sigma2 = dh.sigma2, alpha3 = dh.alpha3, beta = dh.beta;
+  const double inv_2s2 = 1.0 / (2.0 * sigma2);       // (formed while the loads are in flight: a division is ~10 dependent instructions)
   // ---- proposal phase (UpdateMixedMembership.h:131-150): everything of the update that does not depend on the data
   //      (z_proposal.hpp).  Normally it was prepared during the previous iteration's k_factor; otherwise (first
   //      iteration of a run, tempered sweeps, changed state) it is evaluated here, while the loads are in flight ----
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
           }
         }
       }
-      const double z_lpdf = zp.pr_old - beta * (q_old / (2.0 * sigma2));
-      const double z_new_lpdf = zp.pr_new - beta * (q_new / (2.0 * sigma2));
+      const double z_lpdf = zp.pr_old - beta * (q_old * inv_2s2);
+      const double z_new_lpdf = zp.pr_new - beta * (q_new * inv_2s2);
       double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
 #pragma unroll
       for (int k = 0; k < KT; ++k)
@@ -475,6 +476,9 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   ZProposal zp;
   if (fuse_z) z_proposal_load(c, ic, zp, dh.alpha3, dyn->pi);            // likewise
   const double sigma2 = dh.sigma2, beta = dh.beta;
+  // (reciprocals formed once, while the loads are in flight: the Gauss-Seidel recursion below had a division -- ~10 dependent
+  //  instructions -- on each of its M sequential steps)
+  const double inv_s2 = 1.0 / sigma2, inv_2s2 = 1.0 / (2.0 * sigma2);
   // ---- now the staged data: theta to LDS, chi to the curve's tile ----
 #pragma unroll
   for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
@@ -577,11 +581,14 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       }
       __builtin_amdgcn_wave_barrier();
       // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
-      double dl[MT];
+      // (no LDS store inside the recursion: a store to sChi between two steps kept every later read of sRes / sWq / sZn behind
+      //  it -- the compiler must assume they alias -- so each of the M steps paid an LDS round trip on the chain; with the new
+      //  values kept in registers and stored afterwards, all the reads of the recursion are issued up front)
+      double dl[MT], chn[MT];
       double* cslot = c.c_chi + (size_t)dh.slot_hyper * n * M;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        dl[m] = 0.0;
+        dl[m] = 0.0; chn[m] = 0.0;
         if (m < M) {
           double r1 = sRes[nA + m];
 #pragma unroll
@@ -589,11 +596,17 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
             if (m2 < m) r1 -= sRes[tri_index(M, m2, m)] * dl[m2];
           const double W0 = sRes[tri_index(M, m, m)];
           const double chi_old = sChi[m];
-          const double w = ((r1 + chi_old * W0) * beta) / sigma2;
+          const double w = ((r1 + chi_old * W0) * beta) * inv_s2;
           const double chi_new = sWq[m] * w + sWq[M + m] * sZn[m];
           dl[m] = chi_new - chi_old;
-          if (lp == m) { c.chi[i + (size_t)n * m] = chi_new; cslot[i + (size_t)n * m] = chi_new; sChi[m] = chi_new; }
+          chn[m] = chi_new;
         }
+      }
+      {
+        double mine = 0.0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mine = (lp == m) ? chn[m] : mine;
+        if (lp < M) { c.chi[i + (size_t)n * lp] = mine; cslot[i + (size_t)n * lp] = mine; sChi[lp] = mine; }
       }
       // rss(c0 + sum_m dl_m u_m) = rss0 - 2 sum_m dl_m b_m + sum_{m,m2} dl_m dl_m2 A_{m,m2}
 #pragma unroll
@@ -674,8 +687,8 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
           }
         }
       }
-      const double z_lpdf = zp.pr_old - beta * (q_old / (2.0 * sigma2));
-      const double z_new_lpdf = zp.pr_new - beta * (q_new / (2.0 * sigma2));
+      const double z_lpdf = zp.pr_old - beta * (q_old * inv_2s2);
+      const double z_new_lpdf = zp.pr_new - beta * (q_new * inv_2s2);
       double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
 #pragma unroll
       for (int k = 0; k < KT; ++k)
