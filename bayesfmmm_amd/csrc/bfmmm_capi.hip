@@ -711,8 +711,8 @@ extern "C" int bfmmm_get_state(bfmmm_handle* h, const char* name, double* out, i
   else if (s == "stamps") { if (need(64)) return 1; for (int q = 0; q < 64; ++q) out[q] = (double)(dyn.stamps[q] % 100000000000ULL); }
 #ifdef BFMMM_TIMELINE
   else if (s == "fct") { if (need(8)) return 1; unsigned long long w[8]; fetch_fct(w); for (int q = 0; q < 8; ++q) out[q] = (double)(w[q] % 100000000000ULL); }
-  else if (s == "zphase") { if (need(4096)) return 1; std::vector<unsigned long long> w(4096); fetch_zphase(w.data()); for (int q = 0; q < 4096; ++q) out[q] = (double)w[q]; }
-  else if (s == "ztrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_ztrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
+  else if (s == "zphase") { const int N = 8 * 8192; if (need(N)) return 1; std::vector<unsigned long long> w(N); fetch_zphase(w.data()); for (int q = 0; q < N; ++q) out[q] = (double)w[q]; }
+  else if (s == "ztrace") { const int N = 3 * 8192; if (need(N)) return 1; std::vector<unsigned long long> w(N); fetch_ztrace(w.data()); for (int q = 0; q < N; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
   else if (s == "wgtrace") { if (need(3072)) return 1; std::vector<unsigned long long> w(3072); fetch_wgtrace(w.data()); for (int q = 0; q < 3072; ++q) out[q] = (q % 3 == 1) ? (double)w[q] : (double)(w[q] % 100000000000ULL); }
 #endif
   else return fail("bfmmm_get_state: unknown name '" + s + "'");

@@ -19,6 +19,7 @@
 #include "rng.hpp"
 #include "scalar_jobs.hpp"
 #include "z_proposal.hpp"
+#include "lds_dot.hpp"
 
 #include <algorithm>
 
@@ -52,9 +53,9 @@ struct Curve {
   }
   // (G u)[p] with u staged in an LDS row padded by BW zeros on both sides (row points at element 0)
   __device__ inline double matvec(const double* row, int p) const {
-    double v = g[0] * row[p];
+    double v = g[0] * lds_ld(row + p);             // (single ds_read_b64s: lds_dot.hpp)
 #pragma unroll
-    for (int d = 1; d <= BW; ++d) v += g[d] * row[p + d] + gl[d] * row[p - d];
+    for (int d = 1; d <= BW; ++d) v += g[d] * lds_ld(row + p + d) + gl[d] * lds_ld(row + p - d);
     return v;
   }
 };
@@ -94,10 +95,11 @@ __device__ inline double dotL(const double* a, const double* b) {
 // LDS per group: U[K], GU[K], S (1 row), chi (MMAX), res (32)
 // ------------------------------------------------------------------------------------------------
 #ifdef BFMMM_TIMELINE
-__device__ unsigned long long g_ztrace[3 * 1024];
-__device__ unsigned long long g_zphase[8 * 512];
-void fetch_ztrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ztrace), sizeof(unsigned long long) * 3 * 1024); }
-void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zphase), sizeof(unsigned long long) * 8 * 512); }
+constexpr int ZTN = 8192;      // workgroups traced (index: chain * gridDim.x + blockIdx.x)
+__device__ unsigned long long g_ztrace[3 * ZTN];
+__device__ unsigned long long g_zphase[8 * ZTN];
+void fetch_ztrace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ztrace), sizeof(unsigned long long) * 3 * ZTN); }
+void fetch_zphase(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zphase), sizeof(unsigned long long) * 8 * ZTN); }
 #endif
 
 // KT: compile-time bound on K (4 or KMAX).  The per-cluster arrays below are unrolled to KT, not KMAX: with K <= 4 the
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   const int n = d.n, K = d.K, P = d.P, M = d.M, MD = d.MD;
   const int D = COV ? d.D : 0;   // the covariate code is compiled only into the COV instantiation
   const int nth = K * (M + 1) * P;
-  double* sTh = smem;
+  double* sDyn = smem;                               // LEAN: the head of Dyn and pi (model.hpp: dyn_head_fetch)
+  double* sTh = sDyn + DYN_LDS_DOUBLES;
   double* sThX = sTh + nth;                          // D > 0: thetaX, K*(M+1)*D*P
   double* sLog = sThX + (size_t)nth * D;             // GPB*KMAX
   double* sYp = sLog + GPB * KMAX;                   // GPB
@@ -162,8 +165,12 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   const bool valid = i < n;
   const bool act = lp < P;
   const Dyn* dyn = c.dyn;
-  const DynHead dh = dyn_head(dyn);                 // (one batch of loads, not a trip per field: model.hpp)
-  const uint32_t it_cur = LEAN ? dh.iter_hyper + 1u : dh.iter, slot_cur = LEAN ? dh.slot_hyper + 1u : dh.slot;
+  // (LEAN: one load per wave, handed round through LDS -- the head is needed only behind the barrier; otherwise one batch of
+  //  loads, not a trip per field: model.hpp)
+  uint32_t dyn_w = 0u;
+  DynHead dh;
+  if constexpr (LEAN) dyn_w = dyn_head_fetch(dyn);
+  else dh = dyn_head(dyn);
   // ---- all global loads are requested up front.  Z first: the proposal phase below needs nothing else, and loads
   //      retire in issue order, so it can start while the record, theta and chi are still on their way ----
   double Zold[KMAX];
@@ -175,18 +182,18 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   Curve<BW, LPC> cv;
   cv.load(c.rec + (size_t)min(i, n - 1) * d.LREC, P, d.LG, lp);
   const double chi_l = (MD > 1 && lp < M) ? c.chi[min(i, n - 1) + (size_t)n * min(lp, M - 1)] : 0.0;
-  const double sigma2 = dh.sigma2, alpha3 = dh.alpha3, beta = dh.beta;
-  const double inv_2s2 = 1.0 / (2.0 * sigma2);       // (formed while the loads are in flight: a division is ~10 dependent instructions)
   // ---- proposal phase (UpdateMixedMembership.h:131-150): everything of the update that does not depend on the data
   //      (z_proposal.hpp).  Normally it was prepared during the previous iteration's k_factor; otherwise (first
   //      iteration of a run, tempered sweeps, changed state) it is evaluated here, while the loads are in flight ----
   ZProposal zp;
-  if (valid && do_update) {
-    const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == it_cur) & (dh.zprep_tt == dh.tt_step) &
+  if constexpr (LEAN) {
+    z_proposal_fetch(c, min(i, n - 1), zp);          // (the tag is checked, the prior terms added behind the barrier)
+    dyn_head_stage(sDyn, dyn_w);
+  } else if (valid && do_update) {
+    const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == dh.iter) & (dh.zprep_tt == dh.tt_step) &
                      (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
-    if (pre) z_proposal_load(c, i, zp, alpha3, dyn->pi);
-    else if constexpr (LEAN) { if (lp == 0) atomicOr(&c.dyn->status, 2u); }
-    else z_proposal<LPC>(c, make_key(c.seed, c.chain, dh.iter, dh.tt_step), i, lp, Zold, alpha3, dyn->pi, zp);
+    if (pre) z_proposal_load(c, i, zp, dh.alpha3, dyn->pi);
+    else z_proposal<LPC>(c, make_key(c.seed, c.chain, dh.iter, dh.tt_step), i, lp, Zold, dh.alpha3, dyn->pi, zp);
   }
   // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
 #pragma unroll
@@ -201,6 +208,18 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   ZT();
   __syncthreads();
   ZT();
+  if constexpr (LEAN) {
+    dh = dyn_head_lds(sDyn);
+    if (valid && do_update) {
+      const bool pre = (dh.zprep_valid != 0u) & (dh.zprep_iter == dh.iter_hyper + 1u) & (dh.zprep_tt == dh.tt_step) &
+                       (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
+      if (pre) z_proposal_prior(c, zp, dh.alpha3, dyn_pi_lds(sDyn));
+      else if (lp == 0) atomicOr(&c.dyn->status, 2u);
+    }
+  }
+  const uint32_t slot_cur = LEAN ? dh.slot_hyper + 1u : dh.slot;
+  const double beta = dh.beta;
+  const double inv_2s2 = 1.0 / (2.0 * dh.sigma2);
   // covariate adjustment: the curve sees theta_r + sum_d x_id thetaX_{r,d}.  The combination is folded into the sums
   // below (u_k = sum_r coef_r theta_r + sum_d x_d sum_r coef_r thetaX_{r,d}) instead of materialising the K(M+1)
   // effective rows per curve in LDS: that tile cost 50 KB per workgroup and left one workgroup per CU.
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
       double vb[KMAX];                 // the part without covariates
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
-        vb[k] = (k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
+        vb[k] = (k < K && act) ? lds_ld(sTh + (size_t)k * (M + 1) * P + lp) : 0.0;
         ucov[k] = 0.0;
         if (D > 0 && k < K && act) {
           const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
           for (int k = 0; k < KT; ++k)
             if (k < K) {
               const double* tb = sTh + (size_t)k * (M + 1) * P + lp;
-              vb[k] += c0 * tb[r0 * P] + c1 * tb[r1 * P];
+              vb[k] += c0 * lds_ld(tb + r0 * P) + c1 * lds_ld(tb + r1 * P);
               if (D > 0) {
                 const double* xb = sThX + (size_t)k * (M + 1) * D * P + lp;
                 double e0 = 0.0, e1 = 0.0;
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
         while (rem >= K - a) { rem -= K - a; ++a; }
         ra = tU.row(a); rb = tG.row(a + rem);
       }
-      sRes[q] = dotL<LPC>(ra, rb);
+      sRes[q] = dot_lds<LPC>(ra, rb);
     }
     __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
@@ -286,22 +305,27 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
     bool took_new = false;
     if (do_update) {
       // quadratic form of the residual sum of squares in Z
-      double q_old = cv.yy, q_new = cv.yy;
+      // q = yy + sum_k Z_k (-2 a_k + sum_k2 Z_k2 Q_k,k2): one short chain per k (a dependent double-precision operation issues
+      // every ~16 clocks; the flat sum over (k, k2) was one chain of K (K + 1) of them).  The fused update in k_curve_chi forms
+      // the same sums in the same order.
+      double qo = 0.0, qn = 0.0;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (k < K) {
-          q_old -= 2.0 * Zold[k] * av[k];
-          q_new -= 2.0 * zp.Znew[k] * av[k];
+          double to = -2.0 * av[k], tn = -2.0 * av[k];
 #pragma unroll
           for (int k2 = 0; k2 < KT; ++k2) {
             if (k2 < K) {
               const double qq = (k2 >= k) ? Q[k][k2] : Q[k2][k];
-              q_old += Zold[k] * Zold[k2] * qq;
-              q_new += zp.Znew[k] * zp.Znew[k2] * qq;
+              to += Zold[k2] * qq;
+              tn += zp.Znew[k2] * qq;
             }
           }
+          qo += Zold[k] * to;
+          qn += zp.Znew[k] * tn;
         }
       }
+      const double q_old = cv.yy + qo, q_new = cv.yy + qn;
       const double z_lpdf = zp.pr_old - beta * (q_old * inv_2s2);
       const double z_new_lpdf = zp.pr_new - beta * (q_new * inv_2s2);
       double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
@@ -390,6 +414,9 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   TIMELINE(c, 5);
   // mode 0: nothing per curve (only the scalar job), 1: residual sums only, 2: chi update + residual sums
   if (blockIdx.x == 0) {     // one extra workgroup (dispatched first): delta, A, gamma, tau -- hidden under the per-curve work
+#ifdef BFMMM_ABLATE
+    if ((mode >> 8) & 4) return;
+#endif
     job_hyper(c);
     TSTAMP(c, 15);
     return;
@@ -398,6 +425,13 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   // (fused k_curve_z, D == 0 only): the record, theta and Z are already on chip, so the next iteration loses the
   // load phase of k_curve_z (60 % of that kernel) and one launch boundary.
   const bool fuse_z = (mode & 16) != 0;
+#ifdef BFMMM_ABLATE
+  // diagnostic build (tools/timeline.py build --extra -DBFMMM_ABLATE): BFMMM_ABLATE=<bits> cuts parts of the kernel out to time the
+  // rest -- 1: the curve workgroups return at entry; 2: they return behind the first barrier (loads + staging only);
+  // 4: no scalar job (workgroup 0 returns); 8: they return behind the quadratic forms; 16: behind the Gauss-Seidel phase
+  const int abl = (mode >> 8) & 255;
+  if ((abl & 1) && blockIdx.x >= 8) return;
+#endif
   mode &= 15;
   if (mode == 0) return;
   // Workgroups 1-7 are idle: they keep curve block b at grid index 8 + b, i.e. on the XCD that runs block b of
@@ -405,15 +439,17 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   // iteration after iteration stay in that XCD's L2.
 #ifdef BFMMM_TIMELINE
   // per-workgroup trace (start, XCC / HW id, end) of the curve workgroups and of the scalar-job workgroup, in k_curve_z's array
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+  // (traced: the launches that fuse the next Z update, i.e. all but the last iteration of a run)
+  const int zti_ = fuse_z ? (int)(blockIdx.z * gridDim.x + blockIdx.x) : ZTN;
+  if (threadIdx.x == 0 && zti_ < ZTN) {
     unsigned id, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_ztrace[3 * blockIdx.x] = wall_clock64();
-    g_ztrace[3 * blockIdx.x + 1] = ((unsigned long long)(id & 0xf) << 32) | hw;
+    g_ztrace[3 * zti_] = wall_clock64();
+    g_ztrace[3 * zti_ + 1] = ((unsigned long long)(id & 0xf) << 32) | hw;
     if (blockIdx.x == 0) c.dyn->stamps[39] = ((c.dyn->stamps[39] << 4) | (id & 0xf)) & 0xFFFFFFFFFULL;      // history of block 0's XCC, one nibble per launch
   }
-  struct EndTraceC { __device__ ~EndTraceC() { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ztrace[3 * blockIdx.x + 2] = wall_clock64(); } } etc_;
+  struct EndTraceC { int i; __device__ ~EndTraceC() { if (threadIdx.x == 0 && i < ZTN) g_ztrace[3 * i + 2] = wall_clock64(); } } etc_{zti_};
 #endif
   if (blockIdx.x < 8) return;
   const int blk = blockIdx.x - 8;
@@ -434,7 +470,8 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   const int nth = K * (M + 1) * P;
   const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
   const int ntask = Mu * (Mu + 1) / 2 + Mu + 2;
-  double* sTh = smem;
+  double* sDyn = smem;                              // the head of Dyn and pi (model.hpp: dyn_head_fetch)
+  double* sTh = sDyn + DYN_LDS_DOUBLES;
   double* sThX = sTh + nth;
   double* sRss = sThX + (size_t)nth * D;            // GPB
   double* sLog = sRss + GPB;                        // GPB*KMAX (fused Z: block partial of sum_i log Z_ik)
@@ -447,7 +484,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   T tU{gbase}, tG{gbase + (TW - 1) * RT * T::STR}, tX{gbase + TW * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
   double* sChi = gbase + (TW * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
   double* sZn = sChi + M + 1;
-  double* sWq = sZn + M + 1;                         // W_m, then sqrt(W_m): the conditional variances of the chi update
+  double* sWq = sZn + M + 1;                         // c1_m, then c3_m: the folded constants of the chi update (sZn: unused, kept for the layout)
   double* sRes = sWq + 2 * M;
   const int i = blk * GPB + grp;
   const bool valid = i < n;
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   //      k_curve_z), and WITHOUT branches (clamped addresses, values masked afterwards): a load behind a uniform branch makes the
   //      compiler wait for everything outstanding (vmcnt(0)) at the first use behind the join.  The small operands first and the
   //      record -- nine tenths of the bytes -- last: loads retire in issue order, and u_m / c0 below need only the small ones. ----
-  const DynHead dh = dyn_head(dyn);                 // (one batch of loads, not a trip per field: model.hpp)
+  const uint32_t dyn_w = dyn_head_fetch(dyn);        // (one load per wave, handed round through LDS: model.hpp)
   double thv[4];                                     // first 1024 entries of theta (the rest, if any, follows below)
 #pragma unroll
   for (int u = 0; u < 4; ++u) thv[u] = c.theta[min((int)threadIdx.x + 256 * u, nth - 1)];
@@ -474,14 +511,17 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   cv.load(c.rec + (size_t)ic * d.LREC, P, d.LG, lp);
   double zn_pre = c.chi_norm[ic + (size_t)n * min(lp, M - 1)];       // (used only if its tag in Dyn matches)
   ZProposal zp;
-  if (fuse_z) z_proposal_load(c, ic, zp, dh.alpha3, dyn->pi);            // likewise
-  const double sigma2 = dh.sigma2, beta = dh.beta;
-  // (reciprocals formed once, while the loads are in flight: the Gauss-Seidel recursion below had a division -- ~10 dependent
-  //  instructions -- on each of its M sequential steps)
-  const double inv_s2 = 1.0 / sigma2, inv_2s2 = 1.0 / (2.0 * sigma2);
-  // ---- now the staged data: theta to LDS, chi to the curve's tile ----
+  if (fuse_z) z_proposal_fetch(c, ic, zp);                               // likewise
+  // ---- now the staged data: the Dyn head and theta to LDS, chi to the curve's tile ----
+  dyn_head_stage(sDyn, dyn_w);
+#ifdef BFMMM_TIMELINE
+  CT();                                              // (the Dyn head has arrived)
+#endif
 #pragma unroll
   for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
+#ifdef BFMMM_TIMELINE
+  CT();                                              // (theta has arrived)
+#endif
   if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
@@ -491,6 +531,15 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   // (not __syncthreads(): its fence waits for every outstanding load -- the record included.  Only the LDS stores above are published.)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   CT();
+#ifdef BFMMM_ABLATE
+  if (abl & 2) return;
+#endif
+  const DynHead dh = dyn_head_lds(sDyn);
+  const double sigma2 = dh.sigma2, beta = dh.beta;
+  // (reciprocals formed once: the Gauss-Seidel recursion below had a division -- ~10 dependent instructions -- on each of its M
+  //  sequential steps)
+  const double inv_s2 = 1.0 / sigma2, inv_2s2 = 1.0 / (2.0 * sigma2);
+  if (fuse_z) z_proposal_prior(c, zp, dh.alpha3, dyn_pi_lds(sDyn));
   double rss = 0.0;
   double logz_mine = 0.0;
   if (valid) {
@@ -511,7 +560,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       for (int k = 0; k < KT; ++k)
         {
           const int r = min(k, K - 1) * (M + 1) + mt;
-          double e = sTh[r * P + lpc];
+          double e = lds_ld(sTh + r * P + lpc);
           if (D > 0) {
 #pragma unroll
             for (int dd = 0; dd < 8; ++dd)
@@ -555,51 +604,52 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       } else if (q == nA + Mu) {
         rb = tX.row(2);
       }
-      sRes[q] = dotL<LPC>(ra, rb);
+      sRes[q] = dot_lds<LPC>(ra, rb);
     }
     if (Mu > 0) {
       // the normals were drawn by spare workgroups of this iteration's k_factor (job_chi_normals); in place otherwise
       const bool pre = (dh.znorm_valid != 0u) & (dh.znorm_iter == dh.iter_hyper) & (dh.znorm_tt == dh.tt_step) &
                        (dh.zprep_chain == c.chain) & (dh.zprep_seed == c.seed);
-      if (lp < M) {
-        if (pre) sZn[lp] = zn_pre;
-        else sZn[lp] = rnorm(make_key(c.seed, c.chain, dh.iter_hyper, dh.tt_step), UPD_CHI, (uint32_t)(i * M + lp));
-      }
+      if (lp < M && !pre) zn_pre = rnorm(make_key(c.seed, c.chain, dh.iter_hyper, dh.tt_step), UPD_CHI, (uint32_t)(i * M + lp));
     }
     __builtin_amdgcn_wave_barrier();
     CT();
+#ifdef BFMMM_ABLATE
+    if (abl & 8) return;
+#endif
     // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)
     rss = cv.yy - sRes[nA + Mu] - sRes[nA + Mu + 1];
     if (Mu > 0) {
-      // W_m = 1 / (1 + A_mm beta / sigma^2) and its square root do not depend on the recursion: lane m forms them for its m, so
-      // the wave pays ONE division and ONE square root sequence (~60 instructions) instead of M of each inside every lane's copy
-      // of the recursion (the same expressions on the same operands: the values are bit-identical)
+      // chi_m <- W_m w + sqrt(W_m) z_m,  W_m = 1 / (1 + A_mm beta / sigma^2),  w = (r_m + chi_m A_mm) beta / sigma^2,
+      // r_m = b_m - sum_{m2 < m} A_{m2,m} dl_m2  (UpdateChi.h:40-59 in Gram form).  Everything but r_m is known before the
+      // recursion, so lane m folds it into two constants for its m:  dl_m = chi_new - chi_old = c1_m r_m + c3_m  with
+      // c1 = W beta / sigma^2,  c3 = c1 chi_old A_mm + sqrt(W) z - chi_old  -- the wave pays ONE division and ONE square-root
+      // sequence, and a step of the recursion is two dependent operations instead of seven (a dependent double-precision
+      // operation issues every ~16 clocks: the M steps were 700 clocks of latency).
       if (lp < M) {
         const double W0l = sRes[tri_index(M, lp, lp)];
-        const double Wl = 1.0 / (1.0 + ((W0l * beta) / sigma2));
-        sWq[lp] = Wl; sWq[M + lp] = sqrt(Wl);
+        const double den = 1.0 + ((W0l * beta) * inv_s2);
+        const double Wl = 1.0 / den, sq = rsqrt(den);       // (both from den: the two sequences run side by side)
+        const double c1 = Wl * (beta * inv_s2);
+        sWq[lp] = c1; sWq[M + lp] = (c1 * chi_l) * W0l + (sq * zn_pre - chi_l);
       }
       __builtin_amdgcn_wave_barrier();
       // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
-      // (no LDS store inside the recursion: a store to sChi between two steps kept every later read of sRes / sWq / sZn behind
-      //  it -- the compiler must assume they alias -- so each of the M steps paid an LDS round trip on the chain; with the new
-      //  values kept in registers and stored afterwards, all the reads of the recursion are issued up front)
+      // (no LDS store inside the recursion: a store between two steps kept every later read of sRes / sWq behind it -- the
+      //  compiler must assume they alias -- so each of the M steps paid an LDS round trip on the chain; with the new values kept
+      //  in registers and stored afterwards, all the reads of the recursion are issued up front)
       double dl[MT], chn[MT];
       double* cslot = c.c_chi + (size_t)dh.slot_hyper * n * M;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         dl[m] = 0.0; chn[m] = 0.0;
         if (m < M) {
-          double r1 = sRes[nA + m];
+          double r1 = lds_ld(sRes + nA + m);
 #pragma unroll
           for (int m2 = 0; m2 < MT; ++m2)
-            if (m2 < m) r1 -= sRes[tri_index(M, m2, m)] * dl[m2];
-          const double W0 = sRes[tri_index(M, m, m)];
-          const double chi_old = sChi[m];
-          const double w = ((r1 + chi_old * W0) * beta) * inv_s2;
-          const double chi_new = sWq[m] * w + sWq[M + m] * sZn[m];
-          dl[m] = chi_new - chi_old;
-          chn[m] = chi_new;
+            if (m2 < m) r1 -= lds_ld(sRes + tri_index(M, m2, m)) * dl[m2];
+          dl[m] = lds_ld(sWq + m) * r1 + lds_ld(sWq + M + m);
+          chn[m] = lds_ld(sChi + m) + dl[m];
         }
       }
       {
@@ -608,15 +658,20 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
         for (int m = 0; m < MT; ++m) mine = (lp == m) ? chn[m] : mine;
         if (lp < M) { c.chi[i + (size_t)n * lp] = mine; cslot[i + (size_t)n * lp] = mine; sChi[lp] = mine; }
       }
-      // rss(c0 + sum_m dl_m u_m) = rss0 - 2 sum_m dl_m b_m + sum_{m,m2} dl_m dl_m2 A_{m,m2}
+      // rss(c0 + sum_m dl_m u_m) = rss0 + sum_m dl_m (-2 b_m + sum_m2 dl_m2 A_{m,m2}): one chain of M + 1 per m, then two of M / 2
+      {
+        double ra0 = 0.0, ra1 = 0.0;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if (m < M) {
-          rss -= 2.0 * dl[m] * sRes[nA + m];
+        for (int m = 0; m < MT; ++m)
+          if (m < M) {
+            double tm = -2.0 * lds_ld(sRes + nA + m);
 #pragma unroll
-          for (int m2 = 0; m2 < MT; ++m2)
-            if (m2 < M) rss += dl[m] * dl[m2] * sRes[tri_index(M, min(m, m2), max(m, m2))];
-        }
+            for (int m2 = 0; m2 < MT; ++m2)
+              if (m2 < M) tm += dl[m2] * lds_ld(sRes + tri_index(M, min(m, m2), max(m, m2)));
+            if (m & 1) ra1 += dl[m] * tm; else ra0 += dl[m] * tm;
+          }
+        rss += ra0 + ra1;
+      }
       if (D > 0 && act) {      // the eta / Xi steps start from the updated coefficient c_i and g_i = G_i c_i
         double cfin = tX.row(0)[lp], gfin = cv.s - tX.row(1)[lp];
 #pragma unroll
@@ -630,6 +685,9 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       c.gfull[(size_t)i * P + lp] = cv.s - tX.row(1)[lp];
     }
     CT();
+#ifdef BFMMM_ABLATE
+    if (abl & 16) return;
+#endif
     if (fuse_z && !zpre && lp == 0) atomicOr(&c.dyn->status, 2u);      // cannot happen in a fused run (see below); reported by bfmmm_run
     if (fuse_z && zpre) {
       // ---- updateZ_PM of iteration it_next for this curve (UpdateMixedMembership.h:131-185), as in k_curve_z:
@@ -639,7 +697,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       __builtin_amdgcn_wave_barrier();
       double uk[KMAX];
 #pragma unroll
-      for (int k = 0; k < KT; ++k) uk[k] = (k < K && act) ? sTh[(size_t)k * (M + 1) * P + lp] : 0.0;
+      for (int k = 0; k < KT; ++k) uk[k] = (k < K && act) ? lds_ld(sTh + (size_t)k * (M + 1) * P + lp) : 0.0;
       if (MD > 1 && act)
         for (int m = 0; m < M; m += 2) {
           const double c0 = sChi[m], c1 = sChi[m + 1];
@@ -648,7 +706,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
           for (int k = 0; k < KT; ++k)
             if (k < K) {
               const double* th = sTh + (size_t)k * (M + 1) * P + lp;
-              uk[k] += c0 * th[r0 * P] + c1 * th[r1 * P];
+              uk[k] += c0 * lds_ld(th + r0 * P) + c1 * lds_ld(th + r1 * P);
             }
         }
 #pragma unroll
@@ -667,26 +725,28 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
           while (rem >= K - a) { rem -= K - a; ++a; }
           ra = tU.row(a); rb = tG.row(a + rem);
         }
-        sRes[q] = dotL<LPC>(ra, rb);
+        sRes[q] = dot_lds<LPC>(ra, rb);
       }
       __builtin_amdgcn_wave_barrier();
-      double q_old = cv.yy, q_new = cv.yy;
+      double qo = 0.0, qn = 0.0;                       // (as in k_curve_z: one short chain per k)
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (k < K) {
-          const double avk = sRes[k];
-          q_old -= 2.0 * Zi[k] * avk;
-          q_new -= 2.0 * zp.Znew[k] * avk;
+          const double avk = lds_ld(sRes + k);
+          double to = -2.0 * avk, tn = -2.0 * avk;
 #pragma unroll
           for (int k2 = 0; k2 < KT; ++k2) {
             if (k2 < K) {
-              const double qq = sRes[K + tri_index(K, min(k, k2), max(k, k2))];
-              q_old += Zi[k] * Zi[k2] * qq;
-              q_new += zp.Znew[k] * zp.Znew[k2] * qq;
+              const double qq = lds_ld(sRes + K + tri_index(K, min(k, k2), max(k, k2)));
+              to += Zi[k2] * qq;
+              tn += zp.Znew[k2] * qq;
             }
           }
+          qo += Zi[k] * to;
+          qn += zp.Znew[k] * tn;
         }
       }
+      const double q_old = cv.yy + qo, q_new = cv.yy + qn;
       const double z_lpdf = zp.pr_old - beta * (q_old * inv_2s2);
       const double z_new_lpdf = zp.pr_new - beta * (q_new * inv_2s2);
       double acceptance = z_new_lpdf - z_lpdf + zp.lpo - zp.lpn;
@@ -707,8 +767,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   }
   CT();
 #ifdef BFMMM_TIMELINE
-  if (blockIdx.x == 8 && threadIdx.x == 0) for (int x = 0; x + 1 < ci_; ++x) c.dyn->stamps[32 + x] = ct_[x + 1] - ct_[x];
-  if (blockIdx.x == 10 && threadIdx.x == 0) { const int sl_[4] = {27, 29, 31, 37}; for (int x = 0; x + 1 < ci_ && x < 4; ++x) c.dyn->stamps[sl_[x]] = ct_[x + 1] - ct_[x]; }
+  if (threadIdx.x == 0 && zti_ < ZTN) for (int x = 0; x + 1 < ci_ && x < 8; ++x) g_zphase[8 * zti_ + x] = ct_[x + 1] - ct_[x];
 #endif
   if (lp == 0) sRss[grp] = rss;
   if (fuse_z && lp < KMAX) sLog[grp * KMAX + lp] = (lp < K) ? logz_mine : 0.0;
@@ -739,6 +798,14 @@ constexpr bool chi_exact_built() { return (BW == 3 && (!CV || L == 32)) || (BW =
 // The 120 exact instances of k_curve_chi are compiled in a translation unit of their own (kernels_curve_exact.hip includes this
 // file with BFMMM_CURVE_EXACT_TU defined and gets the kernels plus the two functions below; this file then holds everything else),
 // so that the two halves build side by side.  The diagnostic timeline build keeps one unit: its trace arrays are device globals.
+inline int ablate_bits() {
+#ifdef BFMMM_ABLATE
+  static const int v = getenv("BFMMM_ABLATE") ? (atoi(getenv("BFMMM_ABLATE")) << 8) : 0;
+  return v;
+#else
+  return 0;
+#endif
+}
 template <int BW, int L, bool CV>
 bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mode);      // (built combinations only: chi_exact_built)
 template <int BW, int L, bool CV>
@@ -750,7 +817,7 @@ bool launch_chi_exact(const Ctx& c, int nblk, size_t lds, hipStream_t st, int mo
   static_assert(chi_exact_built<BW, L, CV>(), "not on the list");
 #define X(k, m)                                                                                                \
   if (c.d.K == k && c.d.M == m) {                                                                              \
-    hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true, k, m>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, mode);     \
+    hipLaunchKernelGGL((k_curve_chi<BW, L, CV, true, k, m>), dim3(nblk + 8, 1, c.nch), dim3(256), lds, st, c, mode | ablate_bits());     \
     return true;                                                                                               \
   }
   BFMMM_CHI_EXACT(X)
@@ -822,8 +889,8 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
   size_t lds;
   const int TW = c.d.mv ? 1 : 2;
-  if (which == 0) lds = nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 48 + tileE);
-  else lds = nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 4 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
+  if (which == 0) lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 48 + tileE);
+  else lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 4 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
   if (which == 1 || (do_update & 2)) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch (k_curve_chi, lean k_curve_z)
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;

@@ -96,6 +96,29 @@ __device__ __forceinline__ DynHead dyn_head(const Dyn* dyn) {
 }
 #endif
 
+// The same head (and pi) for the kernels whose workgroups all start together and all read it first (k_curve_z, k_curve_chi: 512
+// workgroups x 4 waves x 7 + K uniform loads of ONE line -- 1800 requests per XCD for a line that seven of the eight L2s do not
+// hold, and every other load of the wave queues behind them, in issue order): ONE load instruction per wave (lane j takes dword
+// j of the first 192 bytes: head, rss, loglik, pi), staged in LDS before the workgroup's first barrier, read from there.
+constexpr int DYN_LDS_DOUBLES = 24;
+static_assert(offsetof(Dyn, pi) == 128 && sizeof(double) * KMAX == 64, "dwords 0 .. 47 of Dyn: head, rss, loglik, pi");
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t dyn_head_fetch(const Dyn* dyn) {
+  return reinterpret_cast<const uint32_t*>(dyn)[min((int)(threadIdx.x & 63), 47)];
+}
+__device__ __forceinline__ void dyn_head_stage(double* sDyn, uint32_t w) {      // (every wave stores the same 48 words)
+  reinterpret_cast<uint32_t*>(sDyn)[min((int)(threadIdx.x & 63), 47)] = w;
+}
+__device__ __forceinline__ DynHead dyn_head_lds(const double* sDyn) {           // sDyn: 16-byte aligned
+  union U { DynHead h; int4 q[7]; __device__ U() {} } u;
+  const int4* p = reinterpret_cast<const int4*>(sDyn);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) u.q[j] = p[j];
+  return u.h;
+}
+__device__ __forceinline__ const double* dyn_pi_lds(const double* sDyn) { return sDyn + 16; }
+#endif
+
 struct Dims {
   int n, K, P, M, D;
   int BW;               // band half-width of G_i (= spline degree; 0 for the multivariate model)

@@ -303,8 +303,41 @@ __device__ inline void job_hyper_draws(const Ctx& c, int first) {
   c.gstd[e] = v;
 }
 
-constexpr int HYPER_LDS_DOUBLES = 4 * KMAX * 16 + KMAX * 2 * 6 + KMAX + 2 + 2 * KMAX * PMAX;
+constexpr int HYPER_LDS_DOUBLES = 5 * KMAX * 16 + KMAX * 2 * 6 + KMAX + 2 + 2 * KMAX * PMAX + (2 * BWMAX + 1) * PMAX;
 
+// delta recursion of one cluster (UpdateDelta.h:28-57) on registers: the old delta_km, S_km and the standard gamma variates are
+// read from LDS up front (MT of each, clamped), so the O(M^2) chain of products is a chain of arithmetic only -- with the values
+// read from LDS inside the loops every one of its M (M + 1) / 2 steps paid an LDS round trip.  tilde-tau products are carried
+// along instead of rebuilt: the multiplication order is the reference's (UpdateDelta.h:30-37, 47-54), the work O(M^2) not O(M^3).
+template <int MT>
+__device__ inline void delta_recursion(double* dk, const double* sk, const double* gd, double* tp, int M, bool do_delta) {
+  double dv[MT], sv[MT], gv[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) { const int mc = min(m, M - 1); dv[m] = dk[mc]; sv[m] = sk[mc]; gv[m] = gd[mc]; }
+  if (do_delta) {
+    double pre = 1.0;                                  // prod_{nn < i} delta_new(k, nn)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      if (i < M) {
+        double tt = pre;                               // prod_{nn <= m, nn != i} delta(k, nn), m = i
+        double param2 = 1.0 + 0.5 * tt * sv[i];
+#pragma unroll
+        for (int m = i + 1; m < MT; ++m)
+          if (m < M) { tt *= dv[m]; param2 += 0.5 * tt * sv[m]; }
+        dv[i] = gv[i] * (1.0 / param2);
+        pre *= dv[i];
+      }
+  }
+  double tt = 1.0;                                     // tilde-tau(k, j) = prod_{j2 <= j} delta(k, j2), UpdateGamma.h:26-28
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+    if (m < M) { tt *= dv[m]; tp[m] = tt; dk[m] = dv[m]; }
+}
+
+// One workgroup; a chain of dependent steps, so it is laid out for latency: EVERY global operand the job needs is requested
+// before the first one is waited for (one round trip to memory instead of one per phase: S_km inputs, nu, delta, the penalty band,
+// the A cells, the gamma-scaling inputs, the variates drawn ahead by job_hyper_draws), the phases between run on LDS and
+// registers, and the chain slots are written from the values at hand instead of being read back from the state arrays.
 __device__ inline void job_hyper(const Ctx& c) {
   // scratch carved from the host kernel's dynamic LDS (the job's workgroup does not use it otherwise; the launcher
   // guarantees HYPER_LDS_DOUBLES): no static LDS, so the job does not lower the occupancy of the curve workgroups
@@ -313,28 +346,93 @@ __device__ inline void job_hyper(const Ctx& c) {
   double* dl = Skm + KMAX * 16;       // KMAX * 16
   double* lgd = dl + KMAX * 16;       // KMAX * 16
   double* tpre = lgd + KMAX * 16;     // KMAX * 16
-  double* aw = tpre + KMAX * 16;      // KMAX * 2 * 6
-  double* slog = aw + KMAX * 2 * 6;   // KMAX (+2 pad)
+  double* gDs = tpre + KMAX * 16;     // KMAX * 16
+  double* aw = gDs + KMAX * 16;       // KMAX * 2 * 6
+  double* slog = aw + KMAX * 2 * 6;   // KMAX (+2 pad; unused now, kept for the layout)
   double* qrow = slog + KMAX + 2;     // KMAX * PMAX
   double* snu = qrow + KMAX * PMAX;   // KMAX * PMAX
+  double* sPb = snu + KMAX * PMAX;    // (2 BWMAX + 1) * PMAX: the band of the penalty, [u][p] = P[p][p - BWP + u]
   const Dims& d = c.d;
   const int P = d.P, K = d.K, M = d.M, MD = d.MD, tid = threadIdx.x;
   Dyn* dyn = c.dyn;
-  const uint32_t mask = c.mask, slot = dyn->slot_hyper;
+  const uint32_t mask = c.mask;
   const bool phi_on = MD > 1;
   const bool do_delta = (mask & U_DELTA) && phi_on, do_A = (mask & U_A) && phi_on, do_gamma = (mask & U_GAMMA) && phi_on;
   const bool do_tau = (mask & U_TAU) != 0;
-  const int nG = K * P * M;
+  const int Mc = max(M, 1);
+  const int nG = K * P * M, nGc = max(nG, 1);
   const double* gGam = c.gstd;
   const double* gD = c.gstd + nG;
   const double* gT = gD + K * M;
   const double* aProp = gT + K;
   const double* aUnif = aProp + 2 * K;
   const double* aTerm = c.gstd + hyper_gstd_count(d) + 1;      // 4 per cell: logGamma / log at cur, at the proposal
-  // ---- phase 1: S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2 (8 lanes per (k, m), all loads of a lane in flight
-  //      together) ; nu staged for nu_k' P nu_k ----
+  // ================= all global loads (clamped addresses, no branches: the requests are issued back to back) =================
+  const uint32_t slot = dyn->slot_hyper;
+  // S_km = sum_p gamma_old(k,p,m) phi(k,p,m)^2: 8 lanes per (k, m); first 32 (k, m) here, the rest (K M > 32) in the loop below
+  double s_ph[8], s_gm[8];
+  {
+    const int km = min(tid >> 3, max(K * M - 1, 0)), q = tid & 7;
+    const int k = km / Mc, m = km - k * Mc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = min(q + 8 * u, P - 1);
+      s_ph[u] = c.theta[(size_t)(k * (M + 1) + min(m + 1, M)) * P + p];
+      s_gm[u] = c.gamma[min(k + K * (p + P * m), nGc - 1)];
+    }
+  }
+  // nu_k for nu_k' P nu_k, the old delta and its variates (staged in LDS for the K lanes of the recursion)
+  const int KP = K * P;
+  const int e0 = min(tid, KP - 1), k0 = e0 / P, p0 = e0 - k0 * P;
+  const double nu0 = c.theta[(size_t)(k0 * (M + 1)) * P + p0];
+  const int e1 = min(tid + 256, KP - 1), k1 = e1 / P, p1 = e1 - k1 * P;
+  const double nu1 = c.theta[(size_t)(k1 * (M + 1)) * P + p1];
+  const int kmc = min(tid, max(K * M - 1, 0)), kd = kmc / Mc, md = kmc - kd * Mc;
+  const double dl0 = c.delta[kd + (size_t)K * md];
+  const double gd0 = gD[kmc];
+  // the band of the penalty (the wide-band case reads whole rows below): (2 BWMAX + 1) P <= 704 entries, three per thread, staged in LDS
+  constexpr int NPB = ((2 * BWMAX + 1) * PMAX + 255) / 256;
+  double pb[NPB];
+#pragma unroll
+  for (int r = 0; r < NPB; ++r) {
+    const int idx = min(tid + 256 * r, (2 * BWMAX + 1) * P - 1), u = idx / P, p = idx - u * P;
+    pb[r] = c.Pmat[p + (size_t)P * min(max(p - d.BWP + u, 0), P - 1)];
+  }
+  // A: the term threads (4 per cell) and the accept threads (1 per cell)
+  const int cellT = min(tid >> 2, 2 * K - 1), jobT = tid & 3, jT = cellT / 2, iT = cellT - 2 * jT;
+  const double curT = c.Aa[jT + (size_t)K * iT], naT = aProp[cellT];
+  const double lgaT = aTerm[cellT * 4 + 2 * (jobT & 1)], laT = aTerm[cellT * 4 + 2 * (jobT & 1) + 1];      // drawn ahead (job_hyper_draws)
+  const int cellA = min(tid, 2 * K - 1), idxA = (cellA >> 1) + K * (cellA & 1);
+  const double curA = c.Aa[idxA], naA = aProp[cellA], unA = aUnif[cellA];
+  const int kt = min(max(tid - 32, 0), K - 1);
+  const double tau_old = dyn->tau[kt], gTk = gT[kt];
+  // gamma scaling: e = (i*P + l)*M + j (reference loop order i, l, j); the first three trips here
+  constexpr int GU = 3;
+  double g_std[GU], g_phi[GU];
+#pragma unroll
+  for (int u = 0; u < GU; ++u) {
+    const int e = min(tid + 256 * u, nGc - 1);
+    const int jj = e % Mc, il = e / Mc, l = il % P, i = il / P;
+    g_std[u] = gGam[e];
+    g_phi[u] = c.theta[(size_t)(i * (M + 1) + min(jj + 1, M)) * P + l];
+  }
+  // ================= phase 1: S_km, staging =================
   if (do_delta) {
-    for (int g0 = 0; g0 < K * M; g0 += 32) {
+    {
+      const int km = tid >> 3, q = tid & 7;
+      const bool on = km < K * M;
+      double acc = 0.0;
+      double pr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[u] = (on && q + 8 * u < P) ? s_gm[u] * (s_ph[u] * s_ph[u]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += pr[u];
+      acc = dpp_add<0xB1>(acc);
+      acc = dpp_add<0x4E>(acc);
+      acc = dpp_add<0x141>(acc);
+      if (on && q == 0) Skm[km] = acc;
+    }
+    for (int g0 = 32; g0 < K * M; g0 += 32) {
       const int km = g0 + (tid >> 3), q = tid & 7;
       const bool on = km < K * M;
       const int k = on ? km / M : 0, m = on ? km - k * M : 0;
@@ -355,13 +453,18 @@ __device__ inline void job_hyper(const Ctx& c) {
       if (on && q == 0) Skm[km] = acc;
     }
   }
-  if (do_tau)
-    for (int e = tid; e < K * P; e += 256) { const int k = e / P, p = e - k * P; snu[e] = c.theta[(size_t)(k * (M + 1)) * P + p]; }
-  if (tid < K * M && tid < KMAX * 16) { const int k = tid / M, m = tid - k * M; dl[k * 16 + m] = c.delta[k + (size_t)K * m]; }
+  if (do_tau) {
+    if (tid < KP) snu[tid] = nu0;
+    if (tid + 256 < KP) snu[tid + 256] = nu1;
+  }
+  if (tid < K * M && tid < KMAX * 16) { dl[kd * 16 + md] = dl0; gDs[kd * 16 + md] = gd0; }
+#pragma unroll
+  for (int r = 0; r < NPB; ++r)
+    if (tid + 256 * r < (2 * BWMAX + 1) * P) sPb[tid + 256 * r] = pb[r];
   __syncthreads();
-  // nu_k' P nu_k : lane (k, p) takes row p of P (batches of 8 independent loads), summed per k in phase 2
+  // nu_k' P nu_k : lane (k, p) takes row p of P, summed per k below
   if (do_tau)
-    for (int e = tid; e < K * P; e += 256) {
+    for (int e = tid; e < KP; e += 256) {
       const int k = e / P, p = e - k * P;
       double s = 0.0;
       if (d.mv) s = snu[e];
@@ -370,77 +473,71 @@ __device__ inline void job_hyper(const Ctx& c) {
       } else {
         // the penalty is banded (half-width BWP, the same assumption the factorisation makes): the other products of
         // row p are exact zeros, so skipping them leaves the sum of UpdateTau.h:26-28 unchanged
-        double pv[2 * BWMAX + 1];
-#pragma unroll
-        for (int u = 0; u < 2 * BWMAX + 1; ++u) pv[u] = c.Pmat[p + (size_t)P * min(max(p - d.BWP + u, 0), P - 1)];
 #pragma unroll
         for (int u = 0; u < 2 * BWMAX + 1; ++u) {
           const int q = p - d.BWP + u;
-          if (u <= 2 * d.BWP && q >= 0 && q < P) s += pv[u] * snu[k * P + q];
+          if (u <= 2 * d.BWP && q >= 0 && q < P) s += sPb[u * P + p] * snu[k * P + q];
         }
       }
       qrow[e] = snu[e] * s;
     }
-  // ---- phase 2: delta recursion (K lanes).  tilde-tau products are carried along instead of rebuilt: the
-  //      multiplication order is the reference's (UpdateDelta.h:30-37, 47-54), the work O(M^2) instead of O(M^3) ----
-  if (tid < K) {
-    const int k = tid;
-    double* dk = dl + k * 16;
-    if (do_delta) {
-      double pre = 1.0;                                // prod_{nn < i} delta_new(k, nn)
-      for (int i = 0; i < M; ++i) {
-        double tt = pre;                               // prod_{nn <= m, nn != i} delta(k, nn), m = i
-        double param2 = 1.0 + 0.5 * tt * Skm[k * M + i];
-        for (int m = i + 1; m < M; ++m) { tt *= dk[m]; param2 += 0.5 * tt * Skm[k * M + m]; }
-        dk[i] = gD[k * M + i] * (1.0 / param2);
-        pre *= dk[i];
+  // ---- phase 2: delta recursion (K lanes) ----
+  if (tid < K && M > 0) {
+    if (M <= 8) delta_recursion<8>(dl + tid * 16, Skm + tid * M, gDs + tid * 16, tpre + tid * 16, M, do_delta);
+    else {      // M > 8: the same recursion on LDS operands (48 more live doubles would spill in the kernels that host this job)
+      double* dk = dl + tid * 16;
+      const double* sk = Skm + tid * M;
+      if (do_delta) {
+        double pre = 1.0;
+        for (int i = 0; i < M; ++i) {
+          double tt = pre;
+          double param2 = 1.0 + 0.5 * tt * sk[i];
+          for (int m = i + 1; m < M; ++m) { tt *= dk[m]; param2 += 0.5 * tt * sk[m]; }
+          dk[i] = gDs[tid * 16 + i] * (1.0 / param2);
+          pre *= dk[i];
+        }
       }
+      double tt = 1.0;
+      for (int m = 0; m < M; ++m) { tt *= dk[m]; tpre[tid * 16 + m] = tt; }
     }
-    double tt = 1.0;                                   // tilde-tau(k, j) = prod_{j2 <= j} delta(k, j2), UpdateGamma.h:26-28
-    for (int m = 0; m < M; ++m) { tt *= dk[m]; tpre[k * 16 + m] = tt; }
   }
   __syncthreads();
-  if (do_tau && tid >= 32 && tid < 32 + K) {
+  if (tid >= 32 && tid < 32 + K) {
     const int k = tid - 32;
-    double qf = 0.0;
-    for (int p = 0; p < P; ++p) qf += qrow[k * P + p];
-    const double b = c.h.beta_nu + (0.5 * qf);
-    const double gg = gT[k] * (1.0 / b);
-    dyn->tau[k] = d.mv ? (1.0 / gg) : gg;
+    double tv = tau_old;
+    if (do_tau) {
+      double qf = 0.0;
+      for (int p = 0; p < P; ++p) qf += qrow[k * P + p];
+      const double b = c.h.beta_nu + (0.5 * qf);
+      const double gg = gTk * (1.0 / b);
+      tv = d.mv ? (1.0 / gg) : gg;
+      dyn->tau[k] = tv;
+    }
+    c.c_tau[slot + (size_t)c.T * k] = tv;
   }
   if (tid < K * M) {
-    const int k = tid / M, m = tid - k * M;
-    if (do_delta) c.delta[k + (size_t)K * m] = dl[k * 16 + m];
-    lgd[k * 16 + m] = log(dl[k * 16 + m]);
+    const double dv = dl[kd * 16 + md];
+    if (do_delta) c.delta[kd + (size_t)K * md] = dv;
+    c.c_delta[(size_t)slot * K * M + kd + (size_t)K * md] = dv;
+    lgd[kd * 16 + md] = log(dv);
   }
-  __syncthreads();
-  if (tid < K) {
-    double sl = 0.0;                                   // sum_{q >= 1} log delta(k, q), used by lpdf_a2
-    for (int q = 1; q < M; ++q) sl += lgd[tid * 16 + q];
-    slog[tid] = sl;
-  }
-  __syncthreads();
-  // ---- phase 3: A terms (4 lanes per cell), gamma scaling ----
-  if (do_A && tid < K * 2 * 4) {
-    const int cell = tid >> 2, job = tid & 3;
-    const int j = cell / 2, i = cell - 2 * j;
-    const bool first = (i == 0);
-    const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
-    const double cur = c.Aa[j + (size_t)K * i], na = aProp[cell];
-    double v;
-    if (job < 2) {
-      const double a = (job == 0) ? cur : na;
-      const double lga = aTerm[cell * 4 + 2 * job], la = aTerm[cell * 4 + 2 * job + 1];     // drawn ahead (job_hyper_draws)
-      if (first) v = -lga + (a - 1) * lgd[j * 16] + (c.h.alpha1l - 1) * la - (a * c.h.beta1l);          // UpdateA.h:17-24
-      else { const double x = M - 1; v = -x * lga + (c.h.alpha2l - 1) * la - (a * c.h.beta2l) + (a - 1) * slog[j]; }   // UpdateA.h:33-44
-    } else {
-      v = (job == 2) ? dtruncnorm_lo_log(cur, na, sd, 0.0) : dtruncnorm_lo_log(na, cur, sd, 0.0);
-    }
-    aw[cell * 6 + 1 + job] = v;
-  }
+  // ---- gamma scaling (needs the tilde-tau products of phase 2) ----
   double* s_gam = c.c_gamma + (size_t)slot * K * P * M;
   if (do_gamma) {
-    for (int e = tid; e < nG; e += 256) {            // e = (i*P + l)*M + j  (reference loop order i, l, j)
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int e = tid + 256 * u;
+      if (e < nG) {
+        const int jj = e % M, il = e / M, l = il % P, i = il / P;
+        const double ph = tpre[i * 16 + jj];
+        const double phi = g_phi[u];
+        const double gnew = g_std[u] * (2 / (c.h.nu_1 + ph * (phi * phi)));
+        const size_t at = i + (size_t)K * (l + (size_t)P * jj);
+        c.gamma[at] = gnew;
+        s_gam[at] = gnew;
+      }
+    }
+    for (int e = tid + 256 * GU; e < nG; e += 256) {
       const int jj = e % M, il = e / M, l = il % P, i = il / P;
       const double ph = tpre[i * 16 + jj];
       const double phi = c.theta[(size_t)(i * (M + 1) + jj + 1) * P + l];
@@ -453,16 +550,40 @@ __device__ inline void job_hyper(const Ctx& c) {
     for (int e = tid; e < nG; e += 256) s_gam[e] = c.gamma[e];
   }
   __syncthreads();
-  // ---- phase 4: A accept; chain slots ----
-  if (do_A && tid < K * 2) {
-    const double* w = aw + tid * 6;
-    const double acc = (w[2] + w[3]) - w[1] - w[4];
-    if (log(aUnif[tid]) < acc) c.Aa[(tid >> 1) + (size_t)K * (tid & 1)] = aProp[tid];
+  // ---- phase 3: A terms (4 lanes per cell) ----
+  if (do_A && tid < K * 2 * 4) {
+    const int cell = tid >> 2, job = tid & 3;
+    const int j = jT;
+    const bool first = (iT == 0);
+    const double sd = first ? (c.h.var_epsilon1 / c.h.beta1l) : (c.h.var_epsilon2 / c.h.beta2l);
+    const double cur = curT, na = naT;
+    double v;
+    if (job < 2) {
+      const double a = (job == 0) ? cur : na;
+      const double lga = lgaT, la = laT;
+      if (first) v = -lga + (a - 1) * lgd[j * 16] + (c.h.alpha1l - 1) * la - (a * c.h.beta1l);          // UpdateA.h:17-24
+      else {
+        double sl = 0.0;                                 // sum_{q >= 1} log delta(k, q), used by lpdf_a2
+        for (int q = 1; q < M; ++q) sl += lgd[j * 16 + q];
+        const double x = M - 1;
+        v = -x * lga + (c.h.alpha2l - 1) * la - (a * c.h.beta2l) + (a - 1) * sl;                         // UpdateA.h:33-44
+      }
+    } else {
+      v = (job == 2) ? dtruncnorm_lo_log(cur, na, sd, 0.0) : dtruncnorm_lo_log(na, cur, sd, 0.0);
+    }
+    aw[cell * 6 + 1 + job] = v;
   }
   __syncthreads();
-  if (tid < K * M) c.c_delta[(size_t)slot * K * M + tid] = c.delta[tid];
-  if (tid < K * 2) c.c_A[(size_t)slot * K * 2 + tid] = c.Aa[tid];
-  if (tid < K) c.c_tau[slot + (size_t)c.T * tid] = dyn->tau[tid];
+  // ---- phase 4: A accept; chain slots ----
+  if (tid < K * 2) {
+    double av = curA;
+    if (do_A) {
+      const double* w = aw + tid * 6;
+      const double acc = (w[2] + w[3]) - w[1] - w[4];
+      if (log(unA) < acc) { av = naA; c.Aa[idxA] = naA; }
+    }
+    c.c_A[(size_t)slot * K * 2 + idxA] = av;
+  }
   // end-of-iteration bookkeeping (when the iteration has no k_loglik): the curve workgroups of this kernel work from the
   // sweep's snapshot (iter_hyper / slot_hyper), so the counters can advance here; the log-likelihood of the finished
   // iteration is reduced by the next kernel that has an idle workgroup (deferred_loglik)

@@ -175,7 +175,8 @@ __device__ inline void job_chi_normals(const Ctx& c, int wg) {
 
 // reads a prepared proposal back (every lane of the curve's group gets all of it) and adds the prior terms
 // sum_k (alpha_3 pi_k - 1) log Z_k of lpdf_z (UpdateMixedMembership.h:20-50) for the current pi / alpha_3
-__device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp, double alpha3, const double* pi) {
+// the loads (issued with the kernel's other global loads) ...
+__device__ inline void z_proposal_fetch(const Ctx& c, int i, ZProposal& zp) {
   const int n = c.d.n, K = c.d.K;
   const double* o = c.zprep + i;
 #pragma unroll
@@ -188,6 +189,10 @@ __device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp, doubl
   }
   const double* s = o + (size_t)n * 3 * K;
   zp.lpn = s[(size_t)2 * n]; zp.lpo = s[(size_t)3 * n]; zp.log_uu = s[(size_t)4 * n];
+}
+// ... and the prior terms, from this iteration's pi / alpha_3 (pi: global or LDS)
+__device__ inline void z_proposal_prior(const Ctx& c, ZProposal& zp, double alpha3, const double* pi) {
+  const int K = c.d.K;
   double piv[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) piv[k] = pi[min(k, K - 1)];
@@ -199,6 +204,10 @@ __device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp, doubl
       pr_new += (alpha3 * piv[k] - 1.0) * zp.ln[k];
     }
   zp.pr_old = pr_old; zp.pr_new = pr_new;
+}
+__device__ inline void z_proposal_load(const Ctx& c, int i, ZProposal& zp, double alpha3, const double* pi) {
+  z_proposal_fetch(c, i, zp);
+  z_proposal_prior(c, zp, alpha3, pi);
 }
 
 }  // namespace bfmmm

@@ -116,7 +116,7 @@ class Sampler:
         n, K, P, M = self.n, self.K, self.P, self.M
         return {"nu": (K, P), "Phi": (K, P, M), "chi": (n, M), "Z": (n, K), "pi": (K,), "alpha_3": (1,),
                 "delta": (K, M), "A": (K, 2), "gamma": (K, P, M), "tau": (K,), "sigma_sq": (1,),
-                "loglik": (1,), "status": (1,), "stamps": (64,), "wgtrace": (3072,), "ztrace": (3072,), "zphase": (4096,), "fct": (8,),
+                "loglik": (1,), "status": (1,), "stamps": (64,), "wgtrace": (3072,), "ztrace": (3 * 8192,), "zphase": (8 * 8192,), "fct": (8,),
                 "eta": (P, self.D, K), "xi": (P, self.D, M, K), "gamma_xi": (P, self.D, M, K),
                 "tau_eta": (K, self.D), "delta_xi": (K, M, self.D), "A_xi": (K, 2, self.D)}[name]
 

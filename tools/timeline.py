@@ -31,6 +31,39 @@ def build(sub="tl", extra="-DBFMMM_TIMELINE"):
     print("built", os.path.join(ROOT, "tools", sub, "libbfmmm_hip.so"))
 
 
+def chi_report(zt_all, zp_all, chains, n):
+    """k_curve_chi, last fused launch: per-workgroup start / end (100 MHz) and phase clocks, by XCC."""
+    gx = n // 8 + 8
+    tot = gx * chains
+    zt, zp = zt_all[:tot], zp_all[:tot]
+    ok = zt[:, 0] > 0
+    bx = np.arange(tot) % gx
+    cur = ok & (bx >= 8)
+    t00 = zt[ok, 0].min()
+    st = (zt[:, 0] - t00) / 100.0
+    en = (zt[:, 2] - t00) / 100.0
+    dur = en - st
+    xcc = (zt[:, 1] // 2**32).astype(int)
+    print("  k_curve_chi (last fused launch): %d curve workgroups, kernel span %.2f us; duration us min %.2f median %.2f p90 %.2f max %.2f; start max %.2f" %
+          (cur.sum(), en[ok].max(), dur[cur].min(), np.median(dur[cur]), np.percentile(dur[cur], 90), dur[cur].max(), st[cur].max()))
+    sj = ok & (bx == 0)
+    print("    scalar-job workgroups: duration median %.2f max %.2f, end max %.2f" % (np.median(dur[sj]), dur[sj].max(), en[sj].max()))
+    names = ["dyn head", "theta", "barrier", "u_m c0 (+record)", "G u, dots", "GS rss", "fused Z"]
+    print("    phase clocks (median per XCC): " + " | ".join(names))
+    for x in range(8):
+        m = cur & (xcc == x)
+        if m.any():
+            med = np.median(zp[m][:, :7], axis=0)
+            print("    XCC %d: %4d wgs, dur median %.2f max %.2f, start median %.2f, end max %.2f | " % (x, m.sum(), np.median(dur[m]), dur[m].max(), np.median(st[m]), en[m].max()) +
+                  " ".join("%6d" % v for v in med))
+    # occupancy over time: workgroups resident, sampled every 0.5 us
+    ts = np.arange(0, en[ok].max(), 0.5)
+    occ = [(int(((st <= t) & (en > t) & cur).sum())) for t in ts]
+    print("    resident curve workgroups every 0.5 us:", occ)
+    # starts per microsecond
+    print("    starts per us:", np.histogram(st[cur], bins=np.arange(0, en[ok].max() + 1, 1.0))[0].tolist())
+
+
 def run(a):
     import bayesfmmm_amd as bf
     from bench import make_config2
@@ -80,28 +113,13 @@ def run(a):
         print("  k_curve_chi workgroup 10 (another XCD) first four phase clocks:", [int(st[q]) for q in (27, 29, 31, 37)])
         print("  k_curve_chi workgroup 8 phase clocks (load+stage | u_m, c0 | G u_m, dots | Gauss-Seidel, rss | fused Z):", [int(x) for x in st[32:37]])
         try:
-            zt = smp.get_state("ztrace").reshape(-1, 3)[:520]
-            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-                np.save(os.path.join(ROOT, "gpurun_out", "chi_ztrace.npy"), zt)
-            t00 = zt[8:, 0].min()
-            dur = (zt[8:, 2] - zt[8:, 0]) / 100.0
-            end = (zt[8:, 2] - t00) / 100.0
-            xcc = (zt[8:, 1] // 2**32).astype(int)
-            hw = zt[8:, 1].astype(np.int64) % 2**32
-            cu = (hw >> 8) & 0xf
-            se = (hw >> 13) & 0x7 if False else (hw >> 12) & 0xf
-            print("  k_curve_chi curve workgroups: duration us min %.2f median %.2f p90 %.2f max %.2f; end us median %.2f max %.2f" %
-                  (dur.min(), np.median(dur), np.percentile(dur, 90), dur.max(), np.median(end), end.max()))
-            for x in range(8):
-                m = xcc == x
-                if m.any():
-                    print("    XCC %d: %3d workgroups, duration median %.2f max %.2f, start median %.2f" % (x, m.sum(), np.median(dur[m]), dur[m].max(), np.median((zt[8:, 0][m] - t00) / 100.0)))
-            slow = np.argsort(-dur)[:8]
-            print("    slowest:", [(int(b), round(float(dur[b]), 2), int(xcc[b]), hex(int(hw[b]))) for b in slow])
-            raw = smp.get_state("stamps")
-            print("    XCC of block 0, last launches (oldest first): k_curve_chi %s | k_sweep_chain %s" %
-                  (format(int(raw[39]), "09x"), format(int(raw[38]), "09x")))
-            print("    scalar-job workgroup 0: duration %.2f us, XCC %d, hw %s" % ((zt[0, 2] - zt[0, 0]) / 100.0, int(zt[0, 1] // 2**32), hex(int(zt[0, 1]) % 2**32)))
+            zt_all = smp.get_state("ztrace").reshape(-1, 3)
+            zp_all = smp.get_state("zphase").reshape(-1, 8)
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and q == 0:
+                np.save(os.path.join(ROOT, "gpurun_out", f"chi_ztrace_{a.chains}.npy"), zt_all)
+                np.save(os.path.join(ROOT, "gpurun_out", f"chi_zphase_{a.chains}.npy"), zp_all)
+            if q == 0:
+                chi_report(zt_all, zp_all, a.chains, len(w["y"]))
         except Exception as e:
             print("  (no ztrace:", e, ")")
         pg = st[40:49]
