@@ -62,14 +62,19 @@ struct Curve {
 
 template <int BW, int LPC>
 struct Tile {
-  // padded row stride, ODD: lane a of a group reads row a in the dot products, and with an even stride the rows fall on
-  // the same LDS banks (stride 64 at BW = 0: every row on the same banks)
-  static constexpr int STR = LPC + 2 * BW + 1;
-  double* base;
-  __device__ inline double* row(int r) const { return base + r * STR + BW; }
+  // Rows of LPC entries with BW zeros on either side (the band products read p - BW .. p + BW), the pads SHARED between
+  // neighbours: [BW zeros][row 0: LPC][gap >= BW zeros][row 1: LPC][gap] ...  The row stride is ODD: lane a of a group reads row a
+  // in the dot products, and with an even stride the rows fall on the same LDS banks (stride 64 at BW = 0: every row on the same
+  // banks).  Shared pads took the stride from LPC + 2 BW + 1 to LPC + BW: with the s row gone as well (k_curve_chi) the config-2
+  // workgroup needs 40 KB instead of 46.8 -- a fourth workgroup per CU.
+  static constexpr int STR = ((LPC + BW) % 2 == 0) ? LPC + BW + 1 : LPC + BW;
+  __host__ __device__ static constexpr int doubles(int rows) { return BW + rows * STR; }
+  double* base;        // the first pad
+  __device__ inline double* row(int r) const { return base + BW + r * STR; }
   __device__ inline void zero_pads(int rows, int lp) const {
-    for (int q = lp; q < 2 * BW; q += LPC)      // (a wide band has more pad entries than a 32-lane group has lanes)
-      for (int r = 0; r < rows; ++r) base[r * STR + ((q < BW) ? q : (LPC + q))] = 0.0;
+    for (int q = lp; q < BW; q += LPC) base[q] = 0.0;
+    for (int q = lp; q < STR - LPC; q += LPC)      // (a wide band has more pad entries than a 32-lane group has lanes)
+      for (int r = 0; r < rows; ++r) base[BW + r * STR + LPC + q] = 0.0;
   }
 };
 
@@ -156,10 +161,10 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
   // multivariate model: G_i = I, so G u = u and the GU tile is the U tile (one tile less: a third workgroup per CU)
   const int TW = d.mv ? 1 : 2;
-  const int per_group = (TW * K + 3) * T::STR + MMAX + 48;      // (48: the K + K (K + 1) / 2 <= 44 quadratic forms)
+  const int per_group = T::doubles(TW * K + 3) + MMAX + 48;      // (48: the K + K (K + 1) / 2 <= 44 quadratic forms)
   double* gbase = sYp + GPB + (size_t)grp * per_group;
   T tU{gbase}, tG{gbase + (TW - 1) * K * T::STR}, tS{gbase + TW * K * T::STR};     // tS rows: 0 = s, 1 = o, 2 = G o
-  double* sChi = gbase + (TW * K + 3) * T::STR;
+  double* sChi = gbase + T::doubles(TW * K + 3);
   double* sRes = sChi + MMAX;
   const int i = blk * GPB + grp;
   const bool valid = i < n;
@@ -469,22 +474,21 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   const int D = COV ? d.D : 0;
   const int nth = K * (M + 1) * P;
   const int Mu = (do_update && MD > 1) ? M : 0;     // number of u_m vectors needed
-  const int ntask = Mu * (Mu + 1) / 2 + Mu + 2;
+  const int ntask = Mu * (Mu + 1) / 2 + Mu + 1;
   double* sDyn = smem;                              // the head of Dyn and pi (model.hpp: dyn_head_fetch)
   double* sTh = sDyn + DYN_LDS_DOUBLES;
   double* sThX = sTh + nth;
   double* sRss = sThX + (size_t)nth * D;            // GPB
   double* sLog = sRss + GPB;                        // GPB*KMAX (fused Z: block partial of sum_i log Z_ik)
   const int grp = threadIdx.x / LPC, lp = threadIdx.x % LPC;
-  const int RT = max(M, K);                          // rows of the U / GU tiles (the fused Z update needs K of them)
-  const int nres = max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2);
+  const int RT = max(M, K + 1);                      // rows of the U / GU tiles (the fused Z update needs K of them, and one of U's for s)
+  const int nres = max(M * (M + 1) / 2 + M + 1, K + K * (K + 1) / 2);
   const int TW = d.mv ? 1 : 2;                       // multivariate model: G u = u, the GU tile is the U tile
-  const int per_group = (TW * RT + 3) * T::STR + 4 * M + 2 + nres;
+  const int per_group = T::doubles(TW * RT + 2) + 3 * M + 1 + nres;
   double* gbase = sLog + GPB * KMAX + (size_t)grp * per_group;
-  T tU{gbase}, tG{gbase + (TW - 1) * RT * T::STR}, tX{gbase + TW * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0, 2 = s
-  double* sChi = gbase + (TW * RT + 3) * T::STR;      // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
-  double* sZn = sChi + M + 1;
-  double* sWq = sZn + M + 1;                         // c1_m, then c3_m: the folded constants of the chi update (sZn: unused, kept for the layout)
+  T tU{gbase}, tG{gbase + (TW - 1) * RT * T::STR}, tX{gbase + TW * RT * T::STR};   // tX rows: 0 = c0, 1 = s - G c0
+  double* sChi = gbase + T::doubles(TW * RT + 2);     // M + 1 entries ([M] = 0: pad of the fused Z update's 2-unrolled loop)
+  double* sWq = sChi + M + 1;                        // c1_m, then c3_m: the folded constants of the chi update
   double* sRes = sWq + 2 * M;
   const int i = blk * GPB + grp;
   const bool valid = i < n;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
-    tU.zero_pads(TW * RT + 3, lp);
+    tU.zero_pads(TW * RT + 2, lp);
     if (lp <= M) sChi[lp] = chi_l;
   }
   // (not __syncthreads(): its fence waits for every outstanding load -- the record included.  Only the LDS stores above are published.)
@@ -581,7 +585,9 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       }
     }
     tX.row(0)[lp] = cf;
-    tX.row(2)[lp] = cv.s;                            // (first use of the record)
+    // c0's: the one quadratic form against s of this kernel's chi part -- a sum over the lanes instead of a task over an s row
+    // (the row is 6 % of the workgroup's LDS: the fourth workgroup per CU).  (first use of the record)
+    const double c0s = group_sum<LPC>(cf * cv.s);
     __builtin_amdgcn_wave_barrier();
     CT();
     const double g0 = cv.matvec(tX.row(0), lp);
@@ -589,8 +595,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     if (!d.mv)
       for (int m = 0; m < Mu; ++m) tG.row(m)[lp] = cv.matvec(tU.row(m), lp);
     __builtin_amdgcn_wave_barrier();
-    // tasks: [0, Mu(Mu+1)/2): A_{m,m2} = u_m' G u_m2 (m <= m2);  then Mu of b_m = u_m'(s - G c0);
-    //        then  c0's  and  c0'(s - G c0)
+    // tasks: [0, Mu(Mu+1)/2): A_{m,m2} = u_m' G u_m2 (m <= m2);  then Mu of b_m = u_m'(s - G c0);  then  c0'(s - G c0)
     const int nA = Mu * (Mu + 1) / 2;
     for (int q = lp; q < ntask; q += LPC) {
       const double* ra = tX.row(0);
@@ -601,8 +606,6 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
         ra = tU.row(a); rb = tG.row(a + rem);
       } else if (q < nA + Mu) {
         ra = tU.row(q - nA);
-      } else if (q == nA + Mu) {
-        rb = tX.row(2);
       }
       sRes[q] = dot_lds<LPC>(ra, rb);
     }
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     if (abl & 8) return;
 #endif
     // rss at c0:  yy - 2 c0's + c0'G c0 = yy - c0's - c0'(s - G c0)
-    rss = cv.yy - sRes[nA + Mu] - sRes[nA + Mu + 1];
+    rss = cv.yy - c0s - sRes[nA + Mu];
     if (Mu > 0) {
       // chi_m <- W_m w + sqrt(W_m) z_m,  W_m = 1 / (1 + A_mm beta / sigma^2),  w = (r_m + chi_m A_mm) beta / sigma^2,
       // r_m = b_m - sum_{m2 < m} A_{m2,m} dl_m2  (UpdateChi.h:40-59 in Gram form).  Everything but r_m is known before the
@@ -712,6 +715,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
 #pragma unroll
       for (int k = 0; k < KT; ++k)
         if (k < K) tU.row(k)[lp] = uk[k];
+      tU.row(K)[lp] = cv.s;                            // (row K of the U tile is free now: RT >= K + 1)
       __builtin_amdgcn_wave_barrier();
       if (!d.mv)
         for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       const int nzt = K + K * (K + 1) / 2;       // q < K: a_q = u_q's ;  q >= K: pair (k, k2), k <= k2: u_k' G u_k2
       for (int q = lp; q < nzt; q += LPC) {
         const double* ra = tU.row(min(q, K - 1));
-        const double* rb = tX.row(2);
+        const double* rb = tU.row(K);
         if (q >= K) {
           int a = 0, rem = q - K;
           while (rem >= K - a) { rem -= K - a; ++a; }
@@ -883,14 +887,14 @@ static void launch_curve_bw(const Ctx& c, int which, int do_update, hipStream_t 
   const int GPB = 256 / LPC;
   const int nblk = (c.d.n + GPB - 1) / GPB;
   const int K = c.d.K, M = c.d.M;
-  const int STR = LPC + 2 * BW + 1;
+  const int STR = ((LPC + BW) % 2 == 0) ? LPC + BW + 1 : LPC + BW;      // Tile<BW, LPC>::STR
   const int D = c.d.D;
   const size_t nth = (size_t)K * (M + 1) * c.d.P;
   const size_t tileE = 0;      // (the covariate-adjusted rows are no longer materialised per curve)
   size_t lds;
   const int TW = c.d.mv ? 1 : 2;
-  if (which == 0) lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * ((TW * K + 3) * STR + MMAX + 48 + tileE);
-  else lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * ((TW * std::max(M, K) + 3) * STR + 4 * M + 2 + std::max(M * (M + 1) / 2 + M + 2, K + K * (K + 1) / 2) + tileE);
+  if (which == 0) lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB * KMAX + GPB + (size_t)GPB * (BW + (TW * K + 3) * STR + MMAX + 48 + tileE);
+  else lds = DYN_LDS_DOUBLES + nth * (1 + D) + GPB + GPB * KMAX + (size_t)GPB * (BW + (TW * std::max(M, K + 1) + 2) * STR + 3 * M + 1 + std::max(M * (M + 1) / 2 + M + 1, K + K * (K + 1) / 2) + tileE);
   if (which == 1 || (do_update & 2)) lds = std::max(lds, (size_t)HYPER_LDS_DOUBLES);      // the scalar job's scratch (k_curve_chi, lean k_curve_z)
   lds = (lds + 8) * sizeof(double);
   const bool cov = D > 0;

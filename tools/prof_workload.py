@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--M", type=int, default=6, help="eigenfunctions of the warm / nu_z workloads (config 2: 6)")
     ap.add_argument("--eager", action="store_true", help="event-bracketed eager launches instead of graph replay")
     a = ap.parse_args()
     import bayesfmmm_amd as bf
@@ -30,7 +31,7 @@ def main():
     T = a.steps + a.warmup
     pcz = False
     if a.workload in ("warm", "nu_z", "theta"):
-        w = make_config2(n=a.n, n_i=(100 if a.n <= 4096 else 24))
+        w = make_config2(n=a.n, n_i=(100 if a.n <= 4096 else 24), M=a.M)
         cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=w["K"], n_eigen=w["M"], basis_degree=3, tot_mcmc_iters=T)
         smp = bf.Sampler(cfg, w["y"], w["t"], w["internal_knots"], w["boundary_knots"], n_chains=a.chains)
         mask = {"warm": S.SWEEP_WARM, "nu_z": S.SWEEP_NU_Z, "theta": S.SWEEP_THETA}[a.workload]
