@@ -771,6 +771,7 @@ __global__ void k_run_begin(Ctx c0, uint32_t first_iter, uint32_t slot_base, uin
   dyn->beta = beta; dyn->status = 0;
   dyn->pend_dir = -1;
   dyn->ll_pending = 0;
+  dyn->hyper_pending = 0;
   if (state_dirty) { dyn->zprep_valid = 0; dyn->piprep_valid = 0; }
   dyn->znorm_valid = 0;
   dyn->pi_done = 0;
@@ -899,6 +900,13 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   // without covariates the iteration ends with k_curve_chi: its scalar-job workgroup advances the counters and the
   // log-likelihood is reduced by the next iteration's k_pair_gram job (one kernel boundary less per iteration)
   c.defer_loglik = (c.d.D == 0) ? 1 : 0;
+  // single chain: the scalar job of k_curve_chi rides the next iteration's k_pair_gram instead (its grid has NKS - 1 idle extra
+  // workgroups); the run's flush kernel runs the last one.  BFMMM_DEFER_HYPER=0 / 1 overrides (diagnostic).
+  {
+    static const int env = getenv("BFMMM_DEFER_HYPER") ? atoi(getenv("BFMMM_DEFER_HYPER")) : -1;
+    const bool can = c.defer_loglik && plan.pg && plan.chi && h->nch == 1 && NKS >= 2 && !want_pack(1);
+    c.defer_hyper = (can && (env < 0 || env != 0)) ? 1 : 0;
+  }
   c.ll_use_part = plan.use_rss_part;
   h->last_md = MD;
   if (!prepare_only) {

@@ -422,7 +422,15 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
 #ifdef BFMMM_ABLATE
     if ((mode >> 8) & 4) return;
 #endif
-    job_hyper(c);
+    // (single chain: 513 workgroups on 512 slots -- the two curve workgroups that share this one's CU ended 1.5 us after all the
+    //  others, and with them the kernel; with Ctx::defer_hyper the job itself rides the next k_pair_gram, whose grid has idle
+    //  extra workgroups, and only the counters advance here)
+    if (c.defer_hyper) {
+      job_hyper_counters(c);
+      if (threadIdx.x == 0) c.dyn->hyper_pending = 1u;
+    } else {
+      job_hyper(c);
+    }
     TSTAMP(c, 15);
     return;
   }

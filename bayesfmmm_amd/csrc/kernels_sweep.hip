@@ -99,6 +99,15 @@ __global__ __launch_bounds__(PG_THREADS) void k_pair_gram(Ctx c0, int KS, int nk
       const Ctx c = chain_ctx(c0, (unsigned)ks);
       job_pi_alpha(c);
       TSTAMP(c, 46);
+    } else if (ks >= nch && ks < 2 * nch && threadIdx.x < 256) {
+      // the previous iteration's scalar job (delta, A, gamma, tau), left pending by k_curve_chi (Ctx::defer_hyper): its results are
+      // first read by k_factor, two kernels on
+      const Ctx c = chain_ctx(c0, (unsigned)(ks - nch));
+      if (c.dyn->hyper_pending) {
+        job_hyper(c, false);
+        __syncthreads();
+        if (threadIdx.x == 0) c.dyn->hyper_pending = 0u;
+      }
     }
     return;
   }
@@ -1983,6 +1992,11 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c0, int use_rss_part, int r_
 __global__ __launch_bounds__(256) void k_loglik_flush(Ctx c0, uint32_t* status_out) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   __shared__ double red[256];
+  if (c.dyn->hyper_pending) {        // the last iteration's scalar job (Ctx::defer_hyper); dynamic LDS: HYPER_LDS_DOUBLES
+    job_hyper(c, false);
+    __syncthreads();
+    if (threadIdx.x == 0) c.dyn->hyper_pending = 0u;
+  }
   if (c.dyn->ll_pending) deferred_loglik(c, red);
   if (status_out && threadIdx.x == 0) {
     __hip_atomic_store(&status_out[blockIdx.z], c.dyn->status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2010,7 +2024,7 @@ void launch_pair_gram(const Ctx& c, int do_pg, int NKS, int KS, hipStream_t st) 
   int G = 1;
   if (c.nch > 1 && d.D == 0 && d.RT < 8)      // (with eight or more row tiles per chain the waves are busy chain by chain)
     while (G < c.nch && lds_doubles(G + 1) * sizeof(double) <= 144 * 1024 && (size_t)(G + 1) * ncw * KS <= 12 * 512) ++G;
-  const size_t lds = std::max(lds_doubles(G), (size_t)PI_ALPHA_LDS_DOUBLES) * sizeof(double);
+  const size_t lds = std::max(lds_doubles(G), (size_t)std::max(PI_ALPHA_LDS_DOUBLES, HYPER_LDS_DOUBLES)) * sizeof(double);
   if (c.nch > 1 && G > 1) hipLaunchKernelGGL((k_pair_gram<true, true>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, G);
   else if (c.nch > 1) hipLaunchKernelGGL((k_pair_gram<true, false>), dim3(d.CTG + 2, do_pg ? std::max(NKS, c.nch) : c.nch, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
   else hipLaunchKernelGGL((k_pair_gram<false, false>), dim3(d.CTG + 2, do_pg ? NKS : 1, 1), dim3(PG_THREADS), lds, st, c, KS, NKS, do_pg, 1);
@@ -2131,7 +2145,9 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
   return 0;
 }
 
-void launch_loglik_flush(const Ctx& c, hipStream_t st, uint32_t* status_out) { hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), 0, st, c, status_out); }
+void launch_loglik_flush(const Ctx& c, hipStream_t st, uint32_t* status_out) {
+  hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), (size_t)HYPER_LDS_DOUBLES * sizeof(double), st, c, status_out);
+}
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
   hipLaunchKernelGGL(k_loglik, dim3(1, 1, c.nch), dim3(256), 0, st, c, use_rss_part, r_stored);

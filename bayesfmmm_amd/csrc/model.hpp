@@ -64,7 +64,7 @@ struct Dyn {
   double pi[KMAX];
   double tau[KMAX];
   uint32_t pi_done;     // iteration + 1 whose pi / alpha_3 job has finished (the job as a workgroup of k_factor: Ctx::pi_in_factor)
-  uint32_t pad_pi_;
+  uint32_t hyper_pending;   // the scalar job (delta, A, gamma, tau) of the finished iteration is still to run (Ctx::defer_hyper)
   unsigned long long stamps[64];   // diagnostic kernel timeline (-DBFMMM_TIMELINE), 100 MHz wall clock
 };
 
@@ -197,6 +197,8 @@ struct Ctx {
   double* delta_cur;            // P + 1           theta_new - theta_old of the last step (pending on c_i, g_i)
   int pi_in_factor;             // the pi / alpha_3 job of the iteration is a workgroup of k_factor (batches on the packed pair-Gram path)
   int defer_loglik;             // the iteration has no k_loglik: bookkeeping in job_hyper, reduction in the next k_pair_gram
+  int defer_hyper;              // k_curve_chi's scalar-job workgroup only advances the counters; the job itself runs as an extra
+                                // workgroup of the NEXT k_pair_gram (or of the flush kernel at the end of a run)
   int ll_use_part;              // (deferred) log-likelihood from the per-curve residual partial sums
   int covariance_adj;           // Xi block on (BFMMM.h:4602 vs :4067)
   int A2;                       // eta / xi directions: K*D (+ K*M*D)

@@ -338,7 +338,21 @@ __device__ inline void delta_recursion(double* dk, const double* sk, const doubl
 // before the first one is waited for (one round trip to memory instead of one per phase: S_km inputs, nu, delta, the penalty band,
 // the A cells, the gamma-scaling inputs, the variates drawn ahead by job_hyper_draws), the phases between run on LDS and
 // registers, and the chain slots are written from the values at hand instead of being read back from the state arrays.
-__device__ inline void job_hyper(const Ctx& c) {
+// end-of-iteration bookkeeping (when the iteration has no k_loglik): the curve workgroups of k_curve_chi work from the sweep's
+// snapshot (iter_hyper / slot_hyper), so the counters can advance beside them; the log-likelihood of the finished iteration is
+// reduced by the next kernel that has an idle workgroup (deferred_loglik)
+__device__ inline void job_hyper_counters(const Ctx& c) {
+  Dyn* dyn = c.dyn;
+  if (c.defer_loglik && threadIdx.x == 0) {
+    dyn->ll_slot = dyn->slot_hyper;
+    dyn->ll_use_part = (uint32_t)c.ll_use_part;
+    dyn->ll_pending = 1u;
+    dyn->iter = dyn->iter_hyper + 1u;
+    dyn->slot = dyn->iter_hyper + 1u - dyn->slot_base;
+  }
+}
+
+__device__ inline void job_hyper(const Ctx& c, bool counters = true) {
   // scratch carved from the host kernel's dynamic LDS (the job's workgroup does not use it otherwise; the launcher
   // guarantees HYPER_LDS_DOUBLES): no static LDS, so the job does not lower the occupancy of the curve workgroups
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -584,16 +598,7 @@ __device__ inline void job_hyper(const Ctx& c) {
     }
     c.c_A[(size_t)slot * K * 2 + idxA] = av;
   }
-  // end-of-iteration bookkeeping (when the iteration has no k_loglik): the curve workgroups of this kernel work from the
-  // sweep's snapshot (iter_hyper / slot_hyper), so the counters can advance here; the log-likelihood of the finished
-  // iteration is reduced by the next kernel that has an idle workgroup (deferred_loglik)
-  if (c.defer_loglik && tid == 0) {
-    dyn->ll_slot = slot;
-    dyn->ll_use_part = (uint32_t)c.ll_use_part;
-    dyn->ll_pending = 1u;
-    dyn->iter = dyn->iter_hyper + 1u;
-    dyn->slot = dyn->iter_hyper + 1u - dyn->slot_base;
-  }
+  if (counters) job_hyper_counters(c);
 }
 
 }  // namespace bfmmm

@@ -88,3 +88,32 @@ def test_prepared_multivariate_run_is_bit_identical():
         smp.close()
     for nm in NAMES:
         np.testing.assert_array_equal(outs[0][nm], outs[1][nm], err_msg=nm)
+
+
+def test_run_in_pieces_is_bit_identical_and_state_is_current_between_calls():
+    """A single chain leaves the scalar job (delta, A, gamma, tau) of an iteration to an idle workgroup of the NEXT iteration's
+    k_pair_gram (Ctx::defer_hyper); the run's closing kernel runs the last one.  So: (a) the chain of one 37-iteration call equals
+    that of calls of 12 + 1 + 24 iterations, bit for bit; (b) the state read between the calls is the state of the last stored
+    slot -- nothing is left pending when bfmmm_run returns."""
+    import bayesfmmm_amd as bf
+    S = bf.sampler
+    sim = simulate_functional(n=77, M=2, sigma_sq=0.01, seed=17, D=1)
+    T = 37
+    outs = []
+    for pieces in ((T,), (12, 1, 24)):
+        cfg = bf.default_config(model=bf.MODEL_FUNCTIONAL, K=sim["K"], n_eigen=sim["M"], basis_degree=3, tot_mcmc_iters=T)
+        smp = bf.Sampler(cfg, sim["y"], sim["t"], sim["internal_knots"], sim["boundary_knots"], n_chains=1)
+        smp.set_state(**_state(sim, np.random.default_rng(50)))
+        done = 0
+        for cnt in pieces:
+            smp.run(S.SWEEP_WARM, cnt, first_iter=done, seed=4)
+            done += cnt
+            for nm in ("delta", "A", "gamma", "tau"):
+                ch = np.array(smp.get_chain(nm))
+                last = ch[..., done - 1] if ch.shape[-1] == T else ch[done - 1]
+                np.testing.assert_array_equal(np.array(smp.get_state(nm)).reshape(-1), np.asarray(last).reshape(-1),
+                                              err_msg=f"{nm} after {done} iterations")
+        outs.append({nm: np.array(smp.get_chain(nm)) for nm in NAMES})
+        smp.close()
+    for nm in NAMES:
+        np.testing.assert_array_equal(outs[0][nm], outs[1][nm], err_msg=nm)
