@@ -1992,10 +1992,13 @@ __global__ __launch_bounds__(256) void k_loglik(Ctx c0, int use_rss_part, int r_
 __global__ __launch_bounds__(256) void k_loglik_flush(Ctx c0, uint32_t* status_out) {
   const Ctx c = chain_view(c0);      // chain blockIdx.z of the batch
   __shared__ double red[256];
-  if (c.dyn->hyper_pending) {        // the last iteration's scalar job (Ctx::defer_hyper); dynamic LDS: HYPER_LDS_DOUBLES
-    job_hyper(c, false);
-    __syncthreads();
-    if (threadIdx.x == 0) c.dyn->hyper_pending = 0u;
+  if (blockIdx.x == 1) {             // second workgroup: the last iteration's scalar job (Ctx::defer_hyper), beside the log-likelihood
+    if (c.dyn->hyper_pending) {      // (dynamic LDS: HYPER_LDS_DOUBLES)
+      job_hyper(c, false);
+      __syncthreads();
+      if (threadIdx.x == 0) c.dyn->hyper_pending = 0u;
+    }
+    return;
   }
   if (c.dyn->ll_pending) deferred_loglik(c, red);
   if (status_out && threadIdx.x == 0) {
@@ -2146,7 +2149,7 @@ int launch_sweep(const Ctx& c, hipStream_t st) {
 }
 
 void launch_loglik_flush(const Ctx& c, hipStream_t st, uint32_t* status_out) {
-  hipLaunchKernelGGL(k_loglik_flush, dim3(1, 1, c.nch), dim3(256), (size_t)HYPER_LDS_DOUBLES * sizeof(double), st, c, status_out);
+  hipLaunchKernelGGL(k_loglik_flush, dim3(c.defer_hyper ? 2 : 1, 1, c.nch), dim3(256), (size_t)HYPER_LDS_DOUBLES * sizeof(double), st, c, status_out);
 }
 
 void launch_loglik(const Ctx& c, int use_rss_part, int r_stored, hipStream_t st) {
