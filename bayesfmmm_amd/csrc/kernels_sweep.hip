@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
   // of every chain of a batch are dispatched before any of the short spare jobs (workgroups start in index order)
   const int nch_ = c0.nch;
   const Ctx c = chain_ctx(c0, blockIdx.x % nch_);
-  const int bx = blockIdx.x / nch_, nbx = gridDim.x / nch_;      // job index / number of jobs
+  const int bx = blockIdx.x / nch_;      // job index
   TIMELINE(c, 3);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Dims& d = c.d;
@@ -807,16 +807,22 @@ __global__ __launch_bounds__(256, (BW <= 5) ? 3 : 1) void k_factor(Ctx c0) {
     const int ndraw = (hyper_gstd_count(d) + 1 + 8 * d.K + 255) / 256;
     const int zcw = zprep_curves_per_wg(d.K);
     const int nzp = (c.mask & U_Z) ? (d.n + zcw - 1) / zcw : 0;
+    // Order: draws, then the ONE job that waits (next iteration's pi / alpha_3 tables: it needs this iteration's pi job, which has
+    // a lower workgroup index and is therefore running by the time this one is dispatched -- no deadlock), then the short ones.  It
+    // used to be the LAST workgroup of the grid: in a batch it then started when everything else had been dispatched (21 us into
+    // the kernel for eight chains) and its 5.5 us were the kernel's tail.
+    const int npi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;
+    const int sb = bx - nF;
 #ifdef BFMMM_TIMELINE
-    const int sb_ = bx - nF;       // one workgroup of each kind of spare job: start / end stamps 56 .. 63
-    const int kind_ = sb_ < ndraw ? 0 : sb_ < ndraw + nzp ? 1 : (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) ? 2 : 3;
-    const bool first_ = (sb_ == 0) || (sb_ == ndraw && nzp > 0) || kind_ == 2 || (kind_ == 3 && sb_ == ndraw + nzp);
+    // one workgroup of each kind of spare job: start / end stamps 56 .. 63
+    const int kind_ = sb < ndraw ? 0 : sb < ndraw + npi ? 2 : sb < ndraw + npi + nzp ? 1 : 3;
+    const bool first_ = (sb == 0) || kind_ == 2 || (sb == ndraw + npi && nzp > 0) || (kind_ == 3 && sb == ndraw + npi + nzp);
     if (first_ && threadIdx.x == 0) c.dyn->stamps[56 + 2 * kind_] = wall_clock64();
 #endif
-    if (bx < nF + ndraw) job_hyper_draws(c, (bx - nF) * 256);
-    else if (bx < nF + ndraw + nzp) job_z_prepare(c, bx - nF - ndraw);      // (does not read pi / alpha_3: z_proposal.hpp)
-    else if (bx == nbx - 1 && (c.mask & (U_PI | U_ALPHA3))) { wait_pi(); job_pi_prepare(c); }
-    else job_chi_normals(c, bx - nF - ndraw - nzp);
+    if (sb < ndraw) job_hyper_draws(c, sb * 256);
+    else if (sb < ndraw + npi) { wait_pi(); job_pi_prepare(c); }
+    else if (sb < ndraw + npi + nzp) job_z_prepare(c, sb - ndraw - npi);      // (does not read pi / alpha_3: z_proposal.hpp)
+    else job_chi_normals(c, sb - ndraw - npi - nzp);
 #ifdef BFMMM_TIMELINE
     if (first_ && threadIdx.x == 0) c.dyn->stamps[57 + 2 * kind_] = wall_clock64();
 #endif
@@ -2095,7 +2101,7 @@ void launch_factor(const Ctx& c, hipStream_t st) {
   const int zcw = zprep_curves_per_wg(c.d.K);       // curves per workgroup of job_z_prepare (z_proposal.hpp)
   const int n_zprep = (c.mask & U_Z) ? (c.d.n + zcw - 1) / zcw : 0;      // (covariate-adjusted models too: the proposal does not see the data)
   const int n_znorm = ((c.mask & U_CHI) && c.d.MD > 1) ? (c.d.n * c.d.M + 255) / 256 : 0;
-  const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // the last workgroup: next iteration's pi / alpha_3 tables
+  const int n_pi = (c.mask & (U_PI | U_ALPHA3)) ? 1 : 0;          // next iteration's pi / alpha_3 tables (right behind the draws)
   const int grid = (diag ? 1 : 2) * c.d.A + (c.pi_in_factor ? 1 : 0) + (n_draw + 255) / 256 + n_zprep + n_znorm + n_pi;      // (k_factor: two workgroups per direction)
   if (PP == 32) launch_factor_pp<32>(c, grid, lds, st);
   else launch_factor_pp<64>(c, grid, lds, st);
