@@ -100,7 +100,9 @@ struct bfmmm_handle {
   struct GraphSet {
     hipGraphExec_t gN = nullptr, gFN = nullptr, gL = nullptr;
     hipGraphExec_t gR[NREM] = {}, gFR[NREM] = {};
-    template <typename F> void each(F f) { f(&gN); f(&gFN); f(&gL); for (int r = 0; r < NREM; ++r) { f(&gR[r]); f(&gFR[r]); } }
+    hipGraphExec_t gW = nullptr;      // a WHOLE short run (first Z, bodies, closing iteration, flush) of gW_n iterations
+    int gW_n = 0;
+    template <typename F> void each(F f) { f(&gN); f(&gFN); f(&gL); f(&gW); for (int r = 0; r < NREM; ++r) { f(&gR[r]); f(&gFR[r]); } }
   };
   static constexpr int MAX_SUB = 4;
   // packed partial tiles of k_pair_gram_pack, one buffer per sub-batch stream (+ one for the whole batch on one stream)
@@ -921,6 +923,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     tmark("run_begin queued");
   }
   if (h->profile && prepare_only) return 0;
+  bool whole_launched = false;      // the run went out as ONE graph that ends with the closing kernel (short runs, below)
   if (h->profile) {
     // the same kernels as the graph path (including the fused chi + next-Z launches), bracketed by events
     const bool pfuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
@@ -994,6 +997,10 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
       if (rem <= 0) return 0;
       return ensure(sb, &garr[rem], kind, rem);
     };
+    if (!h->status_host) {
+      HIPCHK(hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * (size_t)h->nch, hipHostMallocMapped));
+      if (hipHostGetDevicePointer((void**)&h->status_dev, h->status_host, 0) != hipSuccess) { (void)hipGetLastError(); h->status_dev = nullptr; }
+    }
     const bool fuse = plan.z && plan.z_update && plan.chi && c.d.D == 0 && n_iters >= 2 && tt_step == 0;
     // sweeps whose Z update cannot ride in k_curve_chi (no chi pass: the Nu_Z stage) still run it at the END of the previous
     // iteration's body, as the lean stand-alone kernel (kind 3 bodies)
@@ -1003,7 +1010,35 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     const bool bodies = fuse || defer;
     const int nrep = bodies ? n_iters - 1 : n_iters;                // fused / deferred run: n_iters - 1 bodies + the closing iteration
     const int nfull = nrep / GRAPH_UNROLL, rem = nrep % GRAPH_UNROLL;
-    for (int s = 0; s < nsub; ++s) {
+    // A SHORT run on one stream is ONE graph: the first Z update, the bodies, the closing iteration and the closing kernel --
+    // one graph launch instead of three and two kernel launches (a 20-iteration call: ~30 us of host time, 1.5 us per step).
+    // Keyed by the number of iterations (re-captured when it changes); BFMMM_WHOLE_GRAPH=0 switches it off.
+    static const int env_whole = getenv("BFMMM_WHOLE_GRAPH") ? atoi(getenv("BFMMM_WHOLE_GRAPH")) : 1;
+    constexpr int WHOLE_MAX = 64;
+    const bool whole = env_whole && bodies && nsub == 1 && n_iters <= WHOLE_MAX && c.defer_loglik && h->status_dev != nullptr;
+    if (whole) {
+      const Sub& sb = subs[0];
+      bfmmm_handle::GraphSet& g_ = h->gs[0];
+      if (g_.gW && g_.gW_n != n_iters) { (void)hipGraphExecDestroy(g_.gW); g_.gW = nullptr; }
+      if (!g_.gW) {
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(sb.st, hipStreamCaptureModeRelaxed));
+        launch_curve(sb.c, 0, plan.z_update, sb.st);              // Z of the first iteration
+        for (int r = 0; r < nrep; ++r) launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, true, body_kind == 1, body_kind == 3, sb.use_pack ? &sb.pk : nullptr, sb.pack, sb.slot);
+        launch_iteration(h, sb.c, plan, NKS, KS, sb.st, nullptr, true, false, false, sb.use_pack ? &sb.pk : nullptr, sb.pack, sb.slot);
+        launch_loglik_flush(c, sb.st, h->status_dev);
+        const hipError_t ec = hipStreamEndCapture(sb.st, &graph);
+        if (ec != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(ec); }
+        const hipError_t ei = hipGraphInstantiate(&g_.gW, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIPCHK(ei);
+        (void)hipGraphUpload(g_.gW, sb.st);
+        g_.gW_n = n_iters;
+        fresh.push_back({g_.gW, sb.st});
+      }
+    }
+    for (int s = 0; s < nsub && !whole; ++s) {
       const Sub& sb = subs[s];
       if (!bodies) {
         if ((nfull > 0 && ensure(sb, sb.gN, 0, GRAPH_UNROLL)) || ensure_rem(sb, sb.gR, 0, rem)) return 1;
@@ -1059,7 +1094,8 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
     }
     HIPCHK(hipEventRecord(h->ev0, h->st));
     for (int q = 1; q < nsub; ++q) { HIPCHK(hipEventRecord(h->evA, h->st)); HIPCHK(hipStreamWaitEvent(subs[q].st, h->evA, 0)); }      // k_run_begin first
-    for (int s = 0; s < nsub; ++s) {
+    if (whole) { HIPCHK(hipGraphLaunch(h->gs[0].gW, subs[0].st)); tmark("graph (whole run) queued"); whole_launched = true; }
+    for (int s = 0; s < nsub && !whole; ++s) {
       const Sub& sb = subs[s];
       if (!bodies) {
         for (int q = 0; q < nfull; ++q) HIPCHK(hipGraphLaunch(*sb.gN, sb.st));
@@ -1082,7 +1118,7 @@ static int run_impl(bfmmm_handle* h, uint32_t mask, int first_iter, int n_iters,
   // the status words reach the host from the run's last kernel when there is one that can carry them (the deferred
   // log-likelihood's flush; the fill kernels behind it never touch a status word), by a queued copy otherwise
   const bool status_by_kernel = c.defer_loglik && n_iters > 0 && h->status_dev != nullptr;
-  if (c.defer_loglik && n_iters > 0) launch_loglik_flush(c, h->st, status_by_kernel ? h->status_dev : nullptr);
+  if (c.defer_loglik && n_iters > 0 && !whole_launched) launch_loglik_flush(c, h->st, status_by_kernel ? h->status_dev : nullptr);      // (a whole-run graph ends with it)
   // chain slots of blocks this sweep does not touch hold the (constant) current value
   if (!(mask & U_Z)) launch_fill_slots(c, c.c_Z, c.Z, (size_t)c.d.n * c.d.K, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
   if (!plan.chi_update) launch_fill_slots(c, c.c_chi, c.chi, (size_t)c.d.n * c.d.M, first_iter - h->slot_base, first_iter - h->slot_base + n_iters, h->st);
