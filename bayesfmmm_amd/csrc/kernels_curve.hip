@@ -71,10 +71,16 @@ struct Tile {
   __host__ __device__ static constexpr int doubles(int rows) { return BW + rows * STR; }
   double* base;        // the first pad
   __device__ inline double* row(int r) const { return base + BW + r * STR; }
+  // (one store instruction per LPC pad entries: lane e takes entry e of the BW + rows (STR - LPC) pads.  A lane per gap column
+  //  and a loop over the rows was `rows` store instructions executed by three lanes -- an LDS store is 6 cycles of the pipe
+  //  whatever its mask, and the batches are bound by that pipe: 14 stores, 6 % of k_curve_chi's LDS time, now 2)
   __device__ inline void zero_pads(int rows, int lp) const {
-    for (int q = lp; q < BW; q += LPC) base[q] = 0.0;
-    for (int q = lp; q < STR - LPC; q += LPC)      // (a wide band has more pad entries than a 32-lane group has lanes)
-      for (int r = 0; r < rows; ++r) base[BW + r * STR + LPC + q] = 0.0;
+    constexpr int GAP = STR - LPC;
+    const int total = BW + rows * GAP;
+    for (int e = lp; e < total; e += LPC) {
+      const int g = e - BW, r = g / GAP, q = g - r * GAP;
+      base[(e < BW) ? e : (BW + r * STR + LPC + q)] = 0.0;
+    }
   }
 };
 
