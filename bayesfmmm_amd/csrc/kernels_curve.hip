@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
   }
   // ---- now the staged data: theta to LDS, the curve's s and chi to its tile ----
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
+  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (256 * u < nth) { if (idx < nth) sTh[idx] = thv[u]; } }      // (uniform test first: no store instruction for an empty trip)
   if (nth > 1024) copy_to_lds<4>(sTh + 1024, c.theta + 1024, nth - 1024, threadIdx.x, 256);
   if (D > 0) copy_to_lds<4>(sThX, c.thetaX, nth * D, threadIdx.x, 256);
   if (valid) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
   CT();                                              // (the Dyn head has arrived)
 #endif
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (idx < nth) sTh[idx] = thv[u]; }
+  for (int u = 0; u < 4; ++u) { const int idx = (int)threadIdx.x + 256 * u; if (256 * u < nth) { if (idx < nth) sTh[idx] = thv[u]; } }      // (uniform test first: no store instruction for an empty trip)
 #ifdef BFMMM_TIMELINE
   CT();                                              // (theta has arrived)
 #endif
