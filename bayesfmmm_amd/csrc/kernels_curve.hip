@@ -675,19 +675,20 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
         for (int m = 0; m < MT; ++m) mine = (lp == m) ? chn[m] : mine;
         if (lp < M) { c.chi[i + (size_t)n * lp] = mine; cslot[i + (size_t)n * lp] = mine; sChi[lp] = mine; }
       }
-      // rss(c0 + sum_m dl_m u_m) = rss0 + sum_m dl_m (-2 b_m + sum_m2 dl_m2 A_{m,m2}): one chain of M + 1 per m, then two of M / 2
+      // rss(c0 + sum_m dl_m u_m) = rss0 + sum_m dl_m (-2 b_m + sum_m2 dl_m2 A_{m,m2}).  Lane m forms the bracket of ITS m -- M + 1
+      // LDS read instructions for the wave instead of the M (M + 1) broadcast reads of every lane summing everything (the batches
+      // are bound by the LDS pipe) --, the M products meet in a DPP sum over the 16-lane row; only lane 0's rss is used below.
       {
-        double ra0 = 0.0, ra1 = 0.0;
+        const int ml = min(lp, M - 1);
+        double tm = -2.0 * lds_ld(sRes + nA + ml);
+        double dml = 0.0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (m < M) {
-            double tm = -2.0 * lds_ld(sRes + nA + m);
-#pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2)
-              if (m2 < M) tm += dl[m2] * lds_ld(sRes + tri_index(M, min(m, m2), max(m, m2)));
-            if (m & 1) ra1 += dl[m] * tm; else ra0 += dl[m] * tm;
+        for (int m2 = 0; m2 < MT; ++m2)
+          if (m2 < M) {
+            tm += dl[m2] * lds_ld(sRes + tri_index(M, min(ml, m2), max(ml, m2)));
+            dml = (lp == m2) ? dl[m2] : dml;
           }
-        rss += ra0 + ra1;
+        rss += row16_sum(dml * tm);                    // (lanes >= M contribute dml = 0)
       }
       if (D > 0 && act) {      // the eta / Xi steps start from the updated coefficient c_i and g_i = G_i c_i
         double cfin = tX.row(0)[lp], gfin = cv.s - tX.row(1)[lp];
