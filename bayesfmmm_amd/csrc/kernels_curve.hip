@@ -84,6 +84,18 @@ struct Tile {
   }
 };
 
+// the value lane m of a curve group holds, to every lane of the group (LPC = 32: two groups to a wave -- both source lanes are
+// read and each half of the wave keeps its own; v_readlane does not depend on EXEC)
+template <int LPC>
+__device__ inline double group_bcast(double v, int m) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo0 = __builtin_amdgcn_readlane(lo, m), hi0 = __builtin_amdgcn_readlane(hi, m);
+  if constexpr (LPC == 64) return __hiloint2double(hi0, lo0);
+  const int lo1 = __builtin_amdgcn_readlane(lo, 32 + m), hi1 = __builtin_amdgcn_readlane(hi, 32 + m);
+  const bool upper = (threadIdx.x & 32) != 0;
+  return __hiloint2double(upper ? hi1 : hi0, upper ? lo1 : lo0);
+}
+
 __device__ inline double dotP(const double* a, const double* b, int P) {
   double s = 0.0;
   for (int p = 0; p < P; ++p) s += a[p] * b[p];
@@ -638,57 +650,53 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
     rss = cv.yy - c0s - sRes[nA + Mu];
     if (Mu > 0) {
       // chi_m <- W_m w + sqrt(W_m) z_m,  W_m = 1 / (1 + A_mm beta / sigma^2),  w = (r_m + chi_m A_mm) beta / sigma^2,
-      // r_m = b_m - sum_{m2 < m} A_{m2,m} dl_m2  (UpdateChi.h:40-59 in Gram form).  Everything but r_m is known before the
-      // recursion, so lane m folds it into two constants for its m:  dl_m = chi_new - chi_old = c1_m r_m + c3_m  with
-      // c1 = W beta / sigma^2,  c3 = c1 chi_old A_mm + sqrt(W) z - chi_old  -- the wave pays ONE division and ONE square-root
-      // sequence, and a step of the recursion is two dependent operations instead of seven (a dependent double-precision
-      // operation issues every ~16 clocks: the M steps were 700 clocks of latency).
-      if (lp < M) {
-        const double W0l = sRes[tri_index(M, lp, lp)];
-        const double den = 1.0 + ((W0l * beta) * inv_s2);
-        const double Wl = 1.0 / den, sq = rsqrt(den);       // (both from den: the two sequences run side by side)
-        const double c1 = Wl * (beta * inv_s2);
-        sWq[lp] = c1; sWq[M + lp] = (c1 * chi_l) * W0l + (sq * zn_pre - chi_l);
+      // r_m = b_m - sum_{m2 < m} A_{m2,m} dl_m2  (UpdateChi.h:40-59 in Gram form).  LANE m OWNS DIRECTION m: it holds b_m, column m
+      // of A, chi_m, z_m and folds everything but r_m into two constants,  dl_m = chi_new - chi_old = c1_m r_m + c3_m  with
+      // c1 = W beta / sigma^2,  c3 = c1 chi_old A_mm + sqrt(W) z - chi_old  (one division and one rsqrt sequence per wave, side by
+      // side).  Step m of the recursion: every lane evaluates c1 r + c3 on its own r, lane m's value is the new dl_m and is handed
+      // to the group through v_readlane (two groups to a wave: both lanes are read, each half keeps its own), and the lanes
+      // behind m take A_{m,j} dl_m off their r_j.  The sums are those of the scalar recursion every lane used to run on broadcast
+      // LDS reads, term for term; the wave issues M + 1 LDS reads for recursion and residual together where it issued
+      // M (M + 1) / 2 + 4 M + M + 1 (the batches are bound by the LDS pipe), and two dependent operations per step remain.
+      const int ml = min(lp, M - 1);
+      const double bl = lds_ld(sRes + nA + ml);
+      double col[MT];                                  // A_{m2, ml}
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) {
+        const int mc = min(m2, M - 1);
+        const double v = lds_ld(sRes + tri_index(M, min(ml, mc), max(ml, mc)));
+        col[m2] = (m2 < M) ? v : 0.0;
       }
-      __builtin_amdgcn_wave_barrier();
-      // scalar Gauss-Seidel recursion over m (every lane runs it redundantly)
-      // (no LDS store inside the recursion: a store between two steps kept every later read of sRes / sWq behind it -- the
-      //  compiler must assume they alias -- so each of the M steps paid an LDS round trip on the chain; with the new values kept
-      //  in registers and stored afterwards, all the reads of the recursion are issued up front)
-      double dl[MT], chn[MT];
+      double W0l = 0.0;
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) W0l = (ml == m2) ? col[m2] : W0l;
+      const double den = 1.0 + ((W0l * beta) * inv_s2);
+      const double Wl = 1.0 / den, sq = rsqrt(den);       // (both from den: the two sequences run side by side)
+      const double c1 = Wl * (beta * inv_s2);
+      const double c3 = (c1 * chi_l) * W0l + (sq * zn_pre - chi_l);
+      double dl[MT];
       double* cslot = c.c_chi + (size_t)dh.slot_hyper * n * M;
+      double r = bl, own = 0.0;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        dl[m] = 0.0; chn[m] = 0.0;
+        dl[m] = 0.0;
         if (m < M) {
-          double r1 = lds_ld(sRes + nA + m);
-#pragma unroll
-          for (int m2 = 0; m2 < MT; ++m2)
-            if (m2 < m) r1 -= lds_ld(sRes + tri_index(M, m2, m)) * dl[m2];
-          dl[m] = lds_ld(sWq + m) * r1 + lds_ld(sWq + M + m);
-          chn[m] = lds_ld(sChi + m) + dl[m];
+          const double cand = c1 * r + c3;
+          own = (lp == m) ? cand : own;
+          dl[m] = group_bcast<LPC>(cand, m);
+          r -= col[m] * dl[m];
         }
       }
+      const double mine = chi_l + own;
+      if (lp < M) { c.chi[i + (size_t)n * lp] = mine; cslot[i + (size_t)n * lp] = mine; sChi[lp] = mine; }
+      // rss(c0 + sum_m dl_m u_m) = rss0 + sum_m dl_m (-2 b_m + sum_m2 dl_m2 A_{m,m2}): lane m forms the bracket of its m from the
+      // column it holds, the M products meet in a DPP sum over the 16-lane row; only lane 0's rss is used below
       {
-        double mine = 0.0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) mine = (lp == m) ? chn[m] : mine;
-        if (lp < M) { c.chi[i + (size_t)n * lp] = mine; cslot[i + (size_t)n * lp] = mine; sChi[lp] = mine; }
-      }
-      // rss(c0 + sum_m dl_m u_m) = rss0 + sum_m dl_m (-2 b_m + sum_m2 dl_m2 A_{m,m2}).  Lane m forms the bracket of ITS m -- M + 1
-      // LDS read instructions for the wave instead of the M (M + 1) broadcast reads of every lane summing everything (the batches
-      // are bound by the LDS pipe) --, the M products meet in a DPP sum over the 16-lane row; only lane 0's rss is used below.
-      {
-        const int ml = min(lp, M - 1);
-        double tm = -2.0 * lds_ld(sRes + nA + ml);
-        double dml = 0.0;
+        double tm = -2.0 * bl;
 #pragma unroll
         for (int m2 = 0; m2 < MT; ++m2)
-          if (m2 < M) {
-            tm += dl[m2] * lds_ld(sRes + tri_index(M, min(ml, m2), max(ml, m2)));
-            dml = (lp == m2) ? dl[m2] : dml;
-          }
-        rss += row16_sum(dml * tm);                    // (lanes >= M contribute dml = 0)
+          if (m2 < M) tm += dl[m2] * col[m2];
+        rss += row16_sum((lp < M) ? own * tm : 0.0);
       }
       if (D > 0 && act) {      // the eta / Xi steps start from the updated coefficient c_i and g_i = G_i c_i
         double cfin = tX.row(0)[lp], gfin = cv.s - tX.row(1)[lp];
