@@ -112,6 +112,41 @@ __device__ inline double dotL(const double* a, const double* b) {
   return s;
 }
 
+// The quadratic forms of the Z update into res: q < K: a_q = u_q's; then the pairs (k, k2), k <= k2: u_k'G u_k2 -- K + K (K + 1) / 2
+// of them (9 at K = 3).  One lane per form left two thirds of a 32-lane group idle through a full 2 LPC-read dot, and the
+// batches are bound by the LDS pipe: two lanes per form where they fit (lane 2 t + h takes entries [h LPC / 2, (h + 1) LPC / 2) of
+// form t, the halves meet by DPP), one lane per form otherwise (K >= 5 at 32 lanes).  Shared by k_curve_z, its lean form and the
+// fused update in k_curve_chi: the three produce the same bits.
+template <int BW, int LPC>
+__device__ inline void z_forms(const Tile<BW, LPC>& tU, const Tile<BW, LPC>& tG, const double* srow, int K, double* res, int lp) {
+  const int ntask = K + K * (K + 1) / 2;
+  auto rows = [&](int q, const double*& ra, const double*& rb) {
+    ra = tU.row(min(q, K - 1));
+    rb = srow;
+    if (q >= K) {
+      int a = 0, rem = q - K;
+      while (rem >= K - a) { rem -= K - a; ++a; }
+      ra = tU.row(a); rb = tG.row(a + rem);
+    }
+  };
+  if (2 * ntask <= LPC) {
+    const int t = lp >> 1, h = lp & 1;
+    if (t < ntask) {
+      const double *ra, *rb;
+      rows(t, ra, rb);
+      const double part = dot_half_lds<LPC>(ra + h * (LPC / 2), rb + h * (LPC / 2));
+      const double s = dpp_add<0xB1>(part);            // + the other half (lane ^ 1)
+      if (h == 0) res[t] = s;
+    }
+  } else {
+    for (int q = lp; q < ntask; q += LPC) {
+      const double *ra, *rb;
+      rows(q, ra, rb);
+      res[q] = dot_lds<LPC>(ra, rb);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Z update.  do_update == 0 only recomputes the partial sums of log Z (used when pi / alpha_3 are
 // sampled with Z held fixed).
@@ -300,18 +335,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : ((KT <= 4 && BW <= 5) ? 3 : 2)) voi
       for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
     ZT();
     __builtin_amdgcn_wave_barrier();
-    // tasks: q < K: a_q = u_q's ;  q >= K: pair (k,k2), k <= k2: u_k' G u_k2  -- one lane each
-    const int ntask = K + K * (K + 1) / 2;      // (K = 7, 8: 35, 44 tasks -- more than a 32-lane group has lanes)
-    for (int q = lp; q < ntask; q += LPC) {
-      const double* ra = tU.row(min(q, K - 1));
-      const double* rb = tS.row(0);
-      if (q >= K) {
-        int a = 0, rem = q - K;
-        while (rem >= K - a) { rem -= K - a; ++a; }
-        ra = tU.row(a); rb = tG.row(a + rem);
-      }
-      sRes[q] = dot_lds<LPC>(ra, rb);
-    }
+    z_forms<BW, LPC>(tU, tG, tS.row(0), K, sRes, lp);      // a_q = u_q's, Q_{k,k2} = u_k'G u_k2
     __builtin_amdgcn_wave_barrier();
     double av[KMAX], Q[KMAX][KMAX];
 #pragma unroll
@@ -743,17 +767,7 @@ __global__ __launch_bounds__(256) void k_curve_chi(Ctx c0, int mode) {
       if (!d.mv)
         for (int k = 0; k < K; ++k) tG.row(k)[lp] = cv.matvec(tU.row(k), lp);
       __builtin_amdgcn_wave_barrier();
-      const int nzt = K + K * (K + 1) / 2;       // q < K: a_q = u_q's ;  q >= K: pair (k, k2), k <= k2: u_k' G u_k2
-      for (int q = lp; q < nzt; q += LPC) {
-        const double* ra = tU.row(min(q, K - 1));
-        const double* rb = tU.row(K);
-        if (q >= K) {
-          int a = 0, rem = q - K;
-          while (rem >= K - a) { rem -= K - a; ++a; }
-          ra = tU.row(a); rb = tG.row(a + rem);
-        }
-        sRes[q] = dot_lds<LPC>(ra, rb);
-      }
+      z_forms<BW, LPC>(tU, tG, tU.row(K), K, sRes, lp);      // a_q = u_q's, Q_{k,k2} = u_k'G u_k2
       __builtin_amdgcn_wave_barrier();
       double qo = 0.0, qn = 0.0;                       // (as in k_curve_z: one short chain per k)
 #pragma unroll

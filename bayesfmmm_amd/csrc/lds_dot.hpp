@@ -252,6 +252,78 @@ __device__ __forceinline__ void dot32_lds(const double* a, const double* b, Dot4
   }
 }
 
+// the same over 16 entries (half a 32-entry row: the Z update's quadratic forms, two lanes per form)
+__device__ __forceinline__ void dot16_lds(const double* a, const double* b, Dot4& d) {
+  double t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
+  asm volatile(
+      "ds_read_b64 %4, %20 offset:0\n\t"
+      "ds_read_b64 %5, %21 offset:0\n\t"
+      "ds_read_b64 %6, %20 offset:8\n\t"
+      "ds_read_b64 %7, %21 offset:8\n\t"
+      "ds_read_b64 %8, %20 offset:16\n\t"
+      "ds_read_b64 %9, %21 offset:16\n\t"
+      "ds_read_b64 %10, %20 offset:24\n\t"
+      "ds_read_b64 %11, %21 offset:24\n\t"
+      "ds_read_b64 %12, %20 offset:32\n\t"
+      "ds_read_b64 %13, %21 offset:32\n\t"
+      "ds_read_b64 %14, %20 offset:40\n\t"
+      "ds_read_b64 %15, %21 offset:40\n\t"
+      "ds_read_b64 %16, %20 offset:48\n\t"
+      "ds_read_b64 %17, %21 offset:48\n\t"
+      "ds_read_b64 %18, %20 offset:56\n\t"
+      "ds_read_b64 %19, %21 offset:56\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_mul_f64 %0, %4, %5\n\t"
+      "v_mul_f64 %1, %6, %7\n\t"
+      "v_mul_f64 %2, %8, %9\n\t"
+      "v_mul_f64 %3, %10, %11\n\t"
+      "ds_read_b64 %4, %20 offset:64\n\t"
+      "ds_read_b64 %5, %21 offset:64\n\t"
+      "ds_read_b64 %6, %20 offset:72\n\t"
+      "ds_read_b64 %7, %21 offset:72\n\t"
+      "ds_read_b64 %8, %20 offset:80\n\t"
+      "ds_read_b64 %9, %21 offset:80\n\t"
+      "ds_read_b64 %10, %20 offset:88\n\t"
+      "ds_read_b64 %11, %21 offset:88\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_fma_f64 %0, %12, %13, %0\n\t"
+      "v_fma_f64 %1, %14, %15, %1\n\t"
+      "v_fma_f64 %2, %16, %17, %2\n\t"
+      "v_fma_f64 %3, %18, %19, %3\n\t"
+      "ds_read_b64 %12, %20 offset:96\n\t"
+      "ds_read_b64 %13, %21 offset:96\n\t"
+      "ds_read_b64 %14, %20 offset:104\n\t"
+      "ds_read_b64 %15, %21 offset:104\n\t"
+      "ds_read_b64 %16, %20 offset:112\n\t"
+      "ds_read_b64 %17, %21 offset:112\n\t"
+      "ds_read_b64 %18, %20 offset:120\n\t"
+      "ds_read_b64 %19, %21 offset:120\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_fma_f64 %0, %4, %5, %0\n\t"
+      "v_fma_f64 %1, %6, %7, %1\n\t"
+      "v_fma_f64 %2, %8, %9, %2\n\t"
+      "v_fma_f64 %3, %10, %11, %3\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_fma_f64 %0, %12, %13, %0\n\t"
+      "v_fma_f64 %1, %14, %15, %1\n\t"
+      "v_fma_f64 %2, %16, %17, %2\n\t"
+      "v_fma_f64 %3, %18, %19, %3\n\t"
+      : "=&v"(d.s0), "=&v"(d.s1), "=&v"(d.s2), "=&v"(d.s3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
+        "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(t10), "=&v"(t11), "=&v"(t12), "=&v"(t13), "=&v"(t14), "=&v"(t15)
+      : "v"(lds_addr(a)), "v"(lds_addr(b))
+      : "memory");
+}
+
+// sum over HALF a tile row (entries [0, LPC / 2) of the rows passed in): four partial sums as above
+template <int LPC>
+__device__ __forceinline__ double dot_half_lds(const double* a, const double* b) {
+  static_assert(LPC == 32 || LPC == 64, "a curve group is 32 or 64 lanes");
+  Dot4 d;
+  if constexpr (LPC == 64) dot32_lds<true>(a, b, d);
+  else dot16_lds(a, b, d);
+  return (d.s0 + d.s1) + (d.s2 + d.s3);
+}
+
 // sum over a whole tile row of LPC (32 or 64) entries
 template <int LPC>
 __device__ __forceinline__ double dot_lds(const double* a, const double* b) {

@@ -41,14 +41,14 @@ def _count(txt, mnemonic):
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
-@pytest.mark.parametrize("sym,max_read2,min_read1,min_dots", [(CHI, 40, 250, 2), (LEANZ, 40, 120, 1)])
-def test_per_curve_kernels_read_lds_with_single_b64_loads(tmp_path, sym, max_read2, min_read1, min_dots):
+@pytest.mark.parametrize("sym,max_read2,min_read1,min_waits", [(CHI, 40, 200, 10), (LEANZ, 40, 80, 3)])
+def test_per_curve_kernels_read_lds_with_single_b64_loads(tmp_path, sym, max_read2, min_read1, min_waits):
     txt, meta = _kernel(tmp_path, sym)
     n2, n1 = _count(txt, "ds_read2_b64"), _count(txt, "ds_read_b64")
     assert n2 <= max_read2, (sym, "ds_read2_b64", n2)      # (what is left: the scalar job's tables and a few staging reads)
     assert n1 >= min_read1, (sym, "ds_read_b64", n1)
-    # the hand-scheduled dot: 7 counted waits per 32-entry block (chi: the chi forms and the fused Z forms; lean Z: the Z forms)
-    assert txt.count("s_waitcnt lgkmcnt(8)") >= 7 * min_dots, sym
+    # the hand-scheduled dots: 7 counted waits per 32-entry block (the chi forms), 3 per 16-entry half row (the Z forms, two lanes each)
+    assert txt.count("s_waitcnt lgkmcnt(8)") >= min_waits, sym
     vg = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
     spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
     assert vg <= 128 and spill == 0, (sym, vg, spill)      # four workgroups (sixteen waves) per CU
